@@ -1,0 +1,71 @@
+"""Shared deterministic test objects (seeded random weights).  TEST INFRASTRUCTURE ONLY.
+
+No SD weights, tokenizer vocabulary or diffusers exist offline, so every parity test uses
+seeded random-init networks of the reference architecture.  Construction is deterministic
+for a given torch build (CPU mt19937 + default nn init), and each golden file stores a
+float64 checksum of the weights it was generated with so drift is detected, not ignored.
+"""
+from types import SimpleNamespace
+
+import torch
+import torch.nn.functional as F
+
+from .scheduler_ref import DDPMSchedulerRef
+from .text_ref import CLIPTextRef, HashTokenizerRef
+from .unet_ref import CONFIGS, UNet2DConditionRef
+
+
+class VAEStandIn(torch.nn.Module):
+    """Cold-path stand-in: the loop only needs config + decode() for preview PNGs
+    (training/sid_training_loop.py:254, 357-363; training/sid_sd_util.py:198-209)."""
+
+    def __init__(self):
+        super().__init__()
+        self.config = SimpleNamespace(block_out_channels=[128, 256, 512, 512], scaling_factor=0.18215, force_upcast=True)
+        self.post_quant_conv = torch.nn.Conv2d(4, 4, 1)
+
+    @property
+    def dtype(self):
+        return self.post_quant_conv.weight.dtype
+
+    def decode(self, z, return_dict=False):
+        img = F.interpolate(z[:, :3], scale_factor=8.0, mode='nearest').clamp(-1, 1)
+        return (img,)
+
+
+def text_stack(cfg_name, seed=4321):
+    cfg = CONFIGS[cfg_name]
+    g = torch.random.get_rng_state()
+    torch.manual_seed(seed)
+    if cfg_name in ('sd15',):
+        te = CLIPTextRef(768, 12, 12, 3072, max_pos=77)
+    elif cfg_name == 'sd21-base':
+        te = CLIPTextRef(1024, 23, 16, 4096, max_pos=77, act='gelu')
+    else:
+        te = CLIPTextRef(cfg.cross_attention_dim, 2, 2, 2 * cfg.cross_attention_dim, max_pos=cfg.text_len)
+    torch.random.set_rng_state(g)
+    tok = HashTokenizerRef(model_max_length=cfg.text_len, pad_token_id=49407 if cfg_name != 'sd21-base' else 0)
+    return te.eval().requires_grad_(False), tok
+
+
+def make_unet(cfg_name, seed=1234, perturb=0.0):
+    g = torch.random.get_rng_state()
+    torch.manual_seed(seed)
+    unet = UNet2DConditionRef(CONFIGS[cfg_name])
+    if perturb:
+        with torch.no_grad():
+            for p in unet.parameters():
+                p.add_(perturb * torch.randn_like(p))
+    torch.random.set_rng_state(g)
+    return unet
+
+
+def factory(cfg_name='tiny', seed=1234):
+    """Same 5-tuple as the reference's load_sd15 (training/sid_sd_util.py:118)."""
+    te, tok = text_stack(cfg_name)
+    return make_unet(cfg_name, seed), VAEStandIn(), DDPMSchedulerRef(), te, tok
+
+
+def checksum(module_or_tensors):
+    ts = list(module_or_tensors.parameters() if isinstance(module_or_tensors, torch.nn.Module) else module_or_tensors)
+    return float(sum(p.detach().double().sum() for p in ts)), float(sum(p.detach().double().abs().sum() for p in ts))

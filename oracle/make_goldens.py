@@ -1,0 +1,152 @@
+"""Generate tests/golden/*.npz by RUNNING THE REFERENCE (imported from /root/reference).
+
+Run in the authoring container only:  python -m oracle.make_goldens
+The reference itself never travels; only these small input/output vectors do.
+Every file records the weight checksum of the seeded random nets it was made with.
+
+  glue_*.npz   reference sid_sd_sampler / sid_sd_denoise (training/sid_sd_util.py:163-274)
+               on duck-typed oracle nets: pins rows A3, A4, A6 of SURVEY.md section 8.
+  loop_*.npz   the UNMODIFIED reference training_loop (training/sid_training_loop.py:148-672)
+               run for a few iterations on CPU: per-step loss values and final parameter
+               checksums: pins A1, A2, A7-A10, A13 (RNG order, accumulation, Adam, EMA).
+  bias_act.npz reference torch_utils/ops/bias_act.py::_bias_act_ref (+ autograd grads).
+  sampler.npz  reference torch_utils/misc.py::InfiniteSampler order.
+"""
+import os
+import sys
+import tempfile
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+
+from oracle import fixtures, ref_harness  # noqa: E402
+
+OUT = os.path.join(ROOT, 'tests', 'golden')
+PROMPTS = [
+    'a photo of a cat sitting on a sofa', 'an astronaut riding a horse', 'a bowl of fruit on a wooden table',
+    'mountains at sunset, oil painting', 'a red bicycle leaning on a wall', 'portrait of an old fisherman',
+    'a city street in the rain at night', 'two dogs playing in the snow', 'a cup of coffee and a book',
+    'a lighthouse on a cliff', 'sailing boats in a harbor', 'a field of sunflowers under blue sky',
+    'a steam train crossing a bridge', 'a child flying a kite', 'close-up of a dragonfly', 'a castle in the clouds',
+    'a bowl of ramen', 'a robot painting a picture', 'a forest path in autumn', 'a vintage car on route 66',
+]
+
+
+def gen_glue():
+    ref = ref_harness.import_reference()
+    for cfg_name, lat in (('tiny', 8), ('tiny40', 8)):
+        unet, vae, sched, te, tok = fixtures.factory(cfg_name)
+        unet2 = fixtures.make_unet(cfg_name, seed=99)
+        unet.eval().requires_grad_(False)
+        out = dict(cfg=cfg_name, weight_checksum=np.array(fixtures.checksum(unet)),
+                   weight_checksum2=np.array(fixtures.checksum(unet2)))
+        g = torch.Generator().manual_seed(7)
+        case = 0
+        for b in (1, 2):
+            prompts = PROMPTS[case:case + b]
+            z = torch.randn(b, 4, lat, lat, generator=g)
+            noise = torch.randn(b, 4, lat, lat, generator=g)
+            t = torch.randint(20, 980, (b,), generator=g)
+            init_t = torch.full((b,), 625, dtype=torch.long)
+            xhat = ref.sd_util.sid_sd_sampler(unet=unet, latents=z, contexts=prompts, init_timesteps=init_t,
+                                              noise_scheduler=sched, text_encoder=te, tokenizer=tok, resolution=lat * 8,
+                                              dtype=torch.float32, return_images=False, vae=None, num_steps=1)
+            out[f'b{b}_z'], out[f'b{b}_noise'], out[f'b{b}_t'] = z.numpy(), noise.numpy(), t.numpy()
+            out[f'b{b}_prompts'] = np.array(prompts)
+            out[f'b{b}_xhat'] = xhat.numpy()
+            for kappa in (1.0, 1.5, 4.5):
+                for px0 in (True, False):
+                    y = ref.sd_util.sid_sd_denoise(unet=unet2, images=xhat, noise=noise, contexts=prompts, timesteps=t,
+                                                   noise_scheduler=sched, text_encoder=te, tokenizer=tok,
+                                                   resolution=lat * 8, dtype=torch.float32, predict_x0=px0,
+                                                   guidance_scale=kappa)
+                    out[f'b{b}_k{kappa}_x0{int(px0)}'] = y.detach().numpy()
+            case += b
+        np.savez_compressed(os.path.join(OUT, f'glue_{cfg_name}.npz'), **out)
+        print('glue', cfg_name, 'done')
+
+
+def _run_loop(name, **kw):
+    with tempfile.TemporaryDirectory() as tmp:
+        pdir = os.path.join(tmp, 'prompts')
+        os.makedirs(pdir)
+        with open(os.path.join(pdir, 'aesthetics_6_plus.txt'), 'wt') as f:
+            f.write('\n'.join(PROMPTS) + '\n')
+        run_dir = os.path.join(tmp, 'run')
+        os.makedirs(run_dir)
+        cfg_name = kw.pop('cfg_name', 'tiny')
+        with ref_harness.cpu_process_group():
+            res = ref_harness.run_reference_training_loop(lambda: fixtures.factory(cfg_name), pdir, run_dir, **kw)
+    out = dict(cfg=cfg_name, prompts=np.array(PROMPTS),
+               loss_names=np.array([n for n, _ in res['losses']]),
+               loss_values=np.array([v for _, v in res['losses']], dtype=np.float64),
+               weight_checksum=np.array(fixtures.checksum(fixtures.make_unet(cfg_name))),
+               fake_score_checksum=np.array(fixtures.checksum(res['fake_score_params'])),
+               G_checksum=np.array(fixtures.checksum(res['G_params'])),
+               # a few raw parameter values for a sharper pin than the checksums
+               G_conv_in_w=res['G_params'][0].numpy(), fake_conv_in_w=res['fake_score_params'][0].numpy(),
+               G_last_b=res['G_params'][-1].numpy(), fake_last_b=res['fake_score_params'][-1].numpy())
+    for k, v in kw.items():
+        out['kw_' + k] = np.array(v)
+    np.savez_compressed(os.path.join(OUT, f'loop_{name}.npz'), **out)
+    print('loop', name, [f'{v:.6g}' for v in out['loss_values']])
+
+
+def gen_loops():
+    # kappa=1.5 everywhere (BASELINE config #1 setting), 2 accumulation rounds, alpha=1
+    _run_loop('k15_a1', iterations=4, batch_size=4, batch_gpu=2, seed=3, alpha=1.0, kappa=(1.5, 1.5, 1.5),
+              lr=1e-4, glr=1e-4, resolution=128)
+    # no guidance (kappa=1: single-branch path, no prompt dropout), alpha=1.2 general branch, default lrs
+    _run_loop('k1_a12', iterations=3, batch_size=2, batch_gpu=2, seed=5, alpha=1.2, kappa=(1.0, 1.0, 1.0),
+              lr=1e-5, glr=1e-5, resolution=128)
+    # kappa 4.5 (BASELINE config #3 guidance), batch_gpu 1
+    _run_loop('k45_a1', iterations=3, batch_size=2, batch_gpu=1, seed=11, alpha=1.0, kappa=(4.5, 4.5, 4.5),
+              lr=1e-4, glr=1e-4, resolution=128)
+
+
+def gen_bias_act():
+    ref = ref_harness.import_reference()
+    g = torch.Generator().manual_seed(3)
+    out = {}
+    x = torch.randn(2, 40, 3, 5, generator=g)
+    b = torch.randn(40, generator=g)
+    dy = torch.randn(2, 40, 3, 5, generator=g)
+    out['x'], out['b'], out['dy'] = x.numpy(), b.numpy(), dy.numpy()
+    for act in ref.bias_act.activation_funcs.keys():
+        for gain, clamp in ((None, None), (1.0, None), (1.5, 0.7)):
+            xx = x.clone().requires_grad_(True)
+            bb = b.clone().requires_grad_(True)
+            y = ref.bias_act._bias_act_ref(xx, bb, dim=1, act=act, gain=gain, clamp=clamp)
+            dx, db = torch.autograd.grad(y, [xx, bb], dy)
+            key = f'{act}_g{gain}_c{clamp}'
+            out[key + '_y'], out[key + '_dx'], out[key + '_db'] = y.detach().numpy(), dx.numpy(), db.numpy()
+    np.savez_compressed(os.path.join(OUT, 'bias_act.npz'), **out)
+    print('bias_act done')
+
+
+def gen_sampler():
+    ref = ref_harness.import_reference()
+    out = {}
+    for n, rank, world, seed in ((20, 0, 1, 0), (20, 1, 2, 3), (7, 2, 4, 9)):
+        it = iter(ref.misc.InfiniteSampler(dataset=list(range(n)), rank=rank, num_replicas=world, seed=seed))
+        out[f'n{n}_r{rank}_w{world}_s{seed}'] = np.array([int(next(it)) for _ in range(64)])
+    np.savez_compressed(os.path.join(OUT, 'sampler.npz'), **out)
+    print('sampler done')
+
+
+if __name__ == '__main__':
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(8)
+    which = sys.argv[1:] or ['glue', 'loops', 'bias_act', 'sampler']
+    if 'glue' in which:
+        gen_glue()
+    if 'bias_act' in which:
+        gen_bias_act()
+    if 'sampler' in which:
+        gen_sampler()
+    if 'loops' in which:
+        gen_loops()
