@@ -1,0 +1,136 @@
+/* sidlsg_hip.h -- C ABI of libsidlsg_hip.so: the MI355X (gfx950) kernels of the SiD-LSG
+ * distillation inner step.  Plain pointers and sizes only (device pointers unless noted);
+ * `stream` is a hipStream_t passed as void*.  Every function returns 0 on success, a positive
+ * hipError_t if the launch failed, or -22 (EINVAL) if the arguments violate the stated
+ * constraints.  No function allocates, synchronises or touches the host heap, so all of them may
+ * be captured into a HIP graph.
+ *
+ * What each entry point replaces in the reference (paths relative to mingyuanzhou/SiD-LSG):
+ * the reference has no native code on this path -- every op below is executed there by
+ * diffusers/ATen kernels reached through `unet(...).sample` (training/sid_sd_util.py:184,194,
+ * 245,263), `torch.optim.Adam.step` (training/sid_training_loop.py:462,549) and inline torch
+ * expressions in the loop.  Its only native-operator seam is the plugin API of
+ * torch_utils/custom_ops.py:46 + torch_utils/ops/bias_act.cpp:32-97, which sidlsg_bias_act
+ * mirrors.  Activations are NHWC bf16 ([tokens][channels], channels contiguous); conv weights
+ * are [Cout][3][3][Cin] (= torch channels_last storage of the diffusers [Cout][Cin][3][3]
+ * parameter); parameters, statistics, losses and gradients of parameters are fp32.
+ */
+#ifndef SIDLSG_HIP_H
+#define SIDLSG_HIP_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* epilogue flags of the GEMM / conv entry points */
+#define SIDLSG_OUT_F32 1 /* C is fp32 instead of bf16 */
+#define SIDLSG_SILU 2    /* y = silu(...) */
+#define SIDLSG_ACCUM 4   /* C += ... (fp32 only) */
+
+/* ---- contractions (MFMA bf16 -> fp32) ------------------------------------------------------
+ * torch.nn.functional.linear / conv2d(k=1) inside diffusers Attention / FeedForward /
+ * Transformer2DModel / ResnetBlock2D.time_emb_proj / conv_shortcut (call site sid_sd_util.py:184).
+ * C[M][ldc] = act(alpha * A[M][K] W[N][K]^T + bias[N] + rowvec[m/rows_per_batch][N] + res[M][ldres])
+ * K, lda multiples of 8.  bias/res/rowvec may be NULL. */
+int sidlsg_gemm_bf16(const void* A, int lda, const void* W, void* C, int ldc, const float* bias, const void* res, int ldres,
+                     const float* rowvec, int rows_per_batch, int M, int N, int K, float alpha, int flags, void* stream);
+
+/* torch conv2d(k=3, pad=1, stride 1|2) of ResnetBlock2D.conv1/conv2, Downsample2D, Upsample2D
+ * (ups=1 fuses the nearest x2 interpolate), conv_in/conv_out.  X: [B][Hs][Ws][ldx] with the virtual
+ * (post-upsample) size H x Wd; W: [Cout][3][3][Cin]; Y: [B][Ho][Wo][ldc].  Same epilogue as the GEMM;
+ * rowvec is the per-sample time-embedding projection [B][Cout].  Cin, ldx multiples of 8.
+ * The backward-data pass is the same entry point fed with dY and the transposed/flipped weights
+ * made by sidlsg_transpose_w. */
+int sidlsg_conv3x3_bf16(const void* X, int ldx, const void* W, void* Y, int ldc, const float* bias, const void* res, int ldres,
+                        const float* rowvec, int B, int H, int Wd, int Cin, int Cout, int stride, int ups, float alpha,
+                        int flags, void* stream);
+
+/* weight gradients (autograd of the two ops above in the reference: loss.backward(),
+ * sid_training_loop.py:450,533).  dW[N][K] += dY[M][N]^T A[M][K], fp32 atomics. */
+int sidlsg_wgrad_bf16(const void* dY, int ldy, const void* A, int lda, float* dW, int M, int N, int K, void* stream);
+int sidlsg_conv3x3_wgrad_bf16(const void* dY, int ldy, const void* X, int ldx, float* dW, int B, int H, int Wd, int Cin,
+                              int Cout, int stride, int ups, void* stream);
+
+/* ---- normalisation (HBM bound) ------------------------------------------------------------
+ * torch.nn.GroupNorm(32, C, eps)+SiLU of ResnetBlock2D.norm1/norm2, Transformer2DModel.norm,
+ * conv_norm_out; torch.nn.LayerNorm of BasicTransformerBlock.norm1-3. */
+int sidlsg_groupnorm_ws_floats(int B, int HW, int C, int G); /* host: workspace size in floats, <0 on bad shape */
+int sidlsg_groupnorm_nchunks(int B, int HW, int C, int G);   /* host */
+int sidlsg_groupnorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* stats, float* ws, int B,
+                         int HW, int C, int G, float eps, int silu, void* stream);
+int sidlsg_groupnorm_bwd(const void* x, const void* dy, const float* stats, const float* gamma, const float* beta, void* dx,
+                         float* dgamma, float* dbeta, float* ws, int B, int HW, int C, int G, int silu, void* stream);
+int sidlsg_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* stats, int rows, int C,
+                         float eps, void* stream);
+int sidlsg_layernorm_bwd_nblocks(int rows); /* host: ws = nblocks*C*2 floats */
+int sidlsg_layernorm_bwd(const void* x, const void* dy, const float* stats, const float* gamma, void* dx, float* dgamma,
+                         float* dbeta, float* ws, int rows, int C, void* stream);
+
+/* ---- attention (diffusers Attention + AttnProcessor2_0 / xformers; sid_sd_util.py:102-113) --
+ * O = softmax(Q K^T D^-1/2) V per head; Q/K/V/O are strided views ([b][token][h*D + d], token
+ * stride ld*, batch stride bs*, in elements) so the fused QKV projection is consumed in place.
+ * D multiple of 8, <= 160.  LSE [B][H][Nq] fp32 (log2 domain) is saved for backward. */
+int sidlsg_attn_fwd(const void* Q, const void* K, const void* V, void* O, float* LSE, int B, int H, int Nq, int Nk, int D,
+                    int ldq, int ldk, int ldv, int ldo, long long bsq, long long bsk, long long bsv, long long bso,
+                    void* stream);
+int sidlsg_attn_bwd(const void* Q, const void* K, const void* V, const void* O, const void* dO, const float* LSE, void* dQ,
+                    void* dK, void* dV, float* delta, int B, int H, int Nq, int Nk, int D, int ldq, int ldk, int ldv, int ldo,
+                    long long bsq, long long bsk, long long bsv, long long bso, void* stream);
+
+/* ---- scheduler / guidance glue (sid_sd_util.py:182-185, 242, 259-272) ----------------------
+ * noisy_input: x_t = s0[b]*x0 + s1[b]*noise (x0 NULL -> zeros: the one-step generator input),
+ *   NCHW fp32 in, NHWC bf16 [dup*B][HW][Cp] out (dup=2: [uncond ; cond] halves of the CFG batch),
+ *   optional fp32 NCHW copy of x_t.
+ * cfg_x0: eps [dup*B][HW][Ce>=C] fp32 -> out NCHW fp32 = predict_x0 ? (x_t - s1*e)/s0 : e with
+ *   e = u + kappa*(c-u) when dup=2. */
+int sidlsg_noisy_input(const float* x0, const float* noise, const float* s0, const float* s1, void* out, float* xt, int B,
+                       int C, int HW, int Cp, int dup, void* stream);
+int sidlsg_noisy_input_bwd(const void* g, const float* s0, float* dx0, int B, int C, int HW, int Cp, int dup, int accumulate,
+                           void* stream);
+int sidlsg_cfg_x0(const float* eps, const float* xt, const float* s0, const float* s1, float* out, int B, int C, int HW,
+                  int Ce, int dup, float kappa, int predict_x0, void* stream);
+int sidlsg_cfg_x0_bwd(const float* g, const float* s0, const float* s1, void* deps, float* dxt, int B, int C, int HW, int Cp,
+                      int dup, float kappa, int predict_x0, void* stream);
+
+/* ---- losses with closed-form gradients (sid_training_loop.py:423-445, 508-530) -------------
+ * Per-sample NaN filtering is done in-kernel (a sample containing NaN contributes 0 and gets zero
+ * gradients), `scale` = loss_scaling / batch_gpu_total.  ws >= 2*S + 8*S floats.  loss: 1 float. */
+int sidlsg_g_loss(const float* x, const float* yr, const float* yf, float* dx, float* dyr, float* dyf, float* loss, float* ws,
+                  int S, int n, float alpha, float scale, void* stream);
+int sidlsg_fake_loss(const float* e, const float* noise, float* de, float* loss, float* ws, int S, int n, float scale,
+                     void* stream);
+
+/* ---- optimizer: nan_to_num + clip + Adam/AdamW + EMA + bf16 weight copy + zero_grad --------
+ * (sid_training_loop.py:458-462, 541-565; sid_train.py:219-226).  hyper: 11 floats in DEVICE memory:
+ * lr, beta1, beta2, eps, bias_corr1, sqrt(bias_corr2), ema_beta, weight_decay, decoupled, clip, grad_scale.
+ * m may be NULL when beta1 == 0; ema, w_bf16 may be NULL. */
+int sidlsg_adam_ema(float* p, float* g, float* m, float* v, float* ema, void* w_bf16, const float* hyper, long long n,
+                    int zero_grad, void* stream);
+
+/* ---- small elementwise / layout kernels ---------------------------------------------------- */
+int sidlsg_timestep_embed(const long long* t, void* out, int B, int dim, void* stream); /* Timesteps(flip_sin_to_cos) */
+int sidlsg_silu_fwd(const void* x, void* y, long long n, void* stream);
+int sidlsg_silu_bwd(const void* x, const void* dy, void* dx, long long n, void* stream);
+int sidlsg_geglu_fwd(const void* h, void* y, long long M, int F, void* stream);           /* diffusers GEGLU */
+int sidlsg_geglu_bwd(const void* h, const void* dy, void* dh, long long M, int F, void* stream);
+int sidlsg_concat2(void* a, void* b, void* out, long long M, int C1, int C2, int to_parts, void* stream); /* skip concat */
+int sidlsg_sumpool2x2(const void* g, void* out, int B, int H, int W, int C, void* stream);   /* bwd of nearest x2 */
+int sidlsg_zero_insert2(const void* g, void* out, int B, int Ho, int Wo, int H, int W, int C, void* stream); /* bwd-data of stride 2: out [B][H][W][C] */
+int sidlsg_add_bf16(const void* a, const void* b, void* o, long long n, void* stream);
+int sidlsg_colsum_nchunks(int B, int rows_per_batch); /* host: ws = B*nchunks*N floats */
+int sidlsg_colsum(const void* g, int ldg, float* per_batch, float* total, float* ws, int B, int rows_per_batch, int N,
+                  void* stream); /* bias / time-embedding gradients */
+int sidlsg_cast_f32_bf16(const float* x, void* y, long long n, void* stream);
+int sidlsg_cast_bf16_f32(const void* x, float* y, long long n, void* stream);
+int sidlsg_transpose_w(const float* src, void* dst, int N, int K, int T, void* stream); /* [N][T][K] -> [K][T rev][N] bf16 */
+
+/* ---- reference plugin op: torch_utils/ops/bias_act.cpp:32 `bias_act(x,b,xref,yref,dy,grad,dim,act,alpha,gain,clamp)`
+ * act: 1 linear 2 relu 3 lrelu 4 tanh 5 sigmoid 6 elu 7 selu 8 softplus 9 swish (bias_act.py:23-33).
+ * grad 0: out = clamp(act(x + b[(i/stepB)%sizeB]) * gain); grad 1: out = dL/dx from dy (x, b = saved inputs).
+ * dtype 0 fp32, 1 bf16. */
+int sidlsg_bias_act(const void* x, const void* b, const void* dy, void* out, long long n, int stepB, int sizeB, int act,
+                    float alpha, float gain, float clamp, int grad, int dtype, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,556 @@
+// Memory-bound elementwise / layout / reduction kernels of the SiD-LSG step (gfx950).
+// All bf16 traffic is 16 bytes per lane; fp32 math inside.
+#include "common.h"
+
+#define GRID1D(n, per) dim3((unsigned)((((size_t)(n)) + (per) - 1) / (per)))
+
+// ---- layout ---------------------------------------------------------------------------------
+// x_t = s0[b]*x0 + s1[b]*noise (x0 may be null), written as NHWC bf16 with Cp (>=C, mult of 8)
+// channels (zero padded), replicated `dup` times along batch (CFG: [uncond ; cond] share x_t).
+// Also optionally stores x_t in fp32 NCHW (needed later for the x0 prediction).
+__global__ void noisy_input_kernel(const float* __restrict__ x0, const float* __restrict__ noise,
+                                   const float* __restrict__ s0, const float* __restrict__ s1,
+                                   bf16* __restrict__ out, float* __restrict__ xt, int B, int C, int HW, int Cp, int dup) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;  // over B*HW
+    if (idx >= B * HW) return;
+    const int b = idx / HW, p = idx - b * HW;
+    bf16x8 o = zero8();
+    for (int c = 0; c < C; c++) {
+        const size_t i = ((size_t)b * C + c) * HW + p;
+        float v = s1[b] * noise[i];
+        if (x0) v += s0[b] * x0[i];
+        if (xt) xt[i] = v;
+        o[c] = f2bf(v);
+    }
+    for (int d = 0; d < dup; d++) {
+        bf16* dst = out + ((size_t)(d * B + b) * HW + p) * Cp;
+        st8(dst, o);
+        for (int c = 8; c < Cp; c += 8) st8(dst + c, zero8());
+    }
+}
+
+// d_x0[b,c,p] = s0[b] * sum_d g[(d*B+b), p, c]   (backward of noisy_input wrt x0); g NHWC bf16
+__global__ void noisy_input_bwd_kernel(const bf16* __restrict__ g, const float* __restrict__ s0, float* __restrict__ dx0,
+                                       int B, int C, int HW, int Cp, int dup, int accumulate) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= B * HW) return;
+    const int b = idx / HW, p = idx - b * HW;
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int d = 0; d < dup; d++) {
+        const bf16x8 v = ld8(g + ((size_t)(d * B + b) * HW + p) * Cp);
+        for (int c = 0; c < 8; c++) acc[c] += bf2f(v[c]);
+    }
+    for (int c = 0; c < C; c++) {
+        const size_t i = ((size_t)b * C + c) * HW + p;
+        const float v = s0[b] * acc[c];
+        dx0[i] = accumulate ? dx0[i] + v : v;
+    }
+}
+
+// CFG combine + optional x0 prediction.  eps: [dup*B][HW][C] fp32 (NHWC, uncond first).
+// out (NCHW fp32) = predict_x0 ? (x_t - s1*e)/s0 : e,   e = dup==2 ? u + kappa*(c-u) : eps
+__global__ void cfg_x0_kernel(const float* __restrict__ eps, const float* __restrict__ xt, const float* __restrict__ s0,
+                              const float* __restrict__ s1, float* __restrict__ out, int B, int C, int HW, int Ce, int dup,
+                              float kappa, int predict_x0) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;  // over B*HW
+    if (idx >= B * HW) return;
+    const int b = idx / HW, p = idx - b * HW;
+    for (int c = 0; c < C; c++) {
+        float e = eps[((size_t)b * HW + p) * Ce + c];
+        if (dup == 2) { const float cnd = eps[((size_t)(B + b) * HW + p) * Ce + c]; e = e + kappa * (cnd - e); }
+        const size_t i = ((size_t)b * C + c) * HW + p;
+        out[i] = predict_x0 ? (xt[i] - s1[b] * e) / s0[b] : e;
+    }
+}
+
+// backward of cfg_x0: d_eps (NHWC bf16 [dup*B][HW][Cp], zero padded) and, when predict_x0, d_xt = g/s0 (fp32 NCHW)
+__global__ void cfg_x0_bwd_kernel(const float* __restrict__ g, const float* __restrict__ s0, const float* __restrict__ s1,
+                                  bf16* __restrict__ deps, float* __restrict__ dxt, int B, int C, int HW, int Cp, int dup,
+                                  float kappa, int predict_x0) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= B * HW) return;
+    const int b = idx / HW, p = idx - b * HW;
+    bf16x8 du = zero8(), dc = zero8();
+    for (int c = 0; c < C; c++) {
+        const size_t i = ((size_t)b * C + c) * HW + p;
+        const float go = g[i];
+        const float ge = predict_x0 ? -go * s1[b] / s0[b] : go;
+        if (dxt) dxt[i] = predict_x0 ? go / s0[b] : 0.f;
+        if (dup == 2) { du[c] = f2bf((1.f - kappa) * ge); dc[c] = f2bf(kappa * ge); }
+        else du[c] = f2bf(ge);
+    }
+    bf16* d0 = deps + ((size_t)b * HW + p) * Cp;
+    st8(d0, du);
+    for (int c = 8; c < Cp; c += 8) st8(d0 + c, zero8());
+    if (dup == 2) {
+        bf16* d1 = deps + ((size_t)(B + b) * HW + p) * Cp;
+        st8(d1, dc);
+        for (int c = 8; c < Cp; c += 8) st8(d1 + c, zero8());
+    }
+}
+
+// ---- timestep embedding: [cos | sin] of t * exp(-ln(1e4) * i/half), bf16 [B][dim] -----------
+__global__ void timestep_embed_kernel(const long long* __restrict__ t, bf16* __restrict__ out, int B, int dim) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int half = dim >> 1;
+    if (idx >= B * half) return;
+    const int b = idx / half, i = idx - b * half;
+    const float freq = expf(-9.210340371976184f * (float)i / (float)half);
+    const float a = (float)t[b] * freq;
+    out[(size_t)b * dim + i] = f2bf(cosf(a));
+    out[(size_t)b * dim + half + i] = f2bf(sinf(a));
+}
+
+// ---- activations ----------------------------------------------------------------------------
+__global__ void silu_fwd_kernel(const bf16* __restrict__ x, bf16* __restrict__ y, size_t n8) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n8) return;
+    const bf16x8 v = ld8(x + i * 8);
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; e++) o[e] = f2bf(silu_f(bf2f(v[e])));
+    st8(y + i * 8, o);
+}
+__global__ void silu_bwd_kernel(const bf16* __restrict__ x, const bf16* __restrict__ dy, bf16* __restrict__ dx, size_t n8) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n8) return;
+    const bf16x8 v = ld8(x + i * 8), d = ld8(dy + i * 8);
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; e++) o[e] = f2bf(bf2f(d[e]) * silu_grad_f(bf2f(v[e])));
+    st8(dx + i * 8, o);
+}
+
+// GEGLU: h [M][2F] -> y [M][F] = h[:, :F] * gelu(h[:, F:])
+__global__ void geglu_fwd_kernel(const bf16* __restrict__ h, bf16* __restrict__ y, size_t M, int F) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int F8 = F >> 3;
+    if (i >= M * F8) return;
+    const size_t m = i / F8; const int c = (int)(i - m * F8) * 8;
+    const bf16x8 a = ld8(h + m * 2 * F + c), g = ld8(h + m * 2 * F + F + c);
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; e++) o[e] = f2bf(bf2f(a[e]) * gelu_f(bf2f(g[e])));
+    st8(y + m * F + c, o);
+}
+__global__ void geglu_bwd_kernel(const bf16* __restrict__ h, const bf16* __restrict__ dy, bf16* __restrict__ dh, size_t M, int F) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int F8 = F >> 3;
+    if (i >= M * F8) return;
+    const size_t m = i / F8; const int c = (int)(i - m * F8) * 8;
+    const bf16x8 a = ld8(h + m * 2 * F + c), g = ld8(h + m * 2 * F + F + c), d = ld8(dy + m * F + c);
+    bf16x8 da, dg;
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+        const float gf = bf2f(g[e]), df = bf2f(d[e]);
+        da[e] = f2bf(df * gelu_f(gf));
+        dg[e] = f2bf(df * bf2f(a[e]) * gelu_grad_f(gf));
+    }
+    st8(dh + m * 2 * F + c, da);
+    st8(dh + m * 2 * F + F + c, dg);
+}
+
+// ---- channel concat / split (NHWC) ----------------------------------------------------------
+// out[m][0:C1]=a[m], out[m][C1:C1+C2]=b[m]   (split = same kernel with to_parts=1)
+__global__ void concat2_kernel(bf16* __restrict__ a, bf16* __restrict__ b, bf16* __restrict__ out, size_t M, int C1, int C2,
+                               int to_parts) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int C8 = (C1 + C2) >> 3;
+    if (i >= M * C8) return;
+    const size_t m = i / C8; const int c = (int)(i - m * C8) * 8;
+    bf16* part = c < C1 ? a + m * C1 + c : b + m * C2 + (c - C1);
+    bf16* full = out + m * (C1 + C2) + c;
+    if (to_parts) st8(part, ld8(full)); else st8(full, ld8(part));
+}
+
+// backward of nearest x2 upsample: out[b][h][w][c] = sum of the 2x2 block of g [b][2h..][2w..][c]
+__global__ void sumpool2x2_kernel(const bf16* __restrict__ g, bf16* __restrict__ out, int B, int H, int W, int C) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int C8 = C >> 3;
+    if (i >= (size_t)B * H * W * C8) return;
+    const int c = (int)(i % C8) * 8; size_t r = i / C8;
+    const int w = (int)(r % W); r /= W; const int h = (int)(r % H); const int b = (int)(r / H);
+    const bf16* s = g + (((size_t)b * 2 * H + 2 * h) * 2 * W + 2 * w) * C + c;
+    const bf16x8 v0 = ld8(s), v1 = ld8(s + C), v2 = ld8(s + (size_t)2 * W * C), v3 = ld8(s + (size_t)2 * W * C + C);
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; e++) o[e] = f2bf(bf2f(v0[e]) + bf2f(v1[e]) + bf2f(v2[e]) + bf2f(v3[e]));
+    st8(out + (((size_t)b * H + h) * W + w) * C + c, o);
+}
+
+// zero insertion (backward-data of a stride-2 conv): out [B][H][W][C], out[2h][2w]=g[h][w], else 0
+// (H = 2Ho or 2Ho-1: the original input size of the strided conv)
+__global__ void zero_insert2_kernel(const bf16* __restrict__ g, bf16* __restrict__ out, int B, int Ho, int Wo, int H, int W, int C) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int C8 = C >> 3;
+    if (i >= (size_t)B * H * W * C8) return;
+    const int c = (int)(i % C8) * 8; size_t r = i / C8;
+    const int w = (int)(r % W); r /= W; const int h = (int)(r % H); const int b = (int)(r / H);
+    bf16x8 v = zero8();
+    if (!(h & 1) && !(w & 1)) v = ld8(g + (((size_t)b * Ho + (h >> 1)) * Wo + (w >> 1)) * C + c);
+    st8(out + (((size_t)b * H + h) * W + w) * C + c, v);
+}
+
+__global__ void add_bf16_kernel(const bf16* __restrict__ a, const bf16* __restrict__ b, bf16* __restrict__ o, size_t n8) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n8) return;
+    const bf16x8 x = ld8(a + i * 8), y = ld8(b + i * 8);
+    bf16x8 r;
+#pragma unroll
+    for (int e = 0; e < 8; e++) r[e] = f2bf(bf2f(x[e]) + bf2f(y[e]));
+    st8(o + i * 8, r);
+}
+
+// ---- column sums: part[b][chunk][N] = sum over the chunk's rows of g[b][row][N] -------------
+// 256 threads; columns are walked in passes of cpp 8-wide chunks, rows split over 256/cpp lanes.
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const bf16* __restrict__ g, float* __restrict__ part,
+                                                             int rows_per_batch, int N, int ldg, int rows_per_chunk, int nch) {
+    __shared__ float sm[256 * 8];
+    const int N8 = N >> 3;
+    const int cpp = N8 < 256 ? N8 : 256;
+    const int rows = 256 / cpp;
+    const int ci = threadIdx.x % cpp, rl = threadIdx.x / cpp;
+    const int b = blockIdx.y, chunk = blockIdx.x;
+    const int r0 = chunk * rows_per_chunk, r1 = min(rows_per_batch, r0 + rows_per_chunk);
+    for (int c0 = 0; c0 < N8; c0 += cpp) {
+        const int cc = c0 + ci;
+        float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (rl < rows && cc < N8)
+            for (int r = r0 + rl; r < r1; r += rows) {
+                const bf16x8 v = ld8(g + ((size_t)b * rows_per_batch + r) * ldg + cc * 8);
+#pragma unroll
+                for (int e = 0; e < 8; e++) s[e] += bf2f(v[e]);
+            }
+        __syncthreads();
+        if (rl < rows)
+#pragma unroll
+            for (int e = 0; e < 8; e++) sm[(rl * cpp + ci) * 8 + e] = s[e];
+        __syncthreads();
+        for (int i = threadIdx.x; i < cpp * 8; i += 256) {
+            if (c0 * 8 + i >= N) continue;
+            float t = 0.f;
+            for (int r = 0; r < rows; r++) t += sm[r * cpp * 8 + i];
+            part[((size_t)b * nch + chunk) * N + c0 * 8 + i] = t;
+        }
+    }
+}
+// out[b][n] (+)= sum_chunk part[b][chunk][n] ; and/or total[n] += sum_b sum_chunk
+__global__ void colsum_final_kernel(const float* __restrict__ part, float* __restrict__ per_batch, float* __restrict__ total,
+                                    int B, int nch, int N) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    float tot = 0.f;
+    for (int b = 0; b < B; b++) {
+        float t = 0.f;
+        for (int k = 0; k < nch; k++) t += part[((size_t)b * nch + k) * N + n];
+        if (per_batch) per_batch[(size_t)b * N + n] = t;
+        tot += t;
+    }
+    if (total) total[n] += tot;
+}
+
+// ---- weights: fp32 master -> bf16 compute copies ---------------------------------------------
+__global__ void cast_f32_bf16_kernel(const float* __restrict__ x, bf16* __restrict__ y, size_t n) {
+    const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 8;
+    if (i + 8 <= n) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(x + i), b = *reinterpret_cast<const f32x4*>(x + i + 4);
+        bf16x8 o = {f2bf(a[0]), f2bf(a[1]), f2bf(a[2]), f2bf(a[3]), f2bf(b[0]), f2bf(b[1]), f2bf(b[2]), f2bf(b[3])};
+        st8(y + i, o);
+    } else {
+        for (size_t j = i; j < n; j++) y[j] = f2bf(x[j]);
+    }
+}
+__global__ void cast_bf16_f32_kernel(const bf16* __restrict__ x, float* __restrict__ y, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] = bf2f(x[i]);
+}
+
+// dgrad weight: src fp32 [N][T][K] -> dst bf16 [K][T][N] with taps reversed (T=1: plain transpose)
+__global__ void transpose_w_kernel(const float* __restrict__ src, bf16* __restrict__ dst, int N, int K, int T) {
+    __shared__ float tile[32][33];
+    const int tap = blockIdx.z;
+    const int n0 = blockIdx.y * 32, k0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 256 threads: 32 x 8
+    for (int j = ty; j < 32; j += 8) {
+        const int n = n0 + j, k = k0 + tx;
+        tile[j][tx] = (n < N && k < K) ? src[((size_t)n * T + tap) * K + k] : 0.f;
+    }
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8) {
+        const int k = k0 + j, n = n0 + tx;
+        if (n < N && k < K) dst[((size_t)k * T + (T - 1 - tap)) * N + n] = f2bf(tile[tx][j]);
+    }
+}
+
+// ---- SiD losses: loss value + closed-form gradients -------------------
+// per-sample prepass: nan flag over the inputs, and sum |x - y_r|
+__global__ void sid_sample_stats_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ c,
+                                        float* __restrict__ st, int n) {
+    // st[s][0] = nan flag, st[s][1] = sum|a-b|   (a=images, b=y_real, c=y_fake; b,c may alias/null)
+    __shared__ float sh[2][4];
+    const int s = blockIdx.x;
+    float flag = 0.f, sum = 0.f;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const float x = a[(size_t)s * n + i];
+        const float y = b ? b[(size_t)s * n + i] : 0.f;
+        const float z = c ? c[(size_t)s * n + i] : 0.f;
+        if (x != x || y != y || z != z) flag = 1.f;
+        sum += fabsf(x - y);
+    }
+    flag = wave_max(flag); sum = wave_sum(sum);
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { sh[0][w] = flag; sh[1][w] = sum; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        st[s * 2] = fmaxf(fmaxf(sh[0][0], sh[0][1]), fmaxf(sh[0][2], sh[0][3]));
+        st[s * 2 + 1] = sh[1][0] + sh[1][1] + sh[1][2] + sh[1][3];
+    }
+}
+
+// generator loss: sum (yr-yf)*((yr-x) - alpha*(yr-yf))/w * scale over non-NaN samples  (alpha==1 -> (yr-yf)(yf-x)/w)
+__global__ void sid_g_loss_kernel(const float* __restrict__ x, const float* __restrict__ yr, const float* __restrict__ yf,
+                                  const float* __restrict__ st, float* __restrict__ dx, float* __restrict__ dyr,
+                                  float* __restrict__ dyf, float* __restrict__ loss_part, int n, float alpha, float scale) {
+    __shared__ float sh[4];
+    const int s = blockIdx.y;
+    const bool drop = st[s * 2] != 0.f;
+    const float w = fmaxf(st[s * 2 + 1] / (float)n, 1e-5f);
+    float acc = 0.f;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const size_t k = (size_t)s * n + i;
+        if (drop) { dx[k] = 0.f; dyr[k] = 0.f; dyf[k] = 0.f; continue; }
+        const float d = yr[k] - yf[k], e = yr[k] - x[k];
+        acc += d * (e - alpha * d) / w;
+        dyr[k] = scale * (e + (1.f - 2.f * alpha) * d) / w;
+        dyf[k] = scale * (-e + 2.f * alpha * d) / w;
+        dx[k] = scale * (-d) / w;
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) loss_part[blockIdx.y * gridDim.x + blockIdx.x] = (sh[0] + sh[1] + sh[2] + sh[3]) * scale;
+}
+
+// fake-score loss: sum (e - noise)^2 * scale over non-NaN samples; grad wrt e
+__global__ void sid_fake_loss_kernel(const float* __restrict__ e, const float* __restrict__ noise, const float* __restrict__ st,
+                                     float* __restrict__ de, float* __restrict__ loss_part, int n, float scale) {
+    __shared__ float sh[4];
+    const int s = blockIdx.y;
+    const bool drop = st[s * 2] != 0.f;
+    float acc = 0.f;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const size_t k = (size_t)s * n + i;
+        if (drop) { de[k] = 0.f; continue; }
+        const float d = e[k] - noise[k];
+        acc += d * d;
+        de[k] = 2.f * scale * d;
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) loss_part[blockIdx.y * gridDim.x + blockIdx.x] = (sh[0] + sh[1] + sh[2] + sh[3]) * scale;
+}
+
+__global__ void sum_small_kernel(const float* __restrict__ part, float* __restrict__ out, int n) {
+    float t = 0.f;
+    for (int i = threadIdx.x; i < n; i += 64) t += part[i];
+    t = wave_sum(t);
+    if (threadIdx.x == 0) out[0] = t;
+}
+
+// ---- bias_act (reference plugin op: torch_utils/ops/bias_act.cu) -----------------------------
+// y = clamp(act(x + b[(i/stepB)%sizeB]) * gain); grad=1: dx from dy using saved x (+b) or y.
+DEVFN float act_fwd(int a, float x, float alpha) {
+    switch (a) {
+        case 1: return x;
+        case 2: return x > 0.f ? x : 0.f;
+        case 3: return x > 0.f ? x : x * alpha;
+        case 4: return tanhf(x);
+        case 5: return 1.f / (1.f + expf(-x));
+        case 6: return x > 0.f ? x : expm1f(x);
+        case 7: return 1.0507009873554805f * (x > 0.f ? x : 1.6732632423543772f * expm1f(x));
+        case 8: return x > 20.f ? x : log1pf(expf(x));
+        case 9: return x / (1.f + expf(-x));
+    }
+    return x;
+}
+// derivative of act at pre-activation x (y = act(x))
+DEVFN float act_grad(int a, float x, float y, float alpha) {
+    switch (a) {
+        case 1: return 1.f;
+        case 2: return x > 0.f ? 1.f : 0.f;
+        case 3: return x > 0.f ? 1.f : alpha;
+        case 4: return 1.f - y * y;
+        case 5: return y * (1.f - y);
+        case 6: return x > 0.f ? 1.f : y + 1.f;
+        case 7: return x > 0.f ? 1.0507009873554805f : y + 1.0507009873554805f * 1.6732632423543772f;
+        case 8: return 1.f / (1.f + expf(-x));
+        case 9: { const float s = 1.f / (1.f + expf(-x)); return s * (1.f + x * (1.f - s)); }
+    }
+    return 1.f;
+}
+template <typename T>
+__global__ void bias_act_kernel(const T* __restrict__ x, const T* __restrict__ b, const T* __restrict__ dy, T* __restrict__ out,
+                                size_t n, int stepB, int sizeB, int act, float alpha, float gain, float clamp, int grad) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float v = (float)x[i];
+    if (b) v += (float)b[(i / stepB) % sizeB];
+    const float y = act_fwd(act, v, alpha);
+    if (grad == 0) {
+        float o = y * gain;
+        if (clamp >= 0.f) o = fminf(fmaxf(o, -clamp), clamp);
+        out[i] = (T)o;
+    } else {
+        float o = (float)dy[i] * gain * act_grad(act, v, y, alpha);
+        if (clamp >= 0.f) { const float yy = y * gain; if (yy > clamp || yy < -clamp) o = 0.f; }
+        out[i] = (T)o;
+    }
+}
+
+extern "C" {
+
+int sidlsg_noisy_input(const float* x0, const float* noise, const float* s0, const float* s1, void* out, float* xt, int B,
+                       int C, int HW, int Cp, int dup, void* stream) {
+    if (C > 8 || Cp % 8 || Cp < 8 || dup < 1) return SIDLSG_EINVAL;
+    hipLaunchKernelGGL(noisy_input_kernel, GRID1D((size_t)B * HW, 256), dim3(256), 0, (hipStream_t)stream, x0, noise, s0, s1,
+                       (bf16*)out, xt, B, C, HW, Cp, dup);
+    return sidlsg_last_error();
+}
+int sidlsg_noisy_input_bwd(const void* g, const float* s0, float* dx0, int B, int C, int HW, int Cp, int dup, int accumulate,
+                           void* stream) {
+    if (C > 8 || Cp % 8) return SIDLSG_EINVAL;
+    hipLaunchKernelGGL(noisy_input_bwd_kernel, GRID1D((size_t)B * HW, 256), dim3(256), 0, (hipStream_t)stream, (const bf16*)g,
+                       s0, dx0, B, C, HW, Cp, dup, accumulate);
+    return sidlsg_last_error();
+}
+int sidlsg_cfg_x0(const float* eps, const float* xt, const float* s0, const float* s1, float* out, int B, int C, int HW,
+                  int Ce, int dup, float kappa, int predict_x0, void* stream) {
+    if (Ce < C) return SIDLSG_EINVAL;
+    hipLaunchKernelGGL(cfg_x0_kernel, GRID1D((size_t)B * HW, 256), dim3(256), 0, (hipStream_t)stream, eps, xt, s0, s1, out, B,
+                       C, HW, Ce, dup, kappa, predict_x0);
+    return sidlsg_last_error();
+}
+int sidlsg_cfg_x0_bwd(const float* g, const float* s0, const float* s1, void* deps, float* dxt, int B, int C, int HW, int Cp,
+                      int dup, float kappa, int predict_x0, void* stream) {
+    if (C > 8 || Cp % 8) return SIDLSG_EINVAL;
+    hipLaunchKernelGGL(cfg_x0_bwd_kernel, GRID1D((size_t)B * HW, 256), dim3(256), 0, (hipStream_t)stream, g, s0, s1,
+                       (bf16*)deps, dxt, B, C, HW, Cp, dup, kappa, predict_x0);
+    return sidlsg_last_error();
+}
+int sidlsg_timestep_embed(const long long* t, void* out, int B, int dim, void* stream) {
+    hipLaunchKernelGGL(timestep_embed_kernel, GRID1D((size_t)B * (dim / 2), 256), dim3(256), 0, (hipStream_t)stream, t,
+                       (bf16*)out, B, dim);
+    return sidlsg_last_error();
+}
+int sidlsg_silu_fwd(const void* x, void* y, long long n, void* stream) {
+    if (n % 8) return SIDLSG_EINVAL;
+    hipLaunchKernelGGL(silu_fwd_kernel, GRID1D(n / 8, 256), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, (bf16*)y, (size_t)n / 8);
+    return sidlsg_last_error();
+}
+int sidlsg_silu_bwd(const void* x, const void* dy, void* dx, long long n, void* stream) {
+    if (n % 8) return SIDLSG_EINVAL;
+    hipLaunchKernelGGL(silu_bwd_kernel, GRID1D(n / 8, 256), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, (const bf16*)dy,
+                       (bf16*)dx, (size_t)n / 8);
+    return sidlsg_last_error();
+}
+int sidlsg_geglu_fwd(const void* h, void* y, long long M, int F, void* stream) {
+    if (F % 8) return SIDLSG_EINVAL;
+    hipLaunchKernelGGL(geglu_fwd_kernel, GRID1D((size_t)M * (F / 8), 256), dim3(256), 0, (hipStream_t)stream, (const bf16*)h,
+                       (bf16*)y, (size_t)M, F);
+    return sidlsg_last_error();
+}
+int sidlsg_geglu_bwd(const void* h, const void* dy, void* dh, long long M, int F, void* stream) {
+    if (F % 8) return SIDLSG_EINVAL;
+    hipLaunchKernelGGL(geglu_bwd_kernel, GRID1D((size_t)M * (F / 8), 256), dim3(256), 0, (hipStream_t)stream, (const bf16*)h,
+                       (const bf16*)dy, (bf16*)dh, (size_t)M, F);
+    return sidlsg_last_error();
+}
+int sidlsg_concat2(void* a, void* b, void* out, long long M, int C1, int C2, int to_parts, void* stream) {
+    if (C1 % 8 || C2 % 8) return SIDLSG_EINVAL;
+    hipLaunchKernelGGL(concat2_kernel, GRID1D((size_t)M * ((C1 + C2) / 8), 256), dim3(256), 0, (hipStream_t)stream, (bf16*)a,
+                       (bf16*)b, (bf16*)out, (size_t)M, C1, C2, to_parts);
+    return sidlsg_last_error();
+}
+int sidlsg_sumpool2x2(const void* g, void* out, int B, int H, int W, int C, void* stream) {
+    if (C % 8) return SIDLSG_EINVAL;
+    hipLaunchKernelGGL(sumpool2x2_kernel, GRID1D((size_t)B * H * W * (C / 8), 256), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16*)g, (bf16*)out, B, H, W, C);
+    return sidlsg_last_error();
+}
+int sidlsg_zero_insert2(const void* g, void* out, int B, int Ho, int Wo, int H, int W, int C, void* stream) {
+    if (C % 8 || (H + 1) / 2 != Ho || (W + 1) / 2 != Wo) return SIDLSG_EINVAL;
+    hipLaunchKernelGGL(zero_insert2_kernel, GRID1D((size_t)B * H * W * (C / 8), 256), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16*)g, (bf16*)out, B, Ho, Wo, H, W, C);
+    return sidlsg_last_error();
+}
+int sidlsg_add_bf16(const void* a, const void* b, void* o, long long n, void* stream) {
+    if (n % 8) return SIDLSG_EINVAL;
+    hipLaunchKernelGGL(add_bf16_kernel, GRID1D(n / 8, 256), dim3(256), 0, (hipStream_t)stream, (const bf16*)a, (const bf16*)b,
+                       (bf16*)o, (size_t)n / 8);
+    return sidlsg_last_error();
+}
+// column sums of g [B][rows_per_batch][N] (row stride ldg): per_batch [B][N] (=) and/or total [N] (+=).
+// ws: B * nch * N floats, nch = sidlsg_colsum_nchunks(...)
+int sidlsg_colsum_nchunks(int B, int rows_per_batch) {
+    int want = (512 + B - 1) / B; int maxch = (rows_per_batch + 63) / 64;
+    int nch = want < maxch ? want : maxch; if (nch < 1) nch = 1; if (nch > 128) nch = 128; return nch;
+}
+int sidlsg_colsum(const void* g, int ldg, float* per_batch, float* total, float* ws, int B, int rows_per_batch, int N,
+                  void* stream) {
+    if (N % 8 || N <= 0) return SIDLSG_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    const int nch = sidlsg_colsum_nchunks(B, rows_per_batch);
+    const int rpc = (rows_per_batch + nch - 1) / nch;
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3(nch, B), dim3(256), 0, s, (const bf16*)g, ws, rows_per_batch, N, ldg, rpc, nch);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((N + 255) / 256), dim3(256), 0, s, ws, per_batch, total, B, nch, N);
+    return sidlsg_last_error();
+}
+int sidlsg_cast_f32_bf16(const float* x, void* y, long long n, void* stream) {
+    hipLaunchKernelGGL(cast_f32_bf16_kernel, GRID1D((n + 7) / 8, 256), dim3(256), 0, (hipStream_t)stream, x, (bf16*)y, (size_t)n);
+    return sidlsg_last_error();
+}
+int sidlsg_cast_bf16_f32(const void* x, float* y, long long n, void* stream) {
+    hipLaunchKernelGGL(cast_bf16_f32_kernel, GRID1D(n, 256), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, y, (size_t)n);
+    return sidlsg_last_error();
+}
+// src fp32 [N][T][K] -> dst bf16 [K][T][N], taps reversed
+int sidlsg_transpose_w(const float* src, void* dst, int N, int K, int T, void* stream) {
+    hipLaunchKernelGGL(transpose_w_kernel, dim3((K + 31) / 32, (N + 31) / 32, T), dim3(256), 0, (hipStream_t)stream, src,
+                       (bf16*)dst, N, K, T);
+    return sidlsg_last_error();
+}
+// Generator loss (A7).  x,yr,yf: [S][n] fp32.  ws: >= S*2 + S*GB floats.  loss[0] = value (already * scale).
+#define SID_GB 8
+int sidlsg_g_loss(const float* x, const float* yr, const float* yf, float* dx, float* dyr, float* dyf, float* loss, float* ws,
+                  int S, int n, float alpha, float scale, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    float* st = ws; float* part = ws + 2 * S;
+    hipLaunchKernelGGL(sid_sample_stats_kernel, dim3(S), dim3(256), 0, s, x, yr, yf, st, n);
+    hipLaunchKernelGGL(sid_g_loss_kernel, dim3(SID_GB, S), dim3(256), 0, s, x, yr, yf, st, dx, dyr, dyf, part, n, alpha, scale);
+    hipLaunchKernelGGL(sum_small_kernel, dim3(1), dim3(64), 0, s, part, loss, S * SID_GB);
+    return sidlsg_last_error();
+}
+int sidlsg_fake_loss(const float* e, const float* noise, float* de, float* loss, float* ws, int S, int n, float scale,
+                     void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    float* st = ws; float* part = ws + 2 * S;
+    hipLaunchKernelGGL(sid_sample_stats_kernel, dim3(S), dim3(256), 0, s, e, (const float*)nullptr, (const float*)nullptr, st, n);
+    hipLaunchKernelGGL(sid_fake_loss_kernel, dim3(SID_GB, S), dim3(256), 0, s, e, noise, st, de, part, n, scale);
+    hipLaunchKernelGGL(sum_small_kernel, dim3(1), dim3(64), 0, s, part, loss, S * SID_GB);
+    return sidlsg_last_error();
+}
+// bias_act: dtype 0 = fp32, 1 = bf16.  grad 0: out = clamp(act(x+b)*gain); grad 1: out = dL/dx given dy (x,b = saved inputs)
+int sidlsg_bias_act(const void* x, const void* b, const void* dy, void* out, long long n, int stepB, int sizeB, int act,
+                    float alpha, float gain, float clamp, int grad, int dtype, void* stream) {
+    if (act < 1 || act > 9 || (grad != 0 && grad != 1) || (grad == 1 && !dy)) return SIDLSG_EINVAL;
+    if (dtype == 0)
+        hipLaunchKernelGGL(bias_act_kernel<float>, GRID1D(n, 256), dim3(256), 0, (hipStream_t)stream, (const float*)x,
+                           (const float*)b, (const float*)dy, (float*)out, (size_t)n, stepB, sizeB, act, alpha, gain, clamp, grad);
+    else
+        hipLaunchKernelGGL(bias_act_kernel<bf16>, GRID1D(n, 256), dim3(256), 0, (hipStream_t)stream, (const bf16*)x,
+                           (const bf16*)b, (const bf16*)dy, (bf16*)out, (size_t)n, stepB, sizeB, act, alpha, gain, clamp, grad);
+    return sidlsg_last_error();
+}
+
+}  // extern "C"

@@ -1,0 +1,495 @@
+// bf16 MFMA GEMM / implicit-GEMM conv3x3 for gfx950 (MI355X).
+//
+//   C[M,N] = epilogue( A[M,K] * W[N,K]^T )        A: dense rows or NHWC implicit im2col
+//
+// Covers every contraction of the SD UNet except attention:
+// ResBlock conv3x3 (fwd and dgrad), 1x1 conv / Linear (fwd and dgrad), GEGLU/FF, QKV.
+// Layout decisions (DESIGN.md "Data layout"): activations NHWC bf16, so a 1x1 conv and a
+// Linear over tokens are the same dense GEMM; conv weights are [Cout][3][3][Cin] (K index =
+// tap*Cin + c) so a K-tile of 64 lies inside one tap and an A-tile row is a contiguous
+// 128-byte run of channels of one input pixel.
+//
+// Tiling: 256 threads = 4 waves (2x2); block tile BM x BN x 64, wave tile 64 x BN/2 as
+// 16x16x32 MFMAs; LDS double buffer, 128-byte rows with a 16-byte-chunk XOR swizzle
+// (chunk ^= (row>>1)&7) that makes every ds_read_b128 lane group conflict free;
+// global->register->LDS staging issued one K-tile ahead of the MFMAs.
+// The MFMA is issued "transposed" (rows = output channel, cols = pixel) and W-tile rows are
+// permuted per tile pair so that each lane ends up with 8 consecutive output channels of one
+// pixel: the epilogue stores 16 bytes per lane.
+#include "common.h"
+
+struct GemmParams {
+    const bf16* A;        // dense: [M][lda]; conv: NHWC image [B][Hs][Ws][ldx]
+    const bf16* W;        // [N][K] row-major (K contiguous)
+    void* C;              // [M][ldc] bf16 (or fp32 when OUT_F32)
+    const float* bias;    // [N] or null
+    const bf16* res;      // [M][ldres] or null
+    const float* rowvec;  // [M/rows_per_batch][N] or null (time-embedding broadcast)
+    int M, N, K;
+    int lda, ldc, ldres;
+    int rows_per_batch;
+    // conv3x3 (pad 1): virtual input H x Wd (after optional nearest x2 upsample), Cin channels
+    int H, Wd, Cin, Ho, Wo, stride, ups;
+    float alpha;
+    int flags;
+};
+
+enum { F_OUT_F32 = 1, F_SILU = 2, F_ACCUM = 4 };
+
+constexpr int BK = 64;
+constexpr int NTHREADS = 256;
+
+template <int BM, int BN, int MODE>
+__global__ __launch_bounds__(NTHREADS) void gemm_bf16_kernel(GemmParams p) {
+    constexpr int WMT = BM / 2, WNT = BN / 2;   // wave tile
+    constexpr int MT = WMT / 16, NT = WNT / 16;
+    constexpr int AR = BM / 32, BR = BN / 32;   // 16B chunks per thread per tile
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    bf16* As = reinterpret_cast<bf16*>(smem);                 // [2][BM][BK]
+    bf16* Bs = As + 2 * BM * BK;                              // [2][BN][BK]
+
+    // ---- XCD-aware block -> tile map: blocks that share an A row-panel sit on one XCD (own L2)
+    const int tiles_n = (p.N + BN - 1) / BN;
+    const int tiles_m = (p.M + BM - 1) / BM;
+    const int nblk = tiles_n * tiles_m;
+    int bid = blockIdx.x;
+    {
+        const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int m0 = (bid / tiles_n) * BM;
+    const int n0 = (bid % tiles_n) * BN;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm0 = (wave >> 1) * WMT, wn0 = (wave & 1) * WNT;
+    const int kc = tid & 7, r0 = tid >> 3;
+
+    // ---- per-thread A row descriptors
+    const bf16* arow[AR];
+    int ahi[AR], awi[AR];
+    bool aok[AR];
+#pragma unroll
+    for (int i = 0; i < AR; i++) {
+        const int m = m0 + r0 + 32 * i;
+        aok[i] = m < p.M;
+        const int mm = aok[i] ? m : 0;
+        if (MODE == 0) {
+            arow[i] = p.A + (size_t)mm * p.lda;
+            ahi[i] = awi[i] = 0;
+        } else {
+            const int hw = p.Ho * p.Wo;
+            const int b = mm / hw, rem = mm - b * hw;
+            const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+            const int Hs = p.ups ? (p.H >> 1) : p.H, Ws = p.ups ? (p.Wd >> 1) : p.Wd;
+            arow[i] = p.A + (size_t)b * Hs * Ws * p.lda;
+            ahi[i] = ho * p.stride - 1;
+            awi[i] = wo * p.stride - 1;
+        }
+    }
+    const bf16* brow[BR];
+    bool bok[BR];
+#pragma unroll
+    for (int i = 0; i < BR; i++) {
+        const int n = n0 + r0 + 32 * i;
+        bok[i] = n < p.N;
+        brow[i] = p.W + (size_t)(bok[i] ? n : 0) * p.K;
+    }
+
+    bf16x8 areg[AR], breg[BR];
+    auto load_tile = [&](int kt) {
+        const int k = kt * BK + kc * 8;
+        const bool kok = k < p.K;
+        if (MODE == 0) {
+#pragma unroll
+            for (int i = 0; i < AR; i++) areg[i] = (aok[i] && kok) ? ld8(arow[i] + k) : zero8();
+        } else {
+            const int tap = k / p.Cin, c = k - tap * p.Cin;
+            const int dh = tap / 3, dw = tap - dh * 3;
+            const int Ws = p.ups ? (p.Wd >> 1) : p.Wd;
+#pragma unroll
+            for (int i = 0; i < AR; i++) {
+                int hi = ahi[i] + dh, wi = awi[i] + dw;
+                const bool ok = aok[i] && kok && hi >= 0 && hi < p.H && wi >= 0 && wi < p.Wd;
+                if (p.ups) { hi >>= 1; wi >>= 1; }
+                areg[i] = ok ? ld8(arow[i] + (size_t)(hi * Ws + wi) * p.lda + c) : zero8();
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < BR; i++) breg[i] = (bok[i] && kok) ? ld8(brow[i] + k) : zero8();
+    };
+    auto store_tile = [&](int buf) {
+        bf16* a = As + buf * BM * BK;
+        bf16* b = Bs + buf * BN * BK;
+#pragma unroll
+        for (int i = 0; i < AR; i++) {
+            const int r = r0 + 32 * i;
+            st8(a + r * BK + ((kc ^ ((r >> 1) & 7)) << 3), areg[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < BR; i++) {
+            const int r = r0 + 32 * i;
+            st8(b + r * BK + ((kc ^ ((r >> 1) & 7)) << 3), breg[i]);
+        }
+    };
+
+    f32x4 acc[NT][MT];
+#pragma unroll
+    for (int i = 0; i < NT; i++)
+#pragma unroll
+        for (int j = 0; j < MT; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // operand row (within the wave's n range) that lane (l&15) of n-tile ni supplies
+    const int li = lane & 15, lg = lane >> 4;
+    int wrow[NT];
+#pragma unroll
+    for (int ni = 0; ni < NT; ni++) {
+        const bool paired = (ni | 1) < NT;
+        wrow[ni] = wn0 + (paired ? 32 * (ni >> 1) + (li >> 2) * 8 + (ni & 1) * 4 + (li & 3) : 16 * ni + li);
+    }
+
+    const int nk = (p.K + BK - 1) / BK;
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; kt++) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) load_tile(kt + 1);
+        const bf16* a = As + buf * BM * BK;
+        const bf16* b = Bs + buf * BN * BK;
+#pragma unroll
+        for (int kk = 0; kk < 2; kk++) {
+            bf16x8 fa[MT], fw[NT];
+            const int ch = kk * 4 + lg;
+#pragma unroll
+            for (int mi = 0; mi < MT; mi++) {
+                const int r = wm0 + mi * 16 + li;
+                fa[mi] = *reinterpret_cast<const bf16x8*>(a + r * BK + ((ch ^ ((r >> 1) & 7)) << 3));
+            }
+#pragma unroll
+            for (int ni = 0; ni < NT; ni++) {
+                const int r = wrow[ni];
+                fw[ni] = *reinterpret_cast<const bf16x8*>(b + r * BK + ((ch ^ ((r >> 1) & 7)) << 3));
+            }
+#pragma unroll
+            for (int ni = 0; ni < NT; ni++)
+#pragma unroll
+                for (int mi = 0; mi < MT; mi++)
+                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[ni], fa[mi], acc[ni][mi], 0, 0, 0);
+        }
+        if (kt + 1 < nk) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: lane (lg, li) holds, for pixel row m = .. + li, 8 (or 4) consecutive channels
+    const bool vec_ok = (p.N & 7) == 0;
+#pragma unroll
+    for (int mi = 0; mi < MT; mi++) {
+        const int m = m0 + wm0 + mi * 16 + li;
+        if (m >= p.M) continue;
+        const float* rv = p.rowvec ? p.rowvec + (size_t)(m / p.rows_per_batch) * p.N : nullptr;
+#pragma unroll
+        for (int pr = 0; pr < (NT + 1) / 2; pr++) {
+            const bool paired = (2 * pr + 1) < NT;
+            const int cnt = paired ? 8 : 4;
+            const int n = n0 + wn0 + 32 * pr + lg * cnt;
+            float v[8];
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                v[r] = acc[2 * pr][mi][r];
+                v[4 + r] = paired ? acc[(2 * pr + 1) < NT ? 2 * pr + 1 : 2 * pr][mi][r] : 0.f;
+            }
+            if (n >= p.N) continue;
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                if (e >= cnt) break;
+                const int nn = n + e;
+                if (nn < p.N) {
+                    float x = v[e] * p.alpha;
+                    if (p.bias) x += p.bias[nn];
+                    if (rv) x += rv[nn];
+                    if (p.res) x += bf2f(p.res[(size_t)m * p.ldres + nn]);
+                    if (p.flags & F_SILU) x = silu_f(x);
+                    v[e] = x;
+                }
+            }
+            if (p.flags & F_OUT_F32) {
+                float* c = reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n;
+                if (vec_ok && n + cnt <= p.N && !(p.flags & F_ACCUM)) {
+                    *reinterpret_cast<f32x4*>(c) = (f32x4){v[0], v[1], v[2], v[3]};
+                    if (cnt == 8) *reinterpret_cast<f32x4*>(c + 4) = (f32x4){v[4], v[5], v[6], v[7]};
+                } else {
+                    for (int e = 0; e < cnt; e++)
+                        if (n + e < p.N) c[e] = (p.flags & F_ACCUM) ? c[e] + v[e] : v[e];
+                }
+            } else {
+                bf16* c = reinterpret_cast<bf16*>(p.C) + (size_t)m * p.ldc + n;
+                if (vec_ok && n + cnt <= p.N) {
+                    if (cnt == 8) {
+                        bf16x8 o;
+#pragma unroll
+                        for (int e = 0; e < 8; e++) o[e] = f2bf(v[e]);
+                        st8(c, o);
+                    } else {
+                        bf16x4 o;
+#pragma unroll
+                        for (int e = 0; e < 4; e++) o[e] = f2bf(v[e]);
+                        *reinterpret_cast<bf16x4*>(c) = o;
+                    }
+                } else {
+                    for (int e = 0; e < cnt; e++)
+                        if (n + e < p.N) c[e] = f2bf(v[e]);
+                }
+            }
+        }
+    }
+}
+
+template <int BM, int BN, int MODE>
+static int launch_gemm(const GemmParams& p, hipStream_t s) {
+    const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
+    const size_t lds = (size_t)2 * (BM + BN) * BK * sizeof(bf16);
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<BM, BN, MODE>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, MODE>), dim3(tiles), dim3(NTHREADS), lds, s, p);
+    return sidlsg_last_error();
+}
+
+template <int MODE>
+static int dispatch_gemm(const GemmParams& p, hipStream_t s) {
+    // N multiple of 160 (every SD channel count is a multiple of 320) -> exact 160-wide tiles;
+    // otherwise 128-wide; narrow outputs (conv_out, dgrad of conv_in) -> 64-wide.
+    if (p.N <= 64) return launch_gemm<128, 64, MODE>(p, s);
+    if (p.N % 160 == 0) return launch_gemm<128, 160, MODE>(p, s);
+    return launch_gemm<128, 128, MODE>(p, s);
+}
+
+static int check_common(const GemmParams& p) {
+    if (p.M <= 0 || p.N <= 0 || p.K <= 0) return SIDLSG_EINVAL;
+    if ((p.K & 7) || (p.lda & 7)) return SIDLSG_EINVAL;            // 16-byte chunks
+    if (!p.A || !p.W || !p.C) return SIDLSG_EINVAL;
+    if (p.rowvec && p.rows_per_batch <= 0) return SIDLSG_EINVAL;
+    if ((p.flags & F_ACCUM) && !(p.flags & F_OUT_F32)) return SIDLSG_EINVAL;
+    return SIDLSG_OK;
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Weight gradient:  dW[N][K] (+)= sum_m dY[m][N] * A[m][K]     (fp32 atomics, split over m)
+//
+// Both operands are stored pixel-major, i.e. the contraction index m is the ROW of both LDS
+// tiles.  MFMA wants 8 consecutive contraction elements per lane, so fragments are fetched
+// with gfx950's LDS transpose read (ds_read_b64_tr_b16): a 16-lane group reads a
+// [4 m][16 cols] block and lane i receives column i.  Two reads (m+0..3, m+4..7) give the
+// 8-element fragment of the 16x16x32 MFMA for both operands, in the same m order.
+// LDS rows are 256 B (128 columns); the 32-byte granule index is XOR-swizzled with
+// (m&3)|((m>>3)&1)<<2 so the 8 rows a 32-lane half touches fall on 8 distinct granules.
+constexpr int WG_T = 128;   // output tile: 128 (n) x 128 (k)
+constexpr int WG_MB = 64;   // contraction rows per LDS stage
+
+struct WgradParams {
+    const bf16* dY;  // [M][ldy]
+    const bf16* A;   // dense [M][lda] or NHWC image
+    float* dW;       // [N][K]
+    int M, N, K, ldy, lda;
+    int H, Wd, Cin, Ho, Wo, stride, ups;
+    int m_per_split;
+};
+
+DEVFN int wg_swz(int row) { return (row & 3) | (((row >> 3) & 1) << 2); }
+
+template <int MODE>
+__global__ __launch_bounds__(NTHREADS) void wgrad_bf16_kernel(WgradParams p) {
+    __shared__ __attribute__((aligned(16))) bf16 Ys[2][WG_MB][WG_T];
+    __shared__ __attribute__((aligned(16))) bf16 Xs[2][WG_MB][WG_T];
+    const int tiles_k = (p.K + WG_T - 1) / WG_T;
+    const int tile = blockIdx.x;
+    const int n0 = (tile / tiles_k) * WG_T, k0 = (tile % tiles_k) * WG_T;
+    const int mbeg = blockIdx.y * p.m_per_split;
+    const int mend = min(p.M, mbeg + p.m_per_split);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lg = lane >> 4;
+    const int wn0 = (wave >> 1) * 64, wk0 = (wave & 1) * 64;
+    const int c16 = tid & 15, r0 = tid >> 4;  // chunk column (8 elements) and first row
+
+    // per-thread constants of the A (k) operand: k is fixed for the whole kernel
+    const int kA = k0 + c16 * 8;
+    const bool kok = kA < p.K;
+    int tap = 0, cA = kA, dh = 0, dw = 0;
+    if (MODE == 1) { tap = kA / p.Cin; cA = kA - tap * p.Cin; dh = tap / 3; dw = tap - dh * 3; }
+    const int nY = n0 + c16 * 8;
+    const bool nok = nY < p.N;     // N % 8 == 0 or N < 8 handled by caller padding rule (N%4==0 -> scalar path below)
+    const int Hs = p.ups ? (p.H >> 1) : p.H, Ws = p.ups ? (p.Wd >> 1) : p.Wd;
+    const int hw = (MODE == 1) ? p.Ho * p.Wo : 1;
+
+    bf16x8 yreg[4], xreg[4];
+    auto load_tile = [&](int mb) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int m = mb + r0 + 16 * i;
+            const bool mok = m < mend;
+            if (nok && mok) {
+                if (nY + 8 <= p.N) yreg[i] = ld8(p.dY + (size_t)m * p.ldy + nY);
+                else {
+                    bf16x8 v = zero8();
+                    for (int e = 0; e < 8; e++) if (nY + e < p.N) v[e] = p.dY[(size_t)m * p.ldy + nY + e];
+                    yreg[i] = v;
+                }
+            } else yreg[i] = zero8();
+            if (MODE == 0) {
+                xreg[i] = (kok && mok) ? ld8(p.A + (size_t)m * p.lda + kA) : zero8();
+            } else {
+                bool ok = kok && mok;
+                const int mm = mok ? m : 0;
+                const int b = mm / hw, rem = mm - b * hw;
+                const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+                int hi = ho * p.stride - 1 + dh, wi = wo * p.stride - 1 + dw;
+                ok = ok && hi >= 0 && hi < p.H && wi >= 0 && wi < p.Wd;
+                if (p.ups) { hi >>= 1; wi >>= 1; }
+                xreg[i] = ok ? ld8(p.A + ((size_t)(b * Hs + hi) * Ws + wi) * p.lda + cA) : zero8();
+            }
+        }
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int r = r0 + 16 * i;
+            const int col = ((((c16 >> 1) ^ wg_swz(r)) << 1) | (c16 & 1)) << 3;
+            st8(&Ys[buf][r][col], yreg[i]);
+            st8(&Xs[buf][r][col], xreg[i]);
+        }
+    };
+
+    f32x4 acc[4][4];   // [n tile][k tile]
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    auto tr_frag = [&](const bf16* tilebase, int mrow, int colbase) -> bf16x8 {
+        // lane t=(li) of group lg addresses row mrow + 8*lg + (t>>2) (+4 for the 2nd read), 4 columns at (t&3)*4
+        const int ra = mrow + 8 * lg + (li >> 2);
+        const int rb = ra + 4;
+        const int g = colbase >> 4;                  // 16-column granule of this fragment
+        const int ca = ((g ^ wg_swz(ra)) << 4) + (li & 3) * 4;
+        const int cb = ((g ^ wg_swz(rb)) << 4) + (li & 3) * 4;
+        s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(tilebase + ra * WG_T + ca));
+        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(tilebase + rb * WG_T + cb));
+        typedef short s16x8 __attribute__((ext_vector_type(8)));
+        s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        return __builtin_bit_cast(bf16x8, v);
+    };
+
+    const int nsteps = (mend - mbeg + WG_MB - 1) / WG_MB;
+    if (nsteps <= 0) return;
+    load_tile(mbeg);
+    store_tile(0);
+    __syncthreads();
+    for (int st = 0; st < nsteps; st++) {
+        const int buf = st & 1;
+        if (st + 1 < nsteps) load_tile(mbeg + (st + 1) * WG_MB);
+#pragma unroll
+        for (int kk = 0; kk < 2; kk++) {
+            bf16x8 fy[4], fx[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) fy[i] = tr_frag(&Ys[buf][0][0], kk * 32, wn0 + i * 16);
+#pragma unroll
+            for (int j = 0; j < 4; j++) fx[j] = tr_frag(&Xs[buf][0][0], kk * 32, wk0 + j * 16);
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fy[i], fx[j], acc[i][j], 0, 0, 0);
+        }
+        if (st + 1 < nsteps) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+    // acc[i][j][r]: n = n0+wn0+16i + lg*4 + r ; k = k0+wk0+16j + li
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int k = k0 + wk0 + 16 * j + li;
+            if (k >= p.K) continue;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int n = n0 + wn0 + 16 * i + lg * 4 + r;
+                if (n < p.N) unsafeAtomicAdd(p.dW + (size_t)n * p.K + k, acc[i][j][r]);
+            }
+        }
+}
+
+template <int MODE>
+static int launch_wgrad(WgradParams p, hipStream_t s) {
+    const int tiles = ((p.N + WG_T - 1) / WG_T) * ((p.K + WG_T - 1) / WG_T);
+    // split the pixel contraction so the grid fills the chip (256 CUs, 2 blocks each)
+    int splits = (768 + tiles - 1) / tiles;
+    const int max_splits = (p.M + 4 * WG_MB - 1) / (4 * WG_MB);
+    if (splits > max_splits) splits = max_splits;
+    if (splits < 1) splits = 1;
+    int mps = (p.M + splits - 1) / splits;
+    mps = (mps + WG_MB - 1) / WG_MB * WG_MB;
+    splits = (p.M + mps - 1) / mps;
+    p.m_per_split = mps;
+    hipLaunchKernelGGL((wgrad_bf16_kernel<MODE>), dim3(tiles, splits), dim3(NTHREADS), 0, s, p);
+    return sidlsg_last_error();
+}
+
+extern "C" {
+
+// Dense GEMM: C[M,N] = act(alpha * A[M,K] W[N,K]^T + bias[N] + rowvec[m/rpb,N] + res[M,N])
+int sidlsg_gemm_bf16(const void* A, int lda, const void* W, void* C, int ldc, const float* bias, const void* res,
+                     int ldres, const float* rowvec, int rows_per_batch, int M, int N, int K, float alpha, int flags,
+                     void* stream) {
+    GemmParams p{};
+    p.A = (const bf16*)A; p.W = (const bf16*)W; p.C = C; p.bias = bias; p.res = (const bf16*)res; p.rowvec = rowvec;
+    p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldc = ldc; p.ldres = ldres; p.rows_per_batch = rows_per_batch;
+    p.alpha = alpha; p.flags = flags;
+    if (int e = check_common(p)) return e;
+    return dispatch_gemm<0>(p, (hipStream_t)stream);
+}
+
+// Implicit-GEMM 3x3 convolution, pad 1, NHWC.  X: [B][Hs][Ws][ldx] (ldx >= Cin, pixel stride),
+// W: [Cout][3][3][Cin], Y: [B][Ho][Wo][ldc].  `ups`=1 reads X through a nearest x2 upsample
+// (virtual input H x Wd = 2Hs x 2Ws).  stride in {1,2}.
+int sidlsg_conv3x3_bf16(const void* X, int ldx, const void* W, void* Y, int ldc, const float* bias, const void* res,
+                        int ldres, const float* rowvec, int B, int H, int Wd, int Cin, int Cout, int stride, int ups,
+                        float alpha, int flags, void* stream) {
+    if (stride != 1 && stride != 2) return SIDLSG_EINVAL;
+    if (Cin & 7) return SIDLSG_EINVAL;
+    if (ups && ((H | Wd) & 1)) return SIDLSG_EINVAL;
+    GemmParams p{};
+    p.A = (const bf16*)X; p.W = (const bf16*)W; p.C = Y; p.bias = bias; p.res = (const bf16*)res; p.rowvec = rowvec;
+    p.H = H; p.Wd = Wd; p.Cin = Cin; p.stride = stride; p.ups = ups;
+    p.Ho = (H + 2 - 3) / stride + 1; p.Wo = (Wd + 2 - 3) / stride + 1;
+    p.M = B * p.Ho * p.Wo; p.N = Cout; p.K = 9 * Cin; p.lda = ldx; p.ldc = ldc; p.ldres = ldres;
+    p.rows_per_batch = p.Ho * p.Wo; p.alpha = alpha; p.flags = flags;
+    if (int e = check_common(p)) return e;
+    return dispatch_gemm<1>(p, (hipStream_t)stream);
+}
+
+// dW[N][K] += dY[M][N]^T A[M][K]   (dense: Linear / 1x1 conv weight gradient; fp32 accumulate)
+int sidlsg_wgrad_bf16(const void* dY, int ldy, const void* A, int lda, float* dW, int M, int N, int K, void* stream) {
+    if (M <= 0 || N <= 0 || K <= 0 || (K & 7) || (lda & 7) || !dY || !A || !dW) return SIDLSG_EINVAL;
+    WgradParams p{};
+    p.dY = (const bf16*)dY; p.A = (const bf16*)A; p.dW = dW; p.M = M; p.N = N; p.K = K; p.ldy = ldy; p.lda = lda;
+    return launch_wgrad<0>(p, (hipStream_t)stream);
+}
+
+// dW[Cout][3][3][Cin] += conv3x3 weight gradient (same geometry arguments as sidlsg_conv3x3_bf16)
+int sidlsg_conv3x3_wgrad_bf16(const void* dY, int ldy, const void* X, int ldx, float* dW, int B, int H, int Wd, int Cin,
+                              int Cout, int stride, int ups, void* stream) {
+    if ((stride != 1 && stride != 2) || (Cin & 7) || (ldx & 7) || !dY || !X || !dW) return SIDLSG_EINVAL;
+    WgradParams p{};
+    p.dY = (const bf16*)dY; p.A = (const bf16*)X; p.dW = dW; p.ldy = ldy; p.lda = ldx;
+    p.H = H; p.Wd = Wd; p.Cin = Cin; p.stride = stride; p.ups = ups;
+    p.Ho = (H + 2 - 3) / stride + 1; p.Wo = (Wd + 2 - 3) / stride + 1;
+    p.M = B * p.Ho * p.Wo; p.N = Cout; p.K = 9 * Cin;
+    return launch_wgrad<1>(p, (hipStream_t)stream);
+}
+
+}  // extern "C"

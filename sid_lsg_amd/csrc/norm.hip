@@ -1,0 +1,391 @@
+// GroupNorm(+SiLU) and LayerNorm, forward and backward, NHWC bf16 activations, fp32 statistics.
+// gfx950 / MI355X.  HBM-bound (61 GroupNorms = 45.06 M elements and 48
+// LayerNorms = 34.65 M elements per sample-forward at SD1.5 512^2): every kernel reads 16 bytes per
+// lane, fully coalesced along the channel axis, and touches each element the minimum number of
+// times (stats pass + apply pass; the second read of a <=~100 MB tensor is served by the
+// 256 MiB Infinity Cache).
+//
+// GroupNorm is split in two kernels so that the grid (B x pixel-chunks) fills all 256 CUs even
+// at batch 1-2, with a deterministic two-level reduction (no atomics):
+//   gn_stats : per (sample, pixel chunk) -> per-group partial (sum, sumsq)
+//   gn_apply : folds the partials, y = act((x-mean)*rstd*gamma+beta), writes (mean, rstd)
+// Backward:
+//   gn_bwd_stats : per (sample, chunk) per-CHANNEL partial (sum dy'*xhat, sum dy') -- these
+//                  yield both the group sums needed for dx and dgamma/dbeta
+//   gn_bwd_apply : dx = rstd*(dy'*gamma - s1/n - xhat*s2/n)
+//   colsum_reduce: dgamma/dbeta (+=) from the per-channel partials
+#include "common.h"
+
+constexpr int GN_MAX_C = 2560;
+
+// thread layout shared by the GroupNorm kernels: blockDim.x = C8 * rows, thread owns channel chunk
+// cc (8 channels) and walks pixels rl, rl+rows, ...
+struct GnGeom {
+    int C, HW, G, cpg, C8, rows, nch, ppb;  // ppb: pixels per block (chunk)
+};
+
+__global__ void gn_stats_kernel(const bf16* __restrict__ x, float* __restrict__ part, GnGeom g) {
+    extern __shared__ float sm[];  // [rows][C][2]
+    const int b = blockIdx.y, chunk = blockIdx.x;
+    const int cc = threadIdx.x % g.C8, rl = threadIdx.x / g.C8;
+    const int p0 = chunk * g.ppb, p1 = min(g.HW, p0 + g.ppb);
+    float s[8], q[8];
+#pragma unroll
+    for (int e = 0; e < 8; e++) s[e] = q[e] = 0.f;
+    const bf16* xb = x + (size_t)b * g.HW * g.C + cc * 8;
+    for (int p = p0 + rl; p < p1; p += g.rows) {
+        const bf16x8 v = ld8(xb + (size_t)p * g.C);
+#pragma unroll
+        for (int e = 0; e < 8; e++) { const float f = bf2f(v[e]); s[e] += f; q[e] += f * f; }
+    }
+    float* row = sm + (size_t)rl * g.C * 2;
+#pragma unroll
+    for (int e = 0; e < 8; e++) { row[(cc * 8 + e) * 2] = s[e]; row[(cc * 8 + e) * 2 + 1] = q[e]; }
+    __syncthreads();
+    for (int grp = threadIdx.x; grp < g.G; grp += blockDim.x) {
+        float a = 0.f, c = 0.f;
+        for (int r = 0; r < g.rows; r++)
+            for (int ch = grp * g.cpg; ch < (grp + 1) * g.cpg; ch++) {
+                a += sm[((size_t)r * g.C + ch) * 2];
+                c += sm[((size_t)r * g.C + ch) * 2 + 1];
+            }
+        float* o = part + (((size_t)b * g.nch + chunk) * g.G + grp) * 2;
+        o[0] = a; o[1] = c;
+    }
+}
+
+__global__ void gn_apply_kernel(const bf16* __restrict__ x, const float* __restrict__ part,
+                                const float* __restrict__ gamma, const float* __restrict__ beta,
+                                bf16* __restrict__ y, float* __restrict__ stats, GnGeom g, float eps, int act) {
+    extern __shared__ float sm[];  // mean[G], rstd[G]
+    const int b = blockIdx.y, chunk = blockIdx.x;
+    for (int grp = threadIdx.x; grp < g.G; grp += blockDim.x) {
+        float a = 0.f, c = 0.f;
+        for (int k = 0; k < g.nch; k++) {
+            const float* o = part + (((size_t)b * g.nch + k) * g.G + grp) * 2;
+            a += o[0]; c += o[1];
+        }
+        const float n = (float)g.cpg * (float)g.HW;
+        const float mean = a / n;
+        const float var = fmaxf(c / n - mean * mean, 0.f);
+        const float rstd = rsqrtf(var + eps);
+        sm[grp] = mean; sm[g.G + grp] = rstd;
+        if (chunk == 0 && stats) { stats[((size_t)b * g.G + grp) * 2] = mean; stats[((size_t)b * g.G + grp) * 2 + 1] = rstd; }
+    }
+    __syncthreads();
+    const int cc = threadIdx.x % g.C8, rl = threadIdx.x / g.C8;
+    float sc[8], sh[8];
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+        const int ch = cc * 8 + e, grp = ch / g.cpg;
+        sc[e] = sm[g.G + grp] * gamma[ch];
+        sh[e] = beta[ch] - sm[grp] * sc[e];
+    }
+    const int p0 = chunk * g.ppb, p1 = min(g.HW, p0 + g.ppb);
+    const size_t base = (size_t)b * g.HW * g.C + cc * 8;
+    for (int p = p0 + rl; p < p1; p += g.rows) {
+        const bf16x8 v = ld8(x + base + (size_t)p * g.C);
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            float f = bf2f(v[e]) * sc[e] + sh[e];
+            if (act) f = silu_f(f);
+            o[e] = f2bf(f);
+        }
+        st8(y + base + (size_t)p * g.C, o);
+    }
+}
+
+__global__ void gn_bwd_stats_kernel(const bf16* __restrict__ x, const bf16* __restrict__ dy,
+                                    const float* __restrict__ stats, const float* __restrict__ gamma,
+                                    const float* __restrict__ beta, float* __restrict__ part, GnGeom g, int act) {
+    extern __shared__ float sm[];  // [rows][C][2]
+    const int b = blockIdx.y, chunk = blockIdx.x;
+    const int cc = threadIdx.x % g.C8, rl = threadIdx.x / g.C8;
+    float mu[8], rs[8], ga[8], be[8], a[8], c[8];
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+        const int ch = cc * 8 + e, grp = ch / g.cpg;
+        mu[e] = stats[((size_t)b * g.G + grp) * 2]; rs[e] = stats[((size_t)b * g.G + grp) * 2 + 1];
+        ga[e] = gamma[ch]; be[e] = beta[ch]; a[e] = c[e] = 0.f;
+    }
+    const int p0 = chunk * g.ppb, p1 = min(g.HW, p0 + g.ppb);
+    const size_t base = (size_t)b * g.HW * g.C + cc * 8;
+    for (int p = p0 + rl; p < p1; p += g.rows) {
+        const bf16x8 xv = ld8(x + base + (size_t)p * g.C), dv = ld8(dy + base + (size_t)p * g.C);
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            const float xh = (bf2f(xv[e]) - mu[e]) * rs[e];
+            float d = bf2f(dv[e]);
+            if (act) d *= silu_grad_f(xh * ga[e] + be[e]);
+            a[e] += d * xh; c[e] += d;
+        }
+    }
+    float* row = sm + (size_t)rl * g.C * 2;
+#pragma unroll
+    for (int e = 0; e < 8; e++) { row[(cc * 8 + e) * 2] = a[e]; row[(cc * 8 + e) * 2 + 1] = c[e]; }
+    __syncthreads();
+    for (int i = threadIdx.x; i < g.C * 2; i += blockDim.x) {
+        float t = 0.f;
+        for (int r = 0; r < g.rows; r++) t += sm[(size_t)r * g.C * 2 + i];
+        part[((size_t)b * g.nch + chunk) * g.C * 2 + i] = t;
+    }
+}
+
+__global__ void gn_bwd_apply_kernel(const bf16* __restrict__ x, const bf16* __restrict__ dy,
+                                    const float* __restrict__ stats, const float* __restrict__ gamma,
+                                    const float* __restrict__ beta, const float* __restrict__ part,
+                                    bf16* __restrict__ dx, GnGeom g, int act) {
+    extern __shared__ float sm[];  // s1[G], s2[G]
+    const int b = blockIdx.y, chunk = blockIdx.x;
+    for (int grp = threadIdx.x; grp < g.G; grp += blockDim.x) {
+        float s1 = 0.f, s2 = 0.f;
+        for (int k = 0; k < g.nch; k++) {
+            const float* o = part + ((size_t)b * g.nch + k) * g.C * 2;
+            for (int ch = grp * g.cpg; ch < (grp + 1) * g.cpg; ch++) { s2 += gamma[ch] * o[ch * 2]; s1 += gamma[ch] * o[ch * 2 + 1]; }
+        }
+        const float n = (float)g.cpg * (float)g.HW;
+        sm[grp] = s1 / n; sm[g.G + grp] = s2 / n;
+    }
+    __syncthreads();
+    const int cc = threadIdx.x % g.C8, rl = threadIdx.x / g.C8;
+    float mu[8], rs[8], ga[8], be[8], m1[8], m2[8];
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+        const int ch = cc * 8 + e, grp = ch / g.cpg;
+        mu[e] = stats[((size_t)b * g.G + grp) * 2]; rs[e] = stats[((size_t)b * g.G + grp) * 2 + 1];
+        ga[e] = gamma[ch]; be[e] = beta[ch]; m1[e] = sm[grp]; m2[e] = sm[g.G + grp];
+    }
+    const int p0 = chunk * g.ppb, p1 = min(g.HW, p0 + g.ppb);
+    const size_t base = (size_t)b * g.HW * g.C + cc * 8;
+    for (int p = p0 + rl; p < p1; p += g.rows) {
+        const bf16x8 xv = ld8(x + base + (size_t)p * g.C), dv = ld8(dy + base + (size_t)p * g.C);
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            const float xh = (bf2f(xv[e]) - mu[e]) * rs[e];
+            float d = bf2f(dv[e]);
+            if (act) d *= silu_grad_f(xh * ga[e] + be[e]);
+            o[e] = f2bf(rs[e] * (d * ga[e] - m1[e] - xh * m2[e]));
+        }
+        st8(dx + base + (size_t)p * g.C, o);
+    }
+}
+
+// out[j*ostride + ooff] += sum_p part[p*X + j*2 + sel]  style reductions are expressed with this:
+// out[i] (+)= sum_{p<P} part[p*pstride + i*istride + ioff],  i < n
+__global__ void colsum_reduce_kernel(const float* __restrict__ part, float* __restrict__ out, int P, size_t pstride,
+                                     int istride, int ioff, int n, int accumulate) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float t = 0.f;
+    for (int p = 0; p < P; p++) t += part[(size_t)p * pstride + (size_t)i * istride + ioff];
+    out[i] = accumulate ? out[i] + t : t;
+}
+
+// ---------------------------------------------------------------------------------------------
+// LayerNorm over the last dim C (C % 8 == 0, C <= 8*64*LN_MAXCH): one wave per token row.
+constexpr int LN_MAXCH = 4;  // chunks of 8 per lane -> C <= 2048
+
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16* __restrict__ x, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, bf16* __restrict__ y,
+                                                     float* __restrict__ stats, int rows, int C, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int C8 = C >> 3;
+    bf16x8 v[LN_MAXCH];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXCH; i++) {
+        const int cc = lane + 64 * i;
+        if (cc < C8) {
+            v[i] = ld8(x + (size_t)row * C + cc * 8);
+#pragma unroll
+            for (int e = 0; e < 8; e++) s += bf2f(v[i][e]);
+        }
+    }
+    const float mean = wave_sum(s) / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXCH; i++) {
+        const int cc = lane + 64 * i;
+        if (cc < C8) {
+#pragma unroll
+            for (int e = 0; e < 8; e++) { const float d = bf2f(v[i][e]) - mean; q += d * d; }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
+    if (lane == 0 && stats) { stats[(size_t)row * 2] = mean; stats[(size_t)row * 2 + 1] = rstd; }
+#pragma unroll
+    for (int i = 0; i < LN_MAXCH; i++) {
+        const int cc = lane + 64 * i;
+        if (cc < C8) {
+            bf16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                const int ch = cc * 8 + e;
+                o[e] = f2bf((bf2f(v[i][e]) - mean) * rstd * gamma[ch] + beta[ch]);
+            }
+            st8(y + (size_t)row * C + cc * 8, o);
+        }
+    }
+}
+
+// dx = rstd*(dy*gamma - mean(dy*gamma) - xhat*mean(dy*gamma*xhat)); per-block partial dgamma/dbeta.
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* __restrict__ x, const bf16* __restrict__ dy,
+                                                     const float* __restrict__ stats, const float* __restrict__ gamma,
+                                                     bf16* __restrict__ dx, float* __restrict__ part, int rows, int C,
+                                                     int rows_per_block) {
+    extern __shared__ float dyn[];  // [4 waves][C][2] for the param-grad partials
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int C8 = C >> 3;
+    float ga[LN_MAXCH][8], pg[LN_MAXCH][8], pb[LN_MAXCH][8];
+#pragma unroll
+    for (int i = 0; i < LN_MAXCH; i++)
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            const int cc = lane + 64 * i;
+            ga[i][e] = cc < C8 ? gamma[cc * 8 + e] : 0.f;
+            pg[i][e] = pb[i][e] = 0.f;
+        }
+    const int rbeg = blockIdx.x * rows_per_block, rend = min(rows, rbeg + rows_per_block);
+    for (int row = rbeg + wave; row < rend; row += 4) {
+        const float mean = stats[(size_t)row * 2], rstd = stats[(size_t)row * 2 + 1];
+        float xh[LN_MAXCH][8], dg[LN_MAXCH][8];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < LN_MAXCH; i++) {
+            const int cc = lane + 64 * i;
+            if (cc < C8) {
+                const bf16x8 xv = ld8(x + (size_t)row * C + cc * 8), dv = ld8(dy + (size_t)row * C + cc * 8);
+#pragma unroll
+                for (int e = 0; e < 8; e++) {
+                    xh[i][e] = (bf2f(xv[e]) - mean) * rstd;
+                    const float d = bf2f(dv[e]);
+                    pg[i][e] += d * xh[i][e]; pb[i][e] += d;
+                    dg[i][e] = d * ga[i][e];
+                    s1 += dg[i][e]; s2 += dg[i][e] * xh[i][e];
+                }
+            }
+        }
+        s1 = wave_sum(s1) / (float)C; s2 = wave_sum(s2) / (float)C;
+#pragma unroll
+        for (int i = 0; i < LN_MAXCH; i++) {
+            const int cc = lane + 64 * i;
+            if (cc < C8) {
+                bf16x8 o;
+#pragma unroll
+                for (int e = 0; e < 8; e++) o[e] = f2bf(rstd * (dg[i][e] - s1 - xh[i][e] * s2));
+                st8(dx + (size_t)row * C + cc * 8, o);
+            }
+        }
+    }
+    if (part) {
+#pragma unroll
+        for (int i = 0; i < LN_MAXCH; i++) {
+            const int cc = lane + 64 * i;
+            if (cc < C8) {
+#pragma unroll
+                for (int e = 0; e < 8; e++) {
+                    dyn[((size_t)wave * C + cc * 8 + e) * 2] = pg[i][e];
+                    dyn[((size_t)wave * C + cc * 8 + e) * 2 + 1] = pb[i][e];
+                }
+            }
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < C * 2; i += 256)
+            part[(size_t)blockIdx.x * C * 2 + i] = dyn[i] + dyn[(size_t)C * 2 + i] + dyn[(size_t)2 * C * 2 + i] + dyn[(size_t)3 * C * 2 + i];
+    }
+}
+
+static int gn_geom(GnGeom& g, int B, int HW, int C, int G) {
+    if (C % 8 || C % G || C > GN_MAX_C || B <= 0 || HW <= 0) return SIDLSG_EINVAL;
+    g.C = C; g.HW = HW; g.G = G; g.cpg = C / G; g.C8 = C / 8;
+    g.rows = 256 / g.C8; if (g.rows < 1) g.rows = 1;
+    if (g.rows > HW) g.rows = HW;
+    // enough (sample, chunk) blocks to fill 256 CUs x2, each chunk >= rows*4 pixels
+    int want = (512 + B - 1) / B;
+    int maxch = HW / (g.rows * 4); if (maxch < 1) maxch = 1;
+    g.nch = want < maxch ? want : maxch;
+    if (g.nch > 64) g.nch = 64;
+    g.ppb = (HW + g.nch - 1) / g.nch;
+    g.nch = (HW + g.ppb - 1) / g.ppb;
+    return SIDLSG_OK;
+}
+
+extern "C" {
+
+// workspace sizes (in floats) a caller must provide
+int sidlsg_groupnorm_ws_floats(int B, int HW, int C, int G) {
+    GnGeom g; if (gn_geom(g, B, HW, C, G)) return -1;
+    return B * g.nch * C * 2;   // large enough for fwd (G*2 per chunk) and bwd (C*2 per chunk)
+}
+int sidlsg_groupnorm_nchunks(int B, int HW, int C, int G) {
+    GnGeom g; if (gn_geom(g, B, HW, C, G)) return -1;
+    return g.nch;
+}
+
+// y = act(GroupNorm(x)); x,y: [B][HW][C] bf16; stats: [B][G][2] fp32 (mean, rstd) saved for backward
+int sidlsg_groupnorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* stats, float* ws,
+                         int B, int HW, int C, int G, float eps, int silu, void* stream) {
+    GnGeom g; if (int e = gn_geom(g, B, HW, C, G)) return e;
+    hipStream_t s = (hipStream_t)stream;
+    const int threads = g.C8 * g.rows;
+    hipLaunchKernelGGL(gn_stats_kernel, dim3(g.nch, B), dim3(threads), (size_t)g.rows * C * 2 * sizeof(float), s,
+                       (const bf16*)x, ws, g);
+    hipLaunchKernelGGL(gn_apply_kernel, dim3(g.nch, B), dim3(threads), (size_t)2 * G * sizeof(float), s,
+                       (const bf16*)x, ws, gamma, beta, (bf16*)y, stats, g, eps, silu);
+    return sidlsg_last_error();
+}
+
+// dx (and optionally dgamma/dbeta +=) of y = act(GroupNorm(x))
+int sidlsg_groupnorm_bwd(const void* x, const void* dy, const float* stats, const float* gamma, const float* beta,
+                         void* dx, float* dgamma, float* dbeta, float* ws, int B, int HW, int C, int G, int silu,
+                         void* stream) {
+    GnGeom g; if (int e = gn_geom(g, B, HW, C, G)) return e;
+    hipStream_t s = (hipStream_t)stream;
+    const int threads = g.C8 * g.rows;
+    hipLaunchKernelGGL(gn_bwd_stats_kernel, dim3(g.nch, B), dim3(threads), (size_t)g.rows * C * 2 * sizeof(float), s,
+                       (const bf16*)x, (const bf16*)dy, stats, gamma, beta, ws, g, silu);
+    hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(g.nch, B), dim3(threads), (size_t)2 * G * sizeof(float), s,
+                       (const bf16*)x, (const bf16*)dy, stats, gamma, beta, ws, (bf16*)dx, g, silu);
+    if (dgamma && dbeta) {
+        const int P = B * g.nch;
+        hipLaunchKernelGGL(colsum_reduce_kernel, dim3((C + 255) / 256), dim3(256), 0, s, ws, dgamma, P, (size_t)C * 2, 2, 0, C, 1);
+        hipLaunchKernelGGL(colsum_reduce_kernel, dim3((C + 255) / 256), dim3(256), 0, s, ws, dbeta, P, (size_t)C * 2, 2, 1, C, 1);
+    }
+    return sidlsg_last_error();
+}
+
+// y = LayerNorm(x) over C; x,y [rows][C] bf16; stats [rows][2]
+int sidlsg_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* stats, int rows, int C,
+                         float eps, void* stream) {
+    if (C % 8 || C > 8 * 64 * LN_MAXCH || rows <= 0) return SIDLSG_EINVAL;
+    hipLaunchKernelGGL(ln_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, gamma, beta,
+                       (bf16*)y, stats, rows, C, eps);
+    return sidlsg_last_error();
+}
+
+int sidlsg_layernorm_bwd_nblocks(int rows) {
+    int nb = (rows + 63) / 64; if (nb > 1024) nb = 1024; if (nb < 1) nb = 1; return nb;
+}
+
+// dx, and dgamma/dbeta (+=) when non-null; ws: [nblocks][C][2] floats
+int sidlsg_layernorm_bwd(const void* x, const void* dy, const float* stats, const float* gamma, void* dx, float* dgamma,
+                         float* dbeta, float* ws, int rows, int C, void* stream) {
+    if (C % 8 || C > 8 * 64 * LN_MAXCH || rows <= 0) return SIDLSG_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    const int nb = sidlsg_layernorm_bwd_nblocks(rows);
+    const int rpb = (rows + nb - 1) / nb;
+    const bool pg = dgamma && dbeta;
+    hipLaunchKernelGGL(ln_bwd_kernel, dim3(nb), dim3(256), pg ? (size_t)4 * C * 2 * sizeof(float) : 0, s, (const bf16*)x,
+                       (const bf16*)dy, stats, gamma, (bf16*)dx, pg ? ws : nullptr, rows, C, rpb);
+    if (pg) {
+        hipLaunchKernelGGL(colsum_reduce_kernel, dim3((C + 255) / 256), dim3(256), 0, s, ws, dgamma, nb, (size_t)C * 2, 2, 0, C, 1);
+        hipLaunchKernelGGL(colsum_reduce_kernel, dim3((C + 255) / 256), dim3(256), 0, s, ws, dbeta, nb, (size_t)C * 2, 2, 1, C, 1);
+    }
+    return sidlsg_last_error();
+}
+
+}  // extern "C"

@@ -1,0 +1,510 @@
+"""Host side of the HIP kernels: thin launch wrappers + torch.autograd.Function glue.
+
+Follows the reference's op-wrapper convention (torch_utils/ops/bias_act.py: public function ->
+cached autograd.Function -> plugin call on the current stream) with one deliberate difference:
+there is no `impl='ref'` fallback.  If the library is absent or a tensor is not on the GPU these
+raise.  PyTorch is used only for device memory, the current stream and autograd bookkeeping.
+
+Conventions: activations are bf16, NHWC / token-major and contiguous; parameters are fp32
+"masters" whose `.grad` is a pre-allocated fp32 view into the network's flat gradient buffer --
+weight/bias gradients are ACCUMULATED IN PLACE by the kernels (atomics / +=) and the autograd
+functions return None for them, so no per-parameter gradient tensors are ever materialised.
+"""
+import torch
+
+from ._lib import lib
+
+BF16 = torch.bfloat16
+F32 = torch.float32
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _s():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _chk(t, dtype=None):
+    if not t.is_cuda:
+        raise RuntimeError('sid_lsg_amd ops need CUDA(HIP) tensors: there is no CPU fallback')
+    if dtype is not None and t.dtype != dtype:
+        raise RuntimeError(f'expected {dtype}, got {t.dtype}')
+    if not t.is_contiguous():
+        raise RuntimeError('expected a contiguous tensor')
+    return t
+
+
+def _wants_grad(p):
+    return p is not None and p.requires_grad and p.grad is not None
+
+
+# ------------------------------------------------------------------------------------------------
+# raw launches
+def gemm(a, w16, out=None, bias=None, res=None, rowvec=None, rows_per_batch=1, alpha=1.0, out_f32=False, lda=None):
+    """C[M,N] = alpha*A[M,K] W[N,K]^T + bias + rowvec[m//rpb] + res"""
+    M = a.shape[0]
+    K = w16.shape[1]
+    N = w16.shape[0]
+    lda = a.stride(0) if lda is None else lda
+    if out is None:
+        out = torch.empty((M, N), device=a.device, dtype=F32 if out_f32 else BF16)
+    lib.sidlsg_gemm_bf16(_p(a), lda, _p(w16), _p(out), out.stride(0), _p(bias), _p(res), res.stride(0) if res is not None else 0,
+                         _p(rowvec), rows_per_batch, M, N, K, float(alpha), 1 if out_f32 else 0, _s())
+    return out
+
+
+def conv3x3(x, w16, bias=None, res=None, rowvec=None, stride=1, ups=0, out_f32=False):
+    """x: [B,Hs,Ws,Cin] bf16 NHWC; w16: [Cout, 9*Cin]; -> [B,Ho,Wo,Cout]"""
+    B, Hs, Ws, Cin = x.shape
+    H, W = (2 * Hs, 2 * Ws) if ups else (Hs, Ws)
+    Cout = w16.shape[0]
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    out = torch.empty((B, Ho, Wo, Cout), device=x.device, dtype=F32 if out_f32 else BF16)
+    lib.sidlsg_conv3x3_bf16(_p(x), Cin, _p(w16), _p(out), Cout, _p(bias), _p(res), Cout if res is not None else 0, _p(rowvec),
+                            B, H, W, Cin, Cout, stride, ups, 1.0, 1 if out_f32 else 0, _s())
+    return out
+
+
+def colsum(g2d, rows_per_batch, per_batch=False, total=None):
+    """g2d: [B*rows_per_batch, N] bf16.  total (fp32 [N]) is accumulated in place; returns per-batch sums if asked."""
+    R, N = g2d.shape
+    B = R // rows_per_batch
+    nch = lib.sidlsg_colsum_nchunks.raw(B, rows_per_batch)
+    ws = torch.empty(B * nch * N, device=g2d.device, dtype=F32)
+    pb = torch.empty((B, N), device=g2d.device, dtype=F32) if per_batch else None
+    lib.sidlsg_colsum(_p(g2d), g2d.stride(0), _p(pb), _p(total), _p(ws), B, rows_per_batch, N, _s())
+    return pb
+
+
+# ------------------------------------------------------------------------------------------------
+class _Linear(torch.autograd.Function):
+    """y = x W^T + b (+ res) (+ rowvec broadcast over rows_per_batch rows).  x: [M,K] bf16."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, w16, w16t, res, rowvec, rows_per_batch, out_f32):
+        _chk(x, BF16)
+        y = gemm(x, w16, bias=bias, res=res, rowvec=rowvec, rows_per_batch=rows_per_batch, out_f32=out_f32)
+        ctx.save_for_backward(x, weight, bias, w16t)
+        ctx.rpb = rows_per_batch
+        ctx.has_res = res is not None
+        ctx.has_rv = rowvec is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, bias, w16t = ctx.saved_tensors
+        dy = dy.contiguous()
+        if dy.dtype != BF16:
+            dy = dy.to(BF16)
+        dx = gemm(dy, w16t) if ctx.needs_input_grad[0] else None
+        if _wants_grad(weight):
+            M, K = x.shape
+            lib.sidlsg_wgrad_bf16(_p(dy), dy.stride(0), _p(x), x.stride(0), _p(weight.grad), M, weight.shape[0], K, _s())
+        drv = None
+        need_b = _wants_grad(bias)
+        if ctx.has_rv and ctx.needs_input_grad[6]:
+            drv = colsum(dy, ctx.rpb, per_batch=True, total=bias.grad if need_b else None)
+        elif need_b:
+            colsum(dy, dy.shape[0], total=bias.grad)
+        dres = dy if (ctx.has_res and ctx.needs_input_grad[5]) else None
+        return dx, None, None, None, None, dres, drv, None, None
+
+
+def linear(x, weight, bias, w16, w16t, res=None, rowvec=None, rows_per_batch=1, out_f32=False):
+    return _Linear.apply(x, weight, bias, w16, w16t, res, rowvec, rows_per_batch, out_f32)
+
+
+class _Conv3x3(torch.autograd.Function):
+    """NHWC 3x3 conv, pad 1, stride 1|2, optional fused nearest-x2 upsample of the input."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, w16, w16t, res, rowvec, stride, ups, out_f32, bias_p):
+        _chk(x, BF16)
+        y = conv3x3(x, w16, bias=bias_p if bias_p is not None else bias, res=res, rowvec=rowvec, stride=stride, ups=ups,
+                    out_f32=out_f32)
+        ctx.save_for_backward(x, weight, bias, w16t)
+        ctx.cfg = (stride, ups, res is not None, rowvec is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, bias, w16t = ctx.saved_tensors
+        stride, ups, has_res, has_rv = ctx.cfg
+        dy = dy.contiguous()
+        if dy.dtype != BF16:
+            dy = dy.to(BF16)
+        B, Ho, Wo, Cout = dy.shape
+        Cin = x.shape[3]
+        dx = None
+        if ctx.needs_input_grad[0]:
+            g = dy
+            if stride == 2:
+                g = torch.empty((B, x.shape[1], x.shape[2], Cout), device=dy.device, dtype=BF16)
+                lib.sidlsg_zero_insert2(_p(dy), _p(g), B, Ho, Wo, x.shape[1], x.shape[2], Cout, _s())
+            dx = conv3x3(g, w16t)           # w16t: [Cin, 9*Cout], taps flipped
+            if ups:
+                full = dx
+                dx = torch.empty_like(x)
+                lib.sidlsg_sumpool2x2(_p(full), _p(dx), B, x.shape[1], x.shape[2], Cin, _s())
+        co_w, ci_w = weight.shape[0], weight.shape[1]     # logical (unpadded) sizes of the master
+        padded = (co_w != Cout) or (ci_w != Cin)           # conv_in (Cin 4->8) / conv_out (Cout 4->8)
+        if _wants_grad(weight):
+            H, W = (2 * x.shape[1], 2 * x.shape[2]) if ups else (x.shape[1], x.shape[2])
+            if not padded:
+                lib.sidlsg_conv3x3_wgrad_bf16(_p(dy), Cout, _p(x), Cin, _p(weight.grad), B, H, W, Cin, Cout, stride, ups, _s())
+            else:
+                tmp = torch.zeros((Cout, 9, Cin), device=dy.device, dtype=F32)
+                lib.sidlsg_conv3x3_wgrad_bf16(_p(dy), Cout, _p(x), Cin, _p(tmp), B, H, W, Cin, Cout, stride, ups, _s())
+                weight.grad.permute(0, 2, 3, 1).reshape(co_w, 9, ci_w).add_(tmp[:co_w, :, :ci_w])
+        dy2 = dy.view(B * Ho * Wo, Cout)
+        drv = None
+        need_b = _wants_grad(bias)
+        btot = None
+        if need_b:
+            btot = bias.grad if co_w == Cout else torch.zeros(Cout, device=dy.device, dtype=F32)
+        if has_rv and ctx.needs_input_grad[6]:
+            drv = colsum(dy2, Ho * Wo, per_batch=True, total=btot)
+        elif need_b:
+            colsum(dy2, dy2.shape[0], total=btot)
+        if need_b and co_w != Cout:
+            bias.grad.add_(btot[:co_w])
+        dres = dy if (has_res and ctx.needs_input_grad[5]) else None
+        return dx, None, None, None, None, dres, drv, None, None, None, None
+
+
+def conv3x3_op(x, weight, bias, w16, w16t, res=None, rowvec=None, stride=1, ups=0, out_f32=False, bias_p=None):
+    return _Conv3x3.apply(x, weight, bias, w16, w16t, res, rowvec, stride, ups, out_f32, bias_p)
+
+
+class _GroupNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, groups, eps, silu):
+        _chk(x, BF16)
+        B, C = x.shape[0], x.shape[-1]
+        HW = x.numel() // (B * C)
+        n = lib.sidlsg_groupnorm_ws_floats.raw(B, HW, C, groups)
+        if n < 0:
+            raise RuntimeError(f'groupnorm: unsupported shape B={B} HW={HW} C={C} G={groups}')
+        ws = torch.empty(n, device=x.device, dtype=F32)
+        stats = torch.empty((B, groups, 2), device=x.device, dtype=F32)
+        y = torch.empty_like(x)
+        lib.sidlsg_groupnorm_fwd(_p(x), _p(gamma), _p(beta), _p(y), _p(stats), _p(ws), B, HW, C, groups, float(eps), int(silu), _s())
+        ctx.save_for_backward(x, gamma, beta, stats)
+        ctx.cfg = (B, HW, C, groups, int(silu), n)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, beta, stats = ctx.saved_tensors
+        B, HW, C, groups, silu, n = ctx.cfg
+        dy = dy.contiguous()
+        ws = torch.empty(n, device=x.device, dtype=F32)
+        dx = torch.empty_like(x)
+        pg = _wants_grad(gamma) and _wants_grad(beta)
+        lib.sidlsg_groupnorm_bwd(_p(x), _p(dy), _p(stats), _p(gamma), _p(beta), _p(dx), _p(gamma.grad) if pg else None,
+                                 _p(beta.grad) if pg else None, _p(ws), B, HW, C, groups, silu, _s())
+        return dx, None, None, None, None, None
+
+
+def group_norm(x, gamma, beta, groups, eps, silu):
+    return _GroupNorm.apply(x, gamma, beta, groups, eps, silu)
+
+
+class _LayerNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        _chk(x, BF16)
+        C = x.shape[-1]
+        rows = x.numel() // C
+        y = torch.empty_like(x)
+        stats = torch.empty((rows, 2), device=x.device, dtype=F32)
+        lib.sidlsg_layernorm_fwd(_p(x), _p(gamma), _p(beta), _p(y), _p(stats), rows, C, float(eps), _s())
+        ctx.save_for_backward(x, gamma, beta, stats)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, beta, stats = ctx.saved_tensors
+        C = x.shape[-1]
+        rows = x.numel() // C
+        dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        pg = _wants_grad(gamma) and _wants_grad(beta)
+        ws = torch.empty(lib.sidlsg_layernorm_bwd_nblocks.raw(rows) * C * 2, device=x.device, dtype=F32) if pg else None
+        lib.sidlsg_layernorm_bwd(_p(x), _p(dy), _p(stats), _p(gamma), _p(dx), _p(gamma.grad) if pg else None,
+                                 _p(beta.grad) if pg else None, _p(ws), rows, C, _s())
+        return dx, None, None, None
+
+
+def layer_norm(x, gamma, beta, eps=1e-5):
+    return _LayerNorm.apply(x, gamma, beta, eps)
+
+
+class _Attention(torch.autograd.Function):
+    """q: [B,Nq,*] view with heads*D channels starting at column qoff of a row of width ldq; same for k, v."""
+
+    @staticmethod
+    def forward(ctx, qbuf, kvbuf, heads, D, qoff, koff, voff):
+        _chk(qbuf, BF16)
+        _chk(kvbuf, BF16)
+        B, Nq, ldq = qbuf.shape
+        Nk, ldk = kvbuf.shape[1], kvbuf.shape[2]
+        C = heads * D
+        o = torch.empty((B, Nq, C), device=qbuf.device, dtype=BF16)
+        lse = torch.empty((B, heads, Nq), device=qbuf.device, dtype=F32)
+        es = qbuf.element_size()
+        lib.sidlsg_attn_fwd(qbuf.data_ptr() + qoff * es, kvbuf.data_ptr() + koff * es, kvbuf.data_ptr() + voff * es, _p(o), _p(lse),
+                            B, heads, Nq, Nk, D, ldq, ldk, ldk, C, Nq * ldq, Nk * ldk, Nk * ldk, Nq * C, _s())
+        ctx.save_for_backward(qbuf, kvbuf, o, lse)
+        ctx.cfg = (heads, D, qoff, koff, voff)
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        qbuf, kvbuf, o, lse = ctx.saved_tensors
+        heads, D, qoff, koff, voff = ctx.cfg
+        B, Nq, ldq = qbuf.shape
+        Nk, ldk = kvbuf.shape[1], kvbuf.shape[2]
+        C = heads * D
+        do = do.contiguous()
+        same = qbuf.data_ptr() == kvbuf.data_ptr()
+        dq = torch.empty_like(qbuf)
+        dkv = dq if same else torch.empty_like(kvbuf)
+        delta = torch.empty((B, heads, Nq), device=qbuf.device, dtype=F32)
+        es = 2
+        lib.sidlsg_attn_bwd(qbuf.data_ptr() + qoff * es, kvbuf.data_ptr() + koff * es, kvbuf.data_ptr() + voff * es, _p(o), _p(do),
+                            _p(lse), dq.data_ptr() + qoff * es, dkv.data_ptr() + koff * es, dkv.data_ptr() + voff * es, _p(delta),
+                            B, heads, Nq, Nk, D, ldq, ldk, ldk, C, Nq * ldq, Nk * ldk, Nk * ldk, Nq * C, _s())
+        return dq, (None if same else dkv), None, None, None, None, None
+
+
+def self_attention(qkv, heads):
+    """qkv: [B,N,3C] (fused projection output) -> [B,N,C]"""
+    C = qkv.shape[2] // 3
+    return _Attention.apply(qkv, qkv, heads, C // heads, 0, C, 2 * C)
+
+
+def cross_attention(q, kv, heads):
+    """q: [B,N,C]; kv: [B,L,2C] (fused k|v projection of the text states) -> [B,N,C]"""
+    C = q.shape[2]
+    return _Attention.apply(q, kv, heads, C // heads, 0, 0, C)
+
+
+class _GEGLU(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, h):
+        _chk(h, BF16)
+        F2 = h.shape[-1]
+        M = h.numel() // F2
+        y = torch.empty(h.shape[:-1] + (F2 // 2,), device=h.device, dtype=BF16)
+        lib.sidlsg_geglu_fwd(_p(h), _p(y), M, F2 // 2, _s())
+        ctx.save_for_backward(h)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (h,) = ctx.saved_tensors
+        F2 = h.shape[-1]
+        dh = torch.empty_like(h)
+        lib.sidlsg_geglu_bwd(_p(h), _p(dy.contiguous()), _p(dh), h.numel() // F2, F2 // 2, _s())
+        return dh
+
+
+def geglu(h):
+    return _GEGLU.apply(h)
+
+
+class _SiLU(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        _chk(x, BF16)
+        y = torch.empty_like(x)
+        lib.sidlsg_silu_fwd(_p(x), _p(y), x.numel(), _s())
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        dx = torch.empty_like(x)
+        lib.sidlsg_silu_bwd(_p(x), _p(dy.contiguous()), _p(dx), x.numel(), _s())
+        return dx
+
+
+def silu(x):
+    return _SiLU.apply(x)
+
+
+class _Concat(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        _chk(a, BF16)
+        _chk(b, BF16)
+        C1, C2 = a.shape[-1], b.shape[-1]
+        M = a.numel() // C1
+        out = torch.empty(a.shape[:-1] + (C1 + C2,), device=a.device, dtype=BF16)
+        lib.sidlsg_concat2(_p(a), _p(b), _p(out), M, C1, C2, 0, _s())
+        ctx.shapes = (a.shape, b.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        sa, sb = ctx.shapes
+        g = g.contiguous()
+        da = torch.empty(sa, device=g.device, dtype=BF16)
+        db = torch.empty(sb, device=g.device, dtype=BF16)
+        lib.sidlsg_concat2(_p(da), _p(db), _p(g), da.numel() // sa[-1], sa[-1], sb[-1], 1, _s())
+        return da, db
+
+
+def concat_channels(a, b):
+    return _Concat.apply(a, b)
+
+
+class _Add(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        o = torch.empty_like(a)
+        lib.sidlsg_add_bf16(_p(_chk(a, BF16)), _p(_chk(b, BF16)), _p(o), a.numel(), _s())
+        return o
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, g
+
+
+def add(a, b):
+    return _Add.apply(a, b)
+
+
+def timestep_embed(t, dim):
+    out = torch.empty((t.shape[0], dim), device=t.device, dtype=BF16)
+    lib.sidlsg_timestep_embed(_p(_chk(t, torch.int64)), _p(out), t.shape[0], dim, _s())
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# scheduler / guidance glue and losses
+class _NoisyInput(torch.autograd.Function):
+    """x_t = s0*x0 + s1*noise -> (NHWC bf16 [dup*B,H,W,8], x_t fp32 NCHW).  x0 may be None."""
+
+    @staticmethod
+    def forward(ctx, x0, noise, s0, s1, dup):
+        B, C, H, W = noise.shape
+        out = torch.empty((dup * B, H, W, 8), device=noise.device, dtype=BF16)
+        xt = torch.empty_like(noise)
+        lib.sidlsg_noisy_input(_p(x0), _p(_chk(noise, F32)), _p(s0), _p(s1), _p(out), _p(xt), B, C, H * W, 8, dup, _s())
+        ctx.save_for_backward(s0, s1)
+        ctx.cfg = (B, C, H, W, dup)
+        return out, xt
+
+    @staticmethod
+    def backward(ctx, g, gxt):
+        s0, s1 = ctx.saved_tensors
+        B, C, H, W, dup = ctx.cfg
+        g = g.contiguous()
+        outs = []
+        for idx, sc in ((0, s0), (1, s1)):
+            if not ctx.needs_input_grad[idx]:
+                outs.append(None)
+                continue
+            d = torch.empty((B, C, H, W), device=g.device, dtype=F32)
+            lib.sidlsg_noisy_input_bwd(_p(g), _p(sc), _p(d), B, C, H * W, 8, dup, 0, _s())
+            if gxt is not None:
+                d = d + gxt * sc.view(B, 1, 1, 1)
+            outs.append(d)
+        return outs[0], outs[1], None, None, None
+
+
+def noisy_input(x0, noise, s0, s1, dup):
+    return _NoisyInput.apply(x0, noise, s0, s1, dup)
+
+
+class _CfgX0(torch.autograd.Function):
+    """eps [dup*B,HW,C] fp32 (+ x_t) -> NCHW fp32 guided eps or x0 prediction."""
+
+    @staticmethod
+    def forward(ctx, eps, xt, s0, s1, kappa, predict_x0):
+        B, C, H, W = xt.shape
+        dup = eps.shape[0] // B
+        out = torch.empty_like(xt)
+        lib.sidlsg_cfg_x0(_p(_chk(eps, F32)), _p(_chk(xt, F32)), _p(s0), _p(s1), _p(out), B, C, H * W, eps.shape[-1], dup,
+                          float(kappa), int(predict_x0), _s())
+        ctx.save_for_backward(s0, s1)
+        ctx.cfg = (B, C, H, W, dup, float(kappa), int(predict_x0))
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        s0, s1 = ctx.saved_tensors
+        B, C, H, W, dup, kappa, px0 = ctx.cfg
+        deps = torch.empty((dup * B, H * W, 8), device=g.device, dtype=BF16)
+        dxt = torch.empty((B, C, H, W), device=g.device, dtype=F32) if ctx.needs_input_grad[1] else None
+        lib.sidlsg_cfg_x0_bwd(_p(g.contiguous()), _p(s0), _p(s1), _p(deps), _p(dxt), B, C, H * W, 8, dup, kappa, px0, _s())
+        return deps, dxt, None, None, None, None
+
+
+def cfg_x0(eps, xt, s0, s1, kappa, predict_x0):
+    return _CfgX0.apply(eps, xt, s0, s1, kappa, predict_x0)
+
+
+class _GLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, yr, yf, alpha, scale):
+        S = x.shape[0]
+        n = x.numel() // S
+        dx, dyr, dyf = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
+        loss = torch.empty(1, device=x.device, dtype=F32)
+        ws = torch.empty(10 * S, device=x.device, dtype=F32)
+        lib.sidlsg_g_loss(_p(_chk(x, F32)), _p(_chk(yr, F32)), _p(_chk(yf, F32)), _p(dx), _p(dyr), _p(dyf), _p(loss), _p(ws), S, n,
+                          float(alpha), float(scale), _s())
+        ctx.save_for_backward(dx, dyr, dyf)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        dx, dyr, dyf = ctx.saved_tensors
+        return dx * g, dyr * g, dyf * g, None, None
+
+
+def sid_generator_loss(x, y_real, y_fake, alpha, scale):
+    return _GLoss.apply(x, y_real, y_fake, alpha, scale)
+
+
+class _FakeLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, e, noise, scale):
+        S = e.shape[0]
+        n = e.numel() // S
+        de = torch.empty_like(e)
+        loss = torch.empty(1, device=e.device, dtype=F32)
+        ws = torch.empty(10 * S, device=e.device, dtype=F32)
+        lib.sidlsg_fake_loss(_p(_chk(e, F32)), _p(_chk(noise, F32)), _p(de), _p(loss), _p(ws), S, n, float(scale), _s())
+        ctx.save_for_backward(de)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        (de,) = ctx.saved_tensors
+        return de * g, None, None
+
+
+def sid_fake_score_loss(e, noise, scale):
+    return _FakeLoss.apply(e, noise, scale)
+
+
+# ------------------------------------------------------------------------------------------------
+def transpose_w(src_f32, n, k, taps=1):
+    """fp32 master [N][T][K] -> bf16 [K][T reversed][N]  (the dgrad operand)"""
+    dst = torch.empty((k, taps * n), device=src_f32.device, dtype=BF16)
+    lib.sidlsg_transpose_w(_p(src_f32), _p(dst), n, k, taps, _s())
+    return dst
+
+
+def cast_bf16(src_f32, out=None):
+    if out is None:
+        out = torch.empty(src_f32.shape, device=src_f32.device, dtype=BF16)
+    lib.sidlsg_cast_f32_bf16(_p(src_f32), _p(out), src_f32.numel(), _s())
+    return out

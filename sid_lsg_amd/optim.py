@@ -1,0 +1,104 @@
+"""Fused optimizer for a network whose parameters live in one flat buffer.
+
+Selectable by class name through `dnnlib.util.construct_class_by_name(params=..., class_name=
+'sid_lsg_amd.optim.FusedAdamEMA', lr=, betas=, eps=)` exactly like the reference selects
+`torch.optim.Adam` (sid_train.py:219-226 -> sid_training_loop.py:291-292).  One kernel launch per
+step does: nan_to_num(grad) (sid_training_loop.py:458-460,541-543) -> optional clip (:546-547) ->
+Adam/AdamW (torch single-tensor semantics) -> EMA lerp (:553-565) -> bf16 compute copy -> zero_grad.
+"""
+import math
+
+import torch
+
+from . import ops
+from ._lib import lib
+
+
+def _flat_of(tensors):
+    tensors = list(tensors)
+    st = tensors[0].untyped_storage()
+    for t in tensors:
+        if t.untyped_storage().data_ptr() != st.data_ptr():
+            raise ValueError('FusedAdamEMA needs all parameters in ONE flat buffer (HipUNet2DCondition.flat_params)')
+    return torch.empty(0, dtype=tensors[0].dtype, device=tensors[0].device).set_(st)
+
+
+class FusedAdamEMA:
+    def __init__(self, params, lr=1e-6, betas=(0.0, 0.999), eps=1e-8, weight_decay=0.0, decoupled=False, clip_value=None):
+        params = [p for p in params]
+        if isinstance(params[0], dict):
+            params = [p for g in params for p in g['params']]
+        flat = _flat_of([p.data for p in params])
+        if any(p.grad is None for p in params):
+            raise ValueError('parameters must carry pre-allocated .grad views of the flat gradient buffer')
+        grad = _flat_of([p.grad for p in params])
+        self._setup(flat, grad, lr, betas, eps, weight_decay, decoupled, clip_value)
+        self.param_groups = [dict(params=params, lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay)]
+
+    @classmethod
+    def from_flat(cls, flat, grad, lr=1e-6, betas=(0.0, 0.999), eps=1e-8, weight_decay=0.0, decoupled=False, clip_value=None,
+                  ema=None, w16=None):
+        self = cls.__new__(cls)
+        self._setup(flat, grad, lr, betas, eps, weight_decay, decoupled, clip_value)
+        self.param_groups = [dict(params=[flat], lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay)]
+        self.attach(ema=ema, w16=w16)
+        return self
+
+    def _setup(self, flat, grad, lr, betas, eps, weight_decay, decoupled, clip_value):
+        if not flat.is_cuda:
+            raise RuntimeError('FusedAdamEMA is a HIP kernel: parameters must be on the GPU (no CPU fallback)')
+        assert flat.numel() == grad.numel() and flat.dtype == torch.float32
+        self.flat, self.grad = flat, grad
+        self.lr, self.betas, self.eps = float(lr), (float(betas[0]), float(betas[1])), float(eps)
+        self.weight_decay, self.decoupled = float(weight_decay), bool(decoupled)
+        self.clip_value = clip_value
+        self.step_count = 0
+        self.exp_avg_sq = torch.zeros_like(flat)
+        self.exp_avg = torch.zeros_like(flat) if self.betas[0] != 0 else None   # beta1 = 0 (the recipe) needs no first moment
+        self.hyper = torch.zeros(16, device=flat.device, dtype=torch.float32)
+        self.ema = self.w16 = None
+        self.grad_scale = 1.0
+
+    def attach(self, ema=None, w16=None):
+        """ema: flat fp32 buffer of the EMA network; w16: flat bf16 compute copy of this network."""
+        self.ema, self.w16 = ema, w16
+        return self
+
+    def zero_grad(self, set_to_none=False):
+        self.grad.zero_()   # normally unnecessary: step() zeroes the gradient buffer
+
+    def set_hyper(self, ema_beta=0.0):
+        """Writes the step's scalars to device memory (outside any captured graph)."""
+        b1, b2 = self.betas
+        t = self.step_count
+        h = [self.lr, b1, b2, self.eps, 1 - b1 ** t, math.sqrt(1 - b2 ** t), float(ema_beta), self.weight_decay,
+             1.0 if self.decoupled else 0.0, float(self.clip_value) if self.clip_value else 0.0, self.grad_scale]
+        self.hyper[:len(h)].copy_(torch.tensor(h, dtype=torch.float32))
+
+    def launch(self, use_ema=True, zero_grad=True):
+        lib.sidlsg_adam_ema(self.flat.data_ptr(), self.grad.data_ptr(), ops._p(self.exp_avg), self.exp_avg_sq.data_ptr(),
+                            ops._p(self.ema) if use_ema else None, ops._p(self.w16), self.hyper.data_ptr(), self.flat.numel(),
+                            1 if zero_grad else 0, ops._s())
+
+    @torch.no_grad()
+    def step(self, ema_beta=None, zero_grad=True):
+        self.step_count += 1
+        self.set_hyper(0.0 if ema_beta is None else ema_beta)
+        self.launch(use_ema=ema_beta is not None and self.ema is not None, zero_grad=zero_grad)
+
+    def state_dict(self):
+        return dict(step=self.step_count, exp_avg_sq=self.exp_avg_sq, exp_avg=self.exp_avg, lr=self.lr, betas=self.betas,
+                    eps=self.eps, weight_decay=self.weight_decay)
+
+    def load_state_dict(self, sd):
+        self.step_count = int(sd['step'])
+        self.exp_avg_sq.copy_(sd['exp_avg_sq'])
+        if self.exp_avg is not None and sd.get('exp_avg') is not None:
+            self.exp_avg.copy_(sd['exp_avg'])
+
+
+class FusedAdamWEMA(FusedAdamEMA):
+    """`--optimizer adamw` variant (sid_train.py:223-226): decoupled weight decay."""
+
+    def __init__(self, params, lr=1e-6, betas=(0.0, 0.999), eps=1e-8, weight_decay=0.01, **kw):
+        super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, decoupled=True, **kw)

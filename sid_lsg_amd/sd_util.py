@@ -1,0 +1,192 @@
+"""SD glue with the reference's names and signatures (training/sid_sd_util.py):
+    load_sd15        :51-118   -> (unet, vae, noise_scheduler, text_encoder, tokenizer)
+    sid_sd_sampler   :163-211  one-step (or few-step) generator  z -> x_hat (or decoded images)
+    sid_sd_denoise   :214-274  add_noise -> (CFG-batched) UNet -> guided eps or x0 prediction
+
+When `unet` is a HipUNet2DCondition the whole glue runs as fused HIP kernels
+(sidlsg_noisy_input / UNet / sidlsg_cfg_x0: no per-sample python loop, no host syncs, the CFG pair
+[uncond ; cond] shares one x_t).  For any other duck-typed `unet` (e.g. the CPU oracle net in the
+host-logic tests) the same arithmetic is expressed with tensor ops on whatever device it lives on.
+"""
+import os
+from types import SimpleNamespace
+
+import torch
+import torch.nn.functional as F
+
+from . import ops
+from .scheduler import DDPMScheduler
+from .text import TEXT_CONFIGS, CLIPBPETokenizer, CLIPTextModel, HashTokenizer
+from .unet import CONFIGS, HipUNet2DCondition
+
+
+def _unwrap(net):
+    return net.module if hasattr(net, 'module') and isinstance(net.module, torch.nn.Module) else net
+
+
+def _is_hip(net):
+    return isinstance(_unwrap(net), HipUNet2DCondition)
+
+
+class LatentPreviewVAE(torch.nn.Module):
+    """Placeholder for AutoencoderKL when no VAE weights are available offline: previews the first three
+    latent channels.  Has the members the reference touches (sid_training_loop.py:254;
+    sid_sd_util.py:198-209).  The real VAE decode is a cold-path "next" row."""
+
+    def __init__(self):
+        super().__init__()
+        self.config = SimpleNamespace(block_out_channels=[128, 256, 512, 512], scaling_factor=0.18215, force_upcast=True)
+        self.post_quant_conv = torch.nn.Conv2d(4, 4, 1)
+
+    @property
+    def dtype(self):
+        return self.post_quant_conv.weight.dtype
+
+    def decode(self, z, return_dict=False):
+        return (F.interpolate(z[:, :3].float(), scale_factor=8.0, mode='nearest').clamp(-1, 1),)
+
+
+def _arch_of(name):
+    n = name.lower()
+    if n.startswith('random:'):
+        return n.split(':', 1)[1]
+    if '2-1-base' in n or 'sd21' in n or 'stable-diffusion-2' in n:
+        return 'sd21-base'
+    return 'sd15'
+
+
+def load_sd15(pretrained_model_name_or_path, pretrained_vae_model_name_or_path, device, weight_dtype, revision=None,
+              variant=None, lora_config=None, enable_xformers=False, gradient_checkpointing=False, seed=0):
+    """Same contract as the reference factory.  Sources, in order:
+      * a local diffusers-layout directory (unet/diffusion_pytorch_model.safetensors, text_encoder/model.safetensors,
+        tokenizer/{vocab.json,merges.txt}) -> real weights through `load_state_dict` (key names are diffusers');
+      * 'random:<arch>' (arch in sd15 | sd21-base | tiny | tiny40), or any hub id when SIDLSG_ALLOW_RANDOM_INIT=1 ->
+        seeded random weights of that architecture (no network here: benchmarks and parity tests use this).
+    `weight_dtype` is accepted for signature compatibility: masters are fp32, compute is bf16 (MFMA).
+    `enable_xformers` / `gradient_checkpointing` are accepted and ignored (attention is always the fused HIP kernel;
+    the reference itself never forwards gradient_checkpointing, sid_training_loop.py:224-228)."""
+    name = str(pretrained_model_name_or_path)
+    arch = _arch_of(name)
+    device = torch.device(device)
+    local = os.path.isdir(name)
+    if not local and not name.lower().startswith('random:') and os.environ.get('SIDLSG_ALLOW_RANDOM_INIT', '0') != '1':
+        raise FileNotFoundError(f'{name}: not a local diffusers directory and there is no network; pass a directory, '
+                                f"'random:{arch}', or set SIDLSG_ALLOW_RANDOM_INIT=1")
+    cfg = CONFIGS[arch]
+    src = None
+    if local:
+        from safetensors.torch import load_file
+        src = load_file(os.path.join(name, 'unet', 'diffusion_pytorch_model.safetensors'))
+    unet = HipUNet2DCondition(cfg)
+    unet.materialize(device, seed=seed, source=src)
+    tcfg = TEXT_CONFIGS.get(arch, dict(hidden=cfg.cross_attention_dim, layers=2, heads=2, dff=2 * cfg.cross_attention_dim,
+                                       act='quick_gelu'))
+    g = torch.random.get_rng_state()
+    torch.manual_seed(seed + 1)
+    text_encoder = CLIPTextModel(max_pos=cfg.text_len, **tcfg)
+    torch.random.set_rng_state(g)
+    tokenizer = HashTokenizer(model_max_length=cfg.text_len, pad_token_id=0 if arch == 'sd21-base' else 49407)
+    if local:
+        from safetensors.torch import load_file
+        te = os.path.join(name, 'text_encoder', 'model.safetensors')
+        if os.path.isfile(te):
+            text_encoder.load_state_dict(load_file(te), strict=False)
+        vj, mt = os.path.join(name, 'tokenizer', 'vocab.json'), os.path.join(name, 'tokenizer', 'merges.txt')
+        if os.path.isfile(vj) and os.path.isfile(mt):
+            tokenizer = CLIPBPETokenizer.from_files(vj, mt, model_max_length=cfg.text_len, pad_token_id=tokenizer.pad_token_id)
+    text_encoder.requires_grad_(False).eval().to(device)
+    vae = LatentPreviewVAE().requires_grad_(False).to(device)
+    return unet, vae, DDPMScheduler().to(device), text_encoder, tokenizer
+
+
+def encode_contexts(contexts, text_encoder, tokenizer, device):
+    """list[str] -> [B, L, D] text states (no grad); a tensor is passed through (pre-computed states)."""
+    if torch.is_tensor(contexts):
+        return contexts
+    ids = tokenizer(list(contexts), padding='max_length', max_length=tokenizer.model_max_length, truncation=True,
+                    return_tensors='pt').input_ids
+    with torch.no_grad():
+        return text_encoder(ids.to(device))[0]
+
+
+# ------------------------------------------------------------------------------------------------
+def hip_generate(unet, z, ctx16, init_t, sched, x0=None):
+    """x_t = s0*x0 + s1*z at t_init ; eps = G(x_t) ; x_hat = (x_t - s1*eps)/s0   (sid_sd_util.py:182-185)"""
+    s0, s1 = sched.coefficients(init_t)
+    xin, xt = ops.noisy_input(x0, z, s0, s1, 1)
+    eps = _unwrap(unet).forward_nhwc(xin, init_t, ctx16)
+    return ops.cfg_x0(eps, xt, s0, s1, 1.0, True)
+
+
+def hip_prepare_denoise(images, noise, t, cond16, uncond16, sched, guided):
+    """Shared by every network evaluated on the same (images, noise, t): the noisy CFG batch and its conditioning."""
+    s0, s1 = sched.coefficients(t)
+    dup = 2 if guided else 1
+    xin, xt = ops.noisy_input(images, noise, s0, s1, dup)
+    ctx = torch.cat([uncond16, cond16]) if guided else cond16          # (sid_sd_util.py:259-261)
+    tt = torch.cat([t, t]) if guided else t
+    return SimpleNamespace(xin=xin, xt=xt, s0=s0, s1=s1, ctx=ctx, tt=tt)
+
+
+def hip_denoise(unet, prep, guidance_scale, predict_x0):
+    eps = _unwrap(unet).forward_nhwc(prep.xin, prep.tt, prep.ctx)
+    return ops.cfg_x0(eps, prep.xt, prep.s0, prep.s1, guidance_scale, predict_x0)  # u + k(c-u), then x0 (:264-272)
+
+
+# ------------------------------------------------------------------------------------------------
+def sid_sd_sampler(unet, latents, contexts, init_timesteps, noise_scheduler, text_encoder, tokenizer, resolution,
+                   dtype=torch.float16, return_images=False, vae=None, guidance_scale=1, num_steps=1, train_sampler=True,
+                   num_steps_eval=1):
+    steps = num_steps if train_sampler else num_steps_eval
+    emb = encode_contexts(contexts, text_encoder, tokenizer, latents.device)
+    hip = _is_hip(unet)
+    if hip:
+        emb = emb.to(torch.bfloat16).contiguous()
+    D_x = None
+    ctxmgr = torch.enable_grad() if train_sampler else torch.no_grad()
+    with ctxmgr:
+        for i in range(steps):
+            noise = latents if i == 0 else torch.randn_like(latents)
+            t_i = (init_timesteps * (1 - i / steps)).to(torch.long)
+            if hip:
+                D_x = hip_generate(unet, noise.to(torch.float32).contiguous(), emb, t_i.contiguous(), noise_scheduler, x0=D_x)
+            else:
+                x0 = torch.zeros_like(latents) if D_x is None else D_x
+                x_t = noise_scheduler.add_noise(x0, noise, t_i).to(torch.float32)
+                eps = unet(noise_scheduler.scale_model_input(x_t, t_i).to(dtype), t_i, encoder_hidden_states=emb).sample
+                D_x = noise_scheduler.step(eps.to(torch.float32), t_i[0], x_t).pred_original_sample.to(torch.float32)
+    if not return_images:
+        return D_x.to(torch.float32)
+    upcast = vae.dtype == torch.float16 and getattr(vae.config, 'force_upcast', False)
+    if upcast:
+        vae.to(dtype=torch.float32)
+    images = vae.decode(D_x.to(vae.dtype) / vae.config.scaling_factor, return_dict=False)[0]
+    if upcast:
+        vae.to(dtype=torch.float16)
+    return images.to(torch.float32)
+
+
+def sid_sd_denoise(unet, images, noise, contexts, timesteps, noise_scheduler, text_encoder, tokenizer, resolution,
+                   dtype=torch.float16, predict_x0=True, guidance_scale=1):
+    b = images.shape[0]
+    cond = encode_contexts(contexts, text_encoder, tokenizer, images.device)
+    guided = guidance_scale != 1
+    uncond = encode_contexts([''] * b, text_encoder, tokenizer, images.device) if guided else None
+    if _is_hip(unet):
+        bf = torch.bfloat16
+        prep = hip_prepare_denoise(images.to(torch.float32).contiguous(), noise.to(torch.float32).contiguous(),
+                                   timesteps.contiguous(), cond.to(bf).contiguous(),
+                                   uncond.to(bf).contiguous() if guided else None, noise_scheduler, guided)
+        return hip_denoise(unet, prep, float(guidance_scale), predict_x0)
+    x_t = noise_scheduler.add_noise(images, noise, timesteps)
+    if not guided:
+        eps = unet(noise_scheduler.scale_model_input(x_t, timesteps).to(dtype), timesteps,
+                   encoder_hidden_states=cond).sample.to(torch.float32)
+    else:
+        both = unet(noise_scheduler.scale_model_input(torch.cat([x_t, x_t]), None).to(dtype), torch.cat([timesteps, timesteps]),
+                    encoder_hidden_states=torch.cat([uncond, cond])).sample.to(torch.float32)
+        eps_u, eps_c = both.chunk(2)
+        eps = eps_u + guidance_scale * (eps_c - eps_u)
+    if not predict_x0:
+        return eps
+    return noise_scheduler.step(eps, timesteps, x_t.to(torch.float32)).pred_original_sample.to(torch.float32)

@@ -1,0 +1,97 @@
+"""The SiD-LSG inner step (the hot path): one fake-score update + one generator update.
+
+Restates training/sid_training_loop.py:383-571 for HipUNet2DCondition networks:
+  phase A (:389-462)  x_hat = G(z) without grad -> eps_psi at guidance kappa1 on the CFG batch ->
+                      fake-score MSE (closed-form grad) -> backward through psi -> fused nan_to_num+Adam
+  phase B (:468-549)  x_hat = G(z) with grad -> y_fake (psi frozen, kappa2) and y_real (teacher phi, kappa4) on
+                      ONE shared noisy CFG batch -> SiD-LSG loss (closed-form grads) -> backward through psi, phi
+                      (data gradients only) and G -> fused nan_to_num+Adam+EMA
+Differences from the reference that do NOT change the math (DESIGN.md "Step"):
+  * inputs are explicit (z, noise, t, text states): RNG order is owned by the caller (training_loop);
+  * per-sample NaN filtering happens inside the loss kernels (no host sync);
+  * x_t, the timestep embedding input and the text states are built once and shared by psi and phi in phase B;
+  * gradients accumulate into flat buffers; the data-parallel exchange is a few large RCCL all-reduces whose
+    mean is folded into the optimizer kernel;
+  * EMA, bf16 weight refresh and zero_grad are fused into the optimizer kernel.
+"""
+import torch
+
+from . import ops
+from .sd_util import hip_denoise, hip_generate, hip_prepare_denoise
+
+
+class SiDStep:
+    def __init__(self, G, fake_score, true_score, G_ema, scheduler, opt_fake, opt_G, *, alpha=1.0, cfg_train_fake=1.0,
+                 cfg_eval_fake=1.0, cfg_eval_real=1.0, loss_scaling=1.0, loss_scaling_G=1.0, batch_gpu_total=1,
+                 init_timestep=625, reducer=None, world_size=1):
+        self.G, self.psi, self.phi, self.G_ema = G, fake_score, true_score, G_ema
+        self.sched, self.opt_fake, self.opt_G = scheduler, opt_fake, opt_G
+        self.alpha, self.k1, self.k2, self.k4 = float(alpha), float(cfg_train_fake), float(cfg_eval_fake), float(cfg_eval_real)
+        self.ls, self.lsg, self.bgt = float(loss_scaling), float(loss_scaling_G), int(batch_gpu_total)
+        self.init_timestep = int(init_timestep)
+        self.reducer, self.world = reducer, world_size
+        opt_fake.grad_scale = opt_G.grad_scale = 1.0 / world_size     # DDP mean, folded into the optimizer kernel
+        opt_fake.attach(ema=None, w16=fake_score.flat_w16)
+        opt_G.attach(ema=(G_ema.flat_params if (G_ema is not None and G_ema is not G) else None), w16=G.flat_w16)
+        self.phi.requires_grad_(False)
+
+    def _init_t(self, n, device):
+        return torch.full((n,), self.init_timestep, device=device, dtype=torch.long)
+
+    # ---- phase A: fake-score network -----------------------------------------------------------
+    def fake_round(self, r):
+        """r: dict(z, noise, t, cond, uncond) (fp32 NCHW / int64 / bf16 text states)."""
+        with torch.no_grad():                                                       # :406-411
+            images = hip_generate(self.G, r['z'], r['cond'], self._init_t(len(r['z']), r['z'].device), self.sched)
+        prep = hip_prepare_denoise(images, r['noise'], r['t'], r['cond'], r.get('uncond'), self.sched, self.k1 != 1)
+        eps = hip_denoise(self.psi, prep, self.k1, predict_x0=False)                # :418-421
+        loss = ops.sid_fake_score_loss(eps, r['noise'], self.ls / self.bgt)         # :423-445
+        loss.backward()                                                             # :449-450
+        return loss.detach()
+
+    def fake_update(self, rounds):
+        self.G.requires_grad_(False)
+        self.psi.requires_grad_(True)                                               # :389
+        loss = None
+        for r in rounds:
+            loss = self.fake_round(r)
+        self.psi.requires_grad_(False)                                              # :455
+        self._optimizer_step(self.psi, self.opt_fake, ema_beta=None)                # :458-462
+        return loss
+
+    # ---- phase B: generator --------------------------------------------------------------------
+    def generator_round(self, r):
+        images = hip_generate(self.G, r['z'], r['cond'], self._init_t(len(r['z']), r['z'].device), self.sched)  # :488-491
+        guided = (self.k2 != 1) or (self.k4 != 1)
+        prep = hip_prepare_denoise(images, r['noise'], r['t'], r['cond'], r.get('uncond'), self.sched, guided)
+        k2 = self.k2 if guided else 1.0
+        k4 = self.k4 if guided else 1.0
+        y_fake = hip_denoise(self.psi, prep, k2, predict_x0=True)                   # :496-499
+        y_real = hip_denoise(self.phi, prep, k4, predict_x0=True)                   # :503-506
+        loss = ops.sid_generator_loss(images, y_real, y_fake, self.alpha, self.lsg / self.bgt)   # :508-530
+        loss.backward()                                                             # :532-533
+        return loss.detach()
+
+    def generator_update(self, rounds, ema_beta=None):
+        self.G.requires_grad_(True)                                                 # :468
+        self.psi.requires_grad_(False)
+        loss = None
+        for r in rounds:
+            loss = self.generator_round(r)
+        self.G.requires_grad_(False)                                                # :538
+        self._optimizer_step(self.G, self.opt_G, ema_beta=ema_beta)                 # :541-565
+        return loss
+
+    # ---- optimizer + data-parallel exchange ------------------------------------------------------
+    def _optimizer_step(self, net, opt, ema_beta):
+        if self.reducer is not None and self.world > 1:
+            self.reducer.start(net.flat_grads)      # few large all-reduce(SUM) on the comm stream
+            self.reducer.wait()
+        opt.step(ema_beta=ema_beta)                 # nan_to_num, /world, Adam, EMA, bf16 copy, zero_grad: one kernel
+        net.refresh_compute_weights(cast=False)     # backward-data operands (transposed bf16 weights)
+
+    def iteration(self, inputs, ema_beta=None):
+        """inputs: dict(A=[rounds], B=[rounds]).  Returns (loss_fake, loss_G) as device scalars."""
+        lf = self.fake_update(inputs['A'])
+        lg = self.generator_update(inputs['B'], ema_beta=ema_beta)
+        return lf, lg

@@ -1,0 +1,379 @@
+"""GPU parity: every HIP kernel against a plain-PyTorch fp32 CPU reference of the same op.
+
+Tolerances (stated per SURVEY.md section 8 / the task's floating-point rule): operands are bf16
+(exactly representable in the fp32 reference), accumulation is fp32 on both sides, so
+  * fp32 outputs (weight grads, losses, eps):   |err| <= 2e-3 * max|ref|   (+ bf16 operand rounding of
+    intermediate activations where a kernel chain is involved)
+  * bf16 outputs:                                |err| <= 1.2e-2 * max|ref|  (one bf16 rounding = 2^-8 rel)
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+BF16, F32 = torch.bfloat16, torch.float32
+
+
+@pytest.fixture(scope='module')
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    from sid_lsg_amd._lib import lib
+    lib.load()   # fail loudly if the HIP library is missing
+    return torch.device('cuda:0')
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(BF16)
+
+
+def close(got, ref, tol, name=''):
+    got = got.detach().float().cpu()
+    ref = ref.detach().float().cpu()
+    assert got.shape == ref.shape, f'{name}: shape {tuple(got.shape)} vs {tuple(ref.shape)}'
+    assert torch.isfinite(got).all(), f'{name}: non-finite output'
+    err = (got - ref).abs().max().item()
+    scale = ref.abs().max().item() + 1e-12
+    assert err <= tol * scale, f'{name}: max err {err:.4g} vs scale {scale:.4g} (rel {err / scale:.3g} > {tol})'
+
+
+# ----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('M,N,K', [(256, 320, 320), (1000, 136, 72), (4096, 960, 320), (77 * 2, 640, 768), (130, 8, 2880), (64, 2560, 320)])
+def test_gemm(dev, M, N, K):
+    from sid_lsg_amd import ops
+    a, w = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5)
+    bias = torch.randn(N, generator=torch.Generator().manual_seed(3))
+    res = rnd(M, N, seed=4)
+    rpb = M // 2 if M % 2 == 0 else M
+    rv = torch.randn(M // rpb, N, generator=torch.Generator().manual_seed(5))
+    ref = a.float() @ w.float().t()
+    close(ops.gemm(a.to(dev), w.to(dev)), ref, 1.2e-2, 'plain')
+    close(ops.gemm(a.to(dev), w.to(dev), out_f32=True), ref, 2e-3, 'f32')
+    full = ref + bias + res.float() + rv.repeat_interleave(rpb, 0)
+    got = ops.gemm(a.to(dev), w.to(dev), bias=bias.to(dev), res=res.to(dev), rowvec=rv.to(dev), rows_per_batch=rpb, out_f32=True)
+    close(got, full, 2e-3, 'epilogue')
+
+
+CONV_CASES = [(2, 16, 16, 64, 160, 1, 0), (2, 16, 16, 64, 128, 2, 0), (1, 8, 8, 128, 64, 1, 1), (2, 12, 20, 8, 320, 1, 0),
+              (2, 8, 8, 320, 8, 1, 0), (1, 64, 64, 320, 320, 1, 0), (3, 9, 7, 72, 40, 2, 0)]
+
+
+def conv_ref(x, w, stride, ups):
+    xn = x.float().permute(0, 3, 1, 2)
+    if ups:
+        xn = F.interpolate(xn, scale_factor=2.0, mode='nearest')
+    cout, k = w.shape
+    cin = k // 9
+    wn = w.float().view(cout, 3, 3, cin).permute(0, 3, 1, 2)
+    return F.conv2d(xn, wn, stride=stride, padding=1).permute(0, 2, 3, 1)
+
+
+@pytest.mark.parametrize('B,H,W,Cin,Cout,stride,ups', CONV_CASES)
+def test_conv3x3(dev, B, H, W, Cin, Cout, stride, ups):
+    from sid_lsg_amd import ops
+    x, w = rnd(B, H, W, Cin, seed=1), rnd(Cout, 9 * Cin, seed=2, scale=(9 * Cin) ** -0.5)
+    ref = conv_ref(x, w, stride, ups)
+    close(ops.conv3x3(x.to(dev), w.to(dev), stride=stride, ups=ups, out_f32=True), ref, 2e-3, 'conv')
+    bias = torch.randn(Cout, generator=torch.Generator().manual_seed(3))
+    rv = torch.randn(B, Cout, generator=torch.Generator().manual_seed(5))
+    res = rnd(*ref.shape, seed=6)
+    got = ops.conv3x3(x.to(dev), w.to(dev), bias=bias.to(dev), res=res.to(dev), rowvec=rv.to(dev), stride=stride, ups=ups)
+    close(got, ref + bias + res.float() + rv[:, None, None, :], 1.2e-2, 'conv+epilogue')
+
+
+@pytest.mark.parametrize('M,N,K', [(512, 128, 128), (1000, 320, 72), (4096, 64, 2880), (333, 8, 320), (8192, 960, 320)])
+def test_wgrad_dense(dev, M, N, K):
+    from sid_lsg_amd._lib import lib
+    from sid_lsg_amd.ops import _p, _s
+    dy, a = rnd(M, N, seed=1), rnd(M, K, seed=2)
+    ref = dy.float().t() @ a.float()
+    dw = torch.full((N, K), 0.5, device=dev, dtype=F32)          # accumulates into existing content
+    dyd, ad = dy.to(dev), a.to(dev)
+    lib.sidlsg_wgrad_bf16(_p(dyd), N, _p(ad), K, _p(dw), M, N, K, _s())
+    close(dw - 0.5, ref, 2e-3, 'wgrad')
+
+
+@pytest.mark.parametrize('B,H,W,Cin,Cout,stride,ups', CONV_CASES)
+def test_conv_autograd(dev, B, H, W, Cin, Cout, stride, ups):
+    """dx, dW, db, d(rowvec), d(res) of the conv op against torch autograd."""
+    from sid_lsg_amd import ops
+    x, w = rnd(B, H, W, Cin, seed=1), rnd(Cout, 9 * Cin, seed=2, scale=(9 * Cin) ** -0.5)
+    bias = torch.randn(Cout, generator=torch.Generator().manual_seed(3))
+    rv = torch.randn(B, Cout, generator=torch.Generator().manual_seed(5))
+    xr, wr, br, rvr = x.float().requires_grad_(), w.float().requires_grad_(), bias.clone().requires_grad_(), rv.clone().requires_grad_()
+    yr = conv_ref(xr, wr, stride, ups) + br + rvr[:, None, None, :]
+    dy = rnd(*yr.shape, seed=7)
+    yr.backward(dy.float())
+    # product op
+    wm = torch.nn.Parameter(w.float().view(Cout, 3, 3, Cin).permute(0, 3, 1, 2).to(dev))   # logical [Cout,Cin,3,3], channels-last storage
+    wm.grad = torch.zeros(Cout, 3, 3, Cin, device=dev).permute(0, 3, 1, 2)
+    bm = torch.nn.Parameter(bias.to(dev))
+    bm.grad = torch.zeros_like(bm)
+    w16 = w.to(dev)
+    w16t = ops.transpose_w(wm.permute(0, 2, 3, 1), Cout, Cin, 9)
+    xd = x.to(dev).requires_grad_()
+    rvd = rv.to(dev).requires_grad_()
+    y = ops.conv3x3_op(xd, wm, bm, w16, w16t, None, rvd, stride, ups, False)
+    close(y, yr, 1.2e-2, 'fwd')
+    y.backward(dy.to(dev))
+    close(xd.grad, xr.grad, 1.2e-2, 'dx')
+    close(wm.grad.permute(0, 2, 3, 1).reshape(Cout, -1), wr.grad, 2e-3, 'dW')
+    close(bm.grad, br.grad, 2e-3, 'db')
+    close(rvd.grad, rvr.grad, 2e-3, 'd_rowvec')
+
+
+def test_linear_autograd(dev):
+    from sid_lsg_amd import ops
+    M, N, K = 520, 320, 640
+    x, w = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5)
+    bias = torch.randn(N, generator=torch.Generator().manual_seed(3))
+    res = rnd(M, N, seed=4)
+    xr, wr, br, rr = x.float().requires_grad_(), w.float().requires_grad_(), bias.clone().requires_grad_(), res.float().requires_grad_()
+    yr = xr @ wr.t() + br + rr
+    dy = rnd(M, N, seed=7)
+    yr.backward(dy.float())
+    wm = torch.nn.Parameter(w.float().to(dev)); wm.grad = torch.zeros_like(wm)
+    bm = torch.nn.Parameter(bias.to(dev)); bm.grad = torch.zeros_like(bm)
+    xd, rd = x.to(dev).requires_grad_(), res.to(dev).requires_grad_()
+    y = ops.linear(xd, wm, bm, w.to(dev), ops.transpose_w(wm, N, K, 1), res=rd)
+    close(y, yr, 1.2e-2, 'fwd')
+    y.backward(dy.to(dev))
+    close(xd.grad, xr.grad, 1.2e-2, 'dx')
+    close(rd.grad, rr.grad, 1.2e-2, 'dres')
+    close(wm.grad, wr.grad, 2e-3, 'dW')
+    close(bm.grad, br.grad, 2e-3, 'db')
+
+
+@pytest.mark.parametrize('B,HW,C,G,silu', [(2, 64, 32, 8, 1), (3, 1024, 320, 32, 1), (2, 256, 1920, 32, 1), (2, 4096, 320, 32, 0),
+                                           (1, 64, 2560, 32, 1), (2, 100, 80, 8, 0)])
+def test_groupnorm(dev, B, HW, C, G, silu):
+    from sid_lsg_amd import ops
+    x = (rnd(B, HW, C, seed=1).float() * 1.5 + 0.3).to(BF16)
+    gam = torch.randn(C, generator=torch.Generator().manual_seed(2)) * 0.5 + 1
+    bet = torch.randn(C, generator=torch.Generator().manual_seed(3)) * 0.3
+    xr, gr, br = x.float().requires_grad_(), gam.clone().requires_grad_(), bet.clone().requires_grad_()
+    yr = F.group_norm(xr.permute(0, 2, 1), G, gr, br, 1e-5).permute(0, 2, 1)
+    if silu:
+        yr = F.silu(yr)
+    dy = rnd(B, HW, C, seed=4)
+    yr.backward(dy.float())
+    gm = torch.nn.Parameter(gam.to(dev)); gm.grad = torch.zeros_like(gm)
+    bm = torch.nn.Parameter(bet.to(dev)); bm.grad = torch.zeros_like(bm)
+    xd = x.to(dev).requires_grad_()
+    y = ops.group_norm(xd, gm, bm, G, 1e-5, silu)
+    close(y, yr, 1.2e-2, 'fwd')
+    y.backward(dy.to(dev))
+    close(xd.grad, xr.grad, 1.5e-2, 'dx')
+    close(gm.grad, gr.grad, 3e-3, 'dgamma')
+    close(bm.grad, br.grad, 3e-3, 'dbeta')
+
+
+@pytest.mark.parametrize('rows,C', [(100, 320), (4096, 640), (257, 1280), (64, 32), (300, 80)])
+def test_layernorm(dev, rows, C):
+    from sid_lsg_amd import ops
+    x = (rnd(rows, C, seed=1).float() * 2 - 0.5).to(BF16)
+    gam = torch.randn(C, generator=torch.Generator().manual_seed(2)) * 0.5 + 1
+    bet = torch.randn(C, generator=torch.Generator().manual_seed(3)) * 0.3
+    xr, gr, br = x.float().requires_grad_(), gam.clone().requires_grad_(), bet.clone().requires_grad_()
+    yr = F.layer_norm(xr, (C,), gr, br, 1e-5)
+    dy = rnd(rows, C, seed=4)
+    yr.backward(dy.float())
+    gm = torch.nn.Parameter(gam.to(dev)); gm.grad = torch.zeros_like(gm)
+    bm = torch.nn.Parameter(bet.to(dev)); bm.grad = torch.zeros_like(bm)
+    xd = x.to(dev).requires_grad_()
+    y = ops.layer_norm(xd, gm, bm, 1e-5)
+    close(y, yr, 1.2e-2, 'fwd')
+    y.backward(dy.to(dev))
+    close(xd.grad, xr.grad, 1.5e-2, 'dx')
+    close(gm.grad, gr.grad, 3e-3, 'dgamma')
+    close(bm.grad, br.grad, 3e-3, 'dbeta')
+
+
+def attn_ref(q, k, v, heads):
+    B, Nq, C = q.shape
+    d = C // heads
+    qh = q.view(B, Nq, heads, d).transpose(1, 2)
+    kh = k.view(B, -1, heads, d).transpose(1, 2)
+    vh = v.view(B, -1, heads, d).transpose(1, 2)
+    p = torch.softmax(qh @ kh.transpose(-1, -2) * d ** -0.5, -1)
+    return (p @ vh).transpose(1, 2).reshape(B, Nq, C)
+
+
+@pytest.mark.parametrize('B,N,heads,D', [(2, 64, 2, 16), (1, 256, 4, 32), (2, 200, 2, 40), (1, 1024, 2, 64), (2, 256, 2, 80),
+                                         (1, 320, 2, 160), (1, 4096, 1, 40)])
+def test_self_attention(dev, B, N, heads, D):
+    from sid_lsg_amd import ops
+    C = heads * D
+    qkv = rnd(B, N, 3 * C, seed=1)
+    r = qkv.float().requires_grad_()
+    yr = attn_ref(r[..., :C], r[..., C:2 * C], r[..., 2 * C:], heads)
+    do = rnd(B, N, C, seed=2)
+    yr.backward(do.float())
+    qd = qkv.to(dev).requires_grad_()
+    y = ops.self_attention(qd, heads)
+    close(y, yr, 1.2e-2, 'fwd')
+    y.backward(do.to(dev))
+    close(qd.grad[..., :C], r.grad[..., :C], 2e-2, 'dq')
+    close(qd.grad[..., C:2 * C], r.grad[..., C:2 * C], 2e-2, 'dk')
+    close(qd.grad[..., 2 * C:], r.grad[..., 2 * C:], 2e-2, 'dv')
+
+
+@pytest.mark.parametrize('B,N,L,heads,D', [(2, 256, 77, 2, 40), (2, 64, 13, 4, 32), (1, 1024, 77, 8, 80), (2, 100, 77, 2, 160)])
+def test_cross_attention(dev, B, N, L, heads, D):
+    from sid_lsg_amd import ops
+    C = heads * D
+    q, kv = rnd(B, N, C, seed=1), rnd(B, L, 2 * C, seed=3)
+    qr, kr = q.float().requires_grad_(), kv.float().requires_grad_()
+    yr = attn_ref(qr, kr[..., :C], kr[..., C:], heads)
+    do = rnd(B, N, C, seed=2)
+    yr.backward(do.float())
+    qd, kd = q.to(dev).requires_grad_(), kv.to(dev).requires_grad_()
+    y = ops.cross_attention(qd, kd, heads)
+    close(y, yr, 1.2e-2, 'fwd')
+    y.backward(do.to(dev))
+    close(qd.grad, qr.grad, 2e-2, 'dq')
+    close(kd.grad, kr.grad, 2e-2, 'dkv')
+
+
+def test_small_ops(dev):
+    from sid_lsg_amd import ops
+    # GEGLU
+    h = rnd(300, 2 * 640, seed=1)
+    hr = h.float().requires_grad_()
+    a, g = hr.chunk(2, -1)
+    yr = a * F.gelu(g)
+    dy = rnd(300, 640, seed=2)
+    yr.backward(dy.float())
+    hd = h.to(dev).requires_grad_()
+    y = ops.geglu(hd)
+    y.backward(dy.to(dev))
+    close(y, yr, 1.2e-2, 'geglu')
+    close(hd.grad, hr.grad, 1.2e-2, 'geglu bwd')
+    # SiLU
+    x = rnd(64, 1280, seed=3)
+    xr = x.float().requires_grad_()
+    F.silu(xr).backward(dy.float()[:64, :].repeat(1, 2))
+    xd = x.to(dev).requires_grad_()
+    ys = ops.silu(xd)
+    ys.backward(dy.to(dev)[:64, :].repeat(1, 2).contiguous())
+    close(ys, F.silu(x.float()), 1.2e-2, 'silu')
+    close(xd.grad, xr.grad, 1.2e-2, 'silu bwd')
+    # concat
+    a, b = rnd(2, 4, 4, 320, seed=4), rnd(2, 4, 4, 640, seed=5)
+    ad, bd = a.to(dev).requires_grad_(), b.to(dev).requires_grad_()
+    c = ops.concat_channels(ad, bd)
+    assert torch.equal(c.cpu(), torch.cat([a, b], -1))
+    gc = rnd(2, 4, 4, 960, seed=6)
+    c.backward(gc.to(dev))
+    assert torch.equal(ad.grad.cpu(), gc[..., :320]) and torch.equal(bd.grad.cpu(), gc[..., 320:])
+    # timestep embedding
+    from oracle.unet_ref import timestep_embedding
+    t = torch.tensor([0, 20, 625, 979])
+    close(ops.timestep_embed(t.to(dev), 320), timestep_embedding(t, 320), 1.2e-2, 'temb')
+    # colsum
+    g = rnd(4 * 1000, 10240, seed=7)
+    tot = torch.zeros(10240, device=dev)
+    pb = ops.colsum(g.to(dev), 1000, per_batch=True, total=tot)
+    close(pb, g.float().view(4, 1000, -1).sum(1), 2e-3, 'colsum per batch')
+    close(tot, g.float().sum(0), 2e-3, 'colsum total')
+
+
+def test_glue_and_losses(dev):
+    """add_noise / CFG / x0 glue and both losses against the pinned oracle (oracle/sid_ref.py)."""
+    from oracle import sid_ref
+    from oracle.scheduler_ref import DDPMSchedulerRef
+    from sid_lsg_amd import ops
+    from sid_lsg_amd.scheduler import DDPMScheduler
+    B, C, H, W = 3, 4, 8, 8
+    g = torch.Generator().manual_seed(0)
+    x0, noise = torch.randn(B, C, H, W, generator=g), torch.randn(B, C, H, W, generator=g)
+    t = torch.tensor([20, 625, 979])
+    ref_s, s = DDPMSchedulerRef(), DDPMScheduler().to(dev)
+    s0, s1 = s.coefficients(t.to(dev))
+    xin, xt = ops.noisy_input(x0.to(dev), noise.to(dev), s0, s1, 2)
+    xt_ref = ref_s.add_noise(x0, noise, t)
+    close(xt, xt_ref, 1e-6, 'x_t')
+    close(xin[:B, ..., :4].permute(0, 3, 1, 2), xt_ref, 1.2e-2, 'x_t nhwc')
+    assert torch.equal(xin[:B], xin[B:]) and float(xin[..., 4:].abs().max()) == 0
+    eps = torch.randn(2 * B, H * W, 8, generator=g)
+    eps[..., 4:] = 0
+    e_nchw = eps[..., :4].view(2 * B, H, W, 4).permute(0, 3, 1, 2)
+    for kappa, px0 in ((1.5, True), (4.5, False)):
+        e = e_nchw[:B] + kappa * (e_nchw[B:] - e_nchw[:B])
+        ref = torch.stack([ref_s.step(n, tt, z).pred_original_sample for n, tt, z in zip(e, t, xt_ref)]) if px0 else e
+        got = ops.cfg_x0(eps.to(dev), xt, s0, s1, kappa, px0)
+        close(got, ref, 1e-5, f'cfg_x0 k={kappa}')
+    # losses (+ NaN-sample dropping)
+    x, yr, yf = (torch.randn(B, C, H, W, generator=g) for _ in range(3))
+    for alpha in (1.0, 1.2):
+        for nan_sample in (None, 1):
+            xx = x.clone()
+            if nan_sample is not None:
+                xx[nan_sample, 0, 0, 0] = float('nan')
+            a, b, c = (v.clone().requires_grad_() for v in (xx, yr, yf))
+            lref, _ = sid_ref.generator_loss_ref(a, b, c, alpha, 1.0, 4)
+            lref.backward()
+            ad, bd, cd = (v.to(dev).requires_grad_() for v in (xx, yr, yf))
+            l = ops.sid_generator_loss(ad, bd, cd, alpha, 1.0 / 4)
+            l.backward()
+            close(l, lref, 1e-5, 'G loss')
+            keep = [i for i in range(B) if i != nan_sample]
+            for got, ref, nm in ((ad.grad, a.grad, 'dx'), (bd.grad, b.grad, 'dyr'), (cd.grad, c.grad, 'dyf')):
+                close(got[keep], ref[keep], 1e-5, nm)
+                if nan_sample is not None:
+                    assert float(got[nan_sample].abs().max()) == 0
+    e = torch.randn(B, C, H, W, generator=g)
+    e[2, 1, 1, 1] = float('nan')
+    er = e.clone().requires_grad_()
+    lref, _ = sid_ref.fake_score_loss_ref(er, noise, 1.0, 4)
+    lref.backward()
+    ed = e.to(dev).requires_grad_()
+    l = ops.sid_fake_score_loss(ed, noise.to(dev), 1.0 / 4)
+    l.backward()
+    close(l, lref, 1e-5, 'fake loss')
+    close(ed.grad[:2], er.grad[:2], 1e-5, 'fake grad')
+
+
+def test_adam_ema(dev):
+    from oracle import sid_ref
+    from sid_lsg_amd.optim import FusedAdamEMA
+    g = torch.Generator().manual_seed(0)
+    n = 100003
+    p0 = torch.randn(n, generator=g)
+    p_ref, ema_ref, st = p0.clone(), p0.clone(), {}
+    p = p0.to(dev).clone()
+    grad = torch.zeros(n, device=dev)
+    ema = p.clone()
+    w16 = torch.zeros(n, device=dev, dtype=BF16)
+    opt = FusedAdamEMA.from_flat(p, grad, lr=1e-3, betas=(0.0, 0.999), eps=1e-8, ema=ema, w16=w16)
+    for step in range(4):
+        gr = torch.randn(n, generator=g) * 10 ** (step - 2)
+        gr[5] = float('nan'); gr[6] = float('inf'); gr[7] = -float('inf')
+        grad.copy_(gr.to(dev))
+        beta = sid_ref.ema_beta_ref(8, step * 8, 50)
+        opt.step(ema_beta=beta)
+        sid_ref.adam_step_ref(p_ref, gr, st, 1e-3, (0.0, 0.999), 1e-8)
+        sid_ref.ema_update_ref(ema_ref, p_ref, beta)
+        close(p, p_ref, 1e-6, f'p step {step}')
+        close(ema, ema_ref, 1e-6, f'ema step {step}')
+        assert float(grad.abs().max()) == 0.0, 'zero_grad folded into the step'
+        assert torch.equal(w16, p.to(BF16)), 'bf16 compute copy = RNE(bf16) of the updated master'
+
+
+def test_bias_act_matches_reference_golden(dev, golden_dir):
+    import os
+    from sid_lsg_amd.bias_act import activation_funcs, bias_act
+    g = np.load(os.path.join(golden_dir, 'bias_act.npz'))
+    x, b, dy = (torch.from_numpy(g[k]).to(dev) for k in ('x', 'b', 'dy'))
+    for act in activation_funcs:
+        for gain, clamp in ((None, None), (1.0, None), (1.5, 0.7)):
+            xx, bb = x.clone().requires_grad_(), b.clone().requires_grad_()
+            y = bias_act(xx, bb, dim=1, act=act, gain=gain, clamp=clamp)
+            y.backward(dy)
+            key = f'{act}_g{gain}_c{clamp}'
+            close(y, torch.from_numpy(g[key + '_y']), 1e-5, key)
+            close(xx.grad, torch.from_numpy(g[key + '_dx']), 1e-5, key + ' dx')
+            close(bb.grad, torch.from_numpy(g[key + '_db']), 1e-5, key + ' db')

@@ -1,0 +1,185 @@
+"""GPU parity of the composed path: HipUNet2DCondition, the fused glue and the whole SiD-LSG step against the
+CPU oracle (oracle/unet_ref.py, oracle/sid_ref.py -- the latter pinned to the reference by golden vectors).
+
+Tolerances: the HIP path computes in bf16 with fp32 accumulation (BASELINE config #2 precision), the oracle in
+fp32.  A 20-60 layer chain of bf16 roundings gives ~1e-2 relative error on activations; stated per assert.
+"""
+import copy
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+BF16, F32 = torch.bfloat16, torch.float32
+
+
+@pytest.fixture(scope='module')
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    from sid_lsg_amd._lib import lib
+    lib.load()
+    return torch.device('cuda:0')
+
+
+def rel_err(got, ref):
+    got, ref = got.detach().float().cpu(), ref.detach().float().cpu()
+    assert torch.isfinite(got).all()
+    return ((got - ref).abs().max() / (ref.abs().max() + 1e-12)).item(), \
+        ((got - ref).norm() / (ref.norm() + 1e-12)).item()
+
+
+def make_pair(cfg_name, dev, seed=1234):
+    from oracle import fixtures
+    from sid_lsg_amd.unet import CONFIGS, HipUNet2DCondition
+    ref = fixtures.make_unet(cfg_name, seed=seed)
+    # weights rounded to bf16 on the oracle side too, so the test isolates ARITHMETIC, not weight quantisation
+    with torch.no_grad():
+        for p in ref.parameters():
+            if p.ndim >= 2:
+                p.copy_(p.to(BF16).float())
+    hip = HipUNet2DCondition(CONFIGS[cfg_name])
+    hip.materialize(dev, source=ref.state_dict())
+    return ref, hip
+
+
+@pytest.mark.parametrize('cfg_name,lat', [('tiny', 16), ('tiny40', 8)])
+def test_unet_forward_backward(dev, cfg_name, lat):
+    from oracle.unet_ref import CONFIGS as RC
+    ref, hip = make_pair(cfg_name, dev)
+    cfg = RC[cfg_name]
+    g = torch.Generator().manual_seed(0)
+    B = 2
+    x = torch.randn(B, 4, lat, lat, generator=g)
+    t = torch.tensor([625, 37])
+    ctx = torch.randn(B, cfg.text_len, cfg.cross_attention_dim, generator=g).to(BF16)
+    # ---- forward
+    xr = x.clone().requires_grad_()
+    ref.requires_grad_(True)
+    yr = ref(xr, t, encoder_hidden_states=ctx.float()).sample
+    hip.requires_grad_(True)
+    xd = x.to(dev).requires_grad_()
+    y = hip(xd, t.to(dev), encoder_hidden_states=ctx.to(dev)).sample
+    emax, el2 = rel_err(y, yr)
+    print(f'{cfg_name}: fwd rel max {emax:.4f} l2 {el2:.4f}')
+    assert emax < 4e-2 and el2 < 2e-2, 'UNet forward: bf16 chain vs fp32 oracle'
+    # ---- backward (input gradient + parameter gradients)
+    dy = torch.randn(B, 4, lat, lat, generator=g)
+    yr.backward(dy)
+    y.backward(dy.to(dev))
+    emax, el2 = rel_err(xd.grad, xr.grad)
+    print(f'{cfg_name}: dx rel max {emax:.4f} l2 {el2:.4f}')
+    assert el2 < 4e-2, 'input gradient'
+    ref_p = dict(ref.named_parameters())
+    worst = 0.0
+    for name, p in hip.named_parameters():
+        gr = ref_p[name].grad
+        e = ((p.grad.detach().float().cpu() - gr).norm() / (gr.norm() + 1e-12)).item()
+        worst = max(worst, e)
+        assert e < 6e-2, f'param grad {name}: rel l2 {e:.4f}'
+    print(f'{cfg_name}: worst param-grad rel l2 {worst:.4f} over {len(ref_p)} tensors')
+
+
+def test_glue_matches_reference_golden(dev, golden_dir):
+    """sid_sd_sampler / sid_sd_denoise through the HIP path vs the golden vectors captured from the REFERENCE's own
+    functions (oracle/make_goldens.py).  bf16 UNet => 3e-2 of max."""
+    from oracle import fixtures
+    from sid_lsg_amd.scheduler import DDPMScheduler
+    from sid_lsg_amd.sd_util import sid_sd_denoise, sid_sd_sampler
+    from sid_lsg_amd.unet import CONFIGS, HipUNet2DCondition
+    for cfg in ('tiny', 'tiny40'):
+        g = np.load(os.path.join(golden_dir, f'glue_{cfg}.npz'))
+        ref1, _, _, te, tok = fixtures.factory(cfg)
+        ref2 = fixtures.make_unet(cfg, seed=99)
+        hip1 = HipUNet2DCondition(CONFIGS[cfg]).materialize(dev, source=ref1.state_dict())
+        hip2 = HipUNet2DCondition(CONFIGS[cfg]).materialize(dev, source=ref2.state_dict())
+        sched = DDPMScheduler().to(dev)
+        te = te.to(dev)
+        for b in (1, 2):
+            z, noise = torch.from_numpy(g[f'b{b}_z']).to(dev), torch.from_numpy(g[f'b{b}_noise']).to(dev)
+            t = torch.from_numpy(g[f'b{b}_t']).to(dev)
+            prompts = [str(p) for p in g[f'b{b}_prompts']]
+            init_t = torch.full((b,), 625, dtype=torch.long, device=dev)
+            with torch.no_grad():
+                xhat = sid_sd_sampler(hip1, z, prompts, init_t, sched, te, tok, 64, dtype=F32)
+            e, _ = rel_err(xhat, torch.from_numpy(g[f'b{b}_xhat']))
+            assert e < 3e-2, f'sampler {cfg} b{b}: {e}'
+            xh = torch.from_numpy(g[f'b{b}_xhat']).to(dev)
+            for kappa in (1.0, 1.5, 4.5):
+                for px0 in (True, False):
+                    with torch.no_grad():
+                        y = sid_sd_denoise(hip2, xh, noise, prompts, t, sched, te, tok, 64, dtype=F32, predict_x0=px0, guidance_scale=kappa)
+                    e, _ = rel_err(y, torch.from_numpy(g[f'b{b}_k{kappa}_x0{int(px0)}']))
+                    assert e < 4e-2, f'denoise {cfg} b{b} k{kappa} x0{px0}: {e}'
+
+
+@pytest.mark.parametrize('kappa,alpha', [(1.5, 1.0), (1.0, 1.2)])
+def test_sid_iteration_matches_oracle(dev, kappa, alpha):
+    """Two full iterations (fake-score step + generator step, 2 accumulation rounds, Adam, EMA) vs oracle/sid_ref.py."""
+    from oracle import fixtures, sid_ref
+    from oracle.scheduler_ref import DDPMSchedulerRef
+    from oracle.unet_ref import CONFIGS as RC
+    from sid_lsg_amd.optim import FusedAdamEMA
+    from sid_lsg_amd.scheduler import DDPMScheduler
+    from sid_lsg_amd.sid_step import SiDStep
+    from sid_lsg_amd.unet import CONFIGS, HipUNet2DCondition
+    cfg_name, lat, b, rounds, lr = 'tiny', 8, 2, 2, 2e-5
+    cfg = RC[cfg_name]
+    phi_r = fixtures.make_unet(cfg_name).eval().requires_grad_(False)
+    psi_r = fixtures.make_unet(cfg_name, seed=77).requires_grad_(False)   # psi != phi so the G loss is non-trivial at step 0
+    G_r = copy.deepcopy(phi_r)
+    Gema_r = copy.deepcopy(G_r)
+    nets_r = dict(true_score=phi_r, fake_score=psi_r, G=G_r, G_ema=Gema_r)
+
+    def hipnet(r):
+        return HipUNet2DCondition(CONFIGS[cfg_name]).materialize(dev, source=r.state_dict())
+    phi, psi, G = hipnet(phi_r), hipnet(psi_r), hipnet(G_r)
+    G_ema = hipnet(G_r)
+    opt_f = FusedAdamEMA(psi.parameters(), lr=lr, betas=(0.0, 0.999), eps=1e-8)
+    opt_g = FusedAdamEMA(G.parameters(), lr=lr, betas=(0.0, 0.999), eps=1e-8)
+    step = SiDStep(G, psi, phi, G_ema, DDPMScheduler().to(dev), opt_f, opt_g, alpha=alpha, cfg_train_fake=kappa,
+                   cfg_eval_fake=kappa, cfg_eval_real=kappa, batch_gpu_total=b * rounds, init_timestep=625)
+    st = dict(fake_score=[{} for _ in psi_r.parameters()], G=[{} for _ in G_r.parameters()])
+    hp = dict(alpha=alpha, kappa1=kappa, kappa2=kappa, kappa4=kappa, ls=1.0, lsg=1.0, batch_gpu_total=b * rounds, lr=lr, glr=lr,
+              betas=(0.0, 0.999), eps=1e-8, init_t=625, batch_size=b * rounds, ema_halflife_kimg=50, ema_rampup_ratio=0.05)
+    gen = torch.Generator().manual_seed(5)
+    cur_nimg = 0
+    for it in range(2):
+        inputs = dict(A=[], B=[])
+        for ph in ('A', 'B'):
+            for _ in range(rounds):
+                inputs[ph].append(dict(z=torch.randn(b, 4, lat, lat, generator=gen), noise=torch.randn(b, 4, lat, lat, generator=gen),
+                                       t=torch.randint(20, 980, (b,), generator=gen),
+                                       cond=torch.randn(b, cfg.text_len, cfg.cross_attention_dim, generator=gen).to(BF16).float(),
+                                       uncond=torch.randn(1, cfg.text_len, cfg.cross_attention_dim, generator=gen).to(BF16).float().expand(b, -1, -1).contiguous()))
+        hp['cur_nimg'] = cur_nimg
+        out_r = sid_ref.sid_iteration_ref(nets_r, st, DDPMSchedulerRef(), inputs, hp)
+        dinp = {ph: [{k: (v.to(dev).to(BF16).contiguous() if k in ('cond', 'uncond') else v.to(dev)) for k, v in r.items()}
+                     for r in inputs[ph]] for ph in inputs}
+        beta = sid_ref.ema_beta_ref(b * rounds, cur_nimg, 50, 0.05)
+        lf, lg = step.iteration(dinp, ema_beta=beta)
+        print(f'iter {it}: loss_fake {float(lf):.5f} vs {out_r["loss_fake"]:.5f}; loss_G {float(lg):.5f} vs {out_r["loss_G"]:.5f}')
+        assert abs(float(lf) - out_r['loss_fake']) <= 2e-2 * abs(out_r['loss_fake'])
+        assert abs(float(lg) - out_r['loss_G']) <= 5e-2 * abs(out_r['loss_G']) + 1e-3
+        cur_nimg += b * rounds
+    # parameters: Adam(beta1=0) moves every weight by ~lr*sign(g); compare the UPDATE direction statistically
+    for net, net_r, name in ((psi, psi_r, 'fake_score'), (G, G_r, 'G')):
+        agree, total = 0, 0
+        init = fixtures.make_unet(cfg_name, seed=77 if name == 'fake_score' else 1234)
+        by_name_r, by_name_0 = dict(net_r.named_parameters()), dict(init.named_parameters())
+        for n, p in net.named_parameters():
+            pr, p0 = by_name_r[n], by_name_0[n]
+            du, dr = (p.detach().cpu() - p0).flatten(), (pr.detach() - p0).flatten()
+            big = dr.abs() > 0.5 * lr          # ignore entries whose reference gradient is ~0 (sign is noise there)
+            agree += int((torch.sign(du[big]) == torch.sign(dr[big])).sum())
+            total += int(big.sum())
+        frac = agree / max(total, 1)
+        print(f'{name}: update-sign agreement {frac:.4f} over {total} weights')
+        assert frac > 0.93
+    ema_r = dict(Gema_r.named_parameters())
+    for n, p in G_ema.named_parameters():
+        if n in ('conv_in.weight', 'conv_out.bias', 'mid_block.attentions.0.proj_in.weight'):
+            e, _ = rel_err(p, ema_r[n])
+            assert e < 1e-3, f'EMA weights {n}'
