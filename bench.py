@@ -1,0 +1,224 @@
+#!/usr/bin/env python
+"""Benchmark: SiD-LSG distillation images/sec (BASELINE.json metric) on N MI355X of one node.
+
+One "step" = one loop iteration of training/sid_training_loop.py:383-571 = one fake-score update + one generator
+update on `batch_gpu` synthetic 512x512 samples per GPU (64x64x4 latents), SD1.5 architecture, kappa=1.5 on every
+branch (CFG batch [uncond ; cond] for both the fake-score net and the teacher), alpha=1, Adam(beta1=0), EMA.
+Nothing is skipped inside the timed region: noise/timestep sampling, CLIP text encoding of the step's prompts
+(PyTorch-ROCm, per north_star), 5 UNet forwards + 4 UNet backwards (18 F), both optimizer steps, EMA, and for N>1
+the gradient all-reduces.  Weights are seeded random (no SD checkpoints offline) and prompts are synthetic
+Aesthetic-style captions tokenised by the offline stand-in tokenizer: `"data": "synthetic"`.
+
+    python bench.py --gpus 1 --steps 5 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29511 \
+        bench.py --gpus 8 --steps 5 --warmup 2
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+F_GMAC = {'sd15': 401.63672064, 'sd21-base': 402.12873216}     # UNet forward GMAC / sample at 64x64 latents
+PEAK_BF16_TFLOPS = 2500.0                                        # dense bf16 MFMA peak, MI355X_MICROARCH.md
+PEAK_HBM_GBS = 8000.0
+
+PROMPT_WORDS = ('a highly detailed photograph of portrait landscape castle mountain river at sunset golden hour cinematic lighting '
+                'oil painting watercolor studio light bokeh sharp focus intricate elegant trending concept art dramatic sky').split()
+
+
+def synth_prompts(n, seed):
+    g = torch.Generator().manual_seed(seed)
+    out = []
+    for _ in range(n):
+        k = int(torch.randint(6, 18, (1,), generator=g))
+        idx = torch.randint(0, len(PROMPT_WORDS), (k,), generator=g).tolist()
+        out.append(' '.join(PROMPT_WORDS[i] for i in idx))
+    return out
+
+
+class KernelTimer:
+    """HIP-event timing of ONE entry point of the C ABI on the stream it is launched on (torch's current stream)."""
+
+    def __init__(self, lib, name, flops_fn):
+        self.lib, self.name, self.flops_fn = lib, name, flops_fn
+        self.events, self.flops, self.orig = [], 0.0, None
+
+    def __enter__(self):
+        self.orig = getattr(self.lib, self.name)
+        orig, self_ = self.orig, self
+
+        def timed(*a):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            orig(*a)
+            e1.record()
+            self_.events.append((e0, e1))
+            self_.flops += self_.flops_fn(*a)
+        self.lib.__dict__[self.name] = timed
+        return self
+
+    def __exit__(self, *exc):
+        self.lib.__dict__[self.name] = self.orig
+
+    def result(self):
+        torch.cuda.synchronize()
+        ms = sum(a.elapsed_time(b) for a, b in self.events)
+        return dict(launches=len(self.events), ms=ms, flops=self.flops)
+
+
+def conv_flops(*a):
+    # sidlsg_conv3x3_bf16(X, ldx, W, Y, ldc, bias, res, ldres, rowvec, B, H, Wd, Cin, Cout, stride, ups, alpha, flags, stream)
+    B, H, Wd, Cin, Cout, stride = a[9], a[10], a[11], a[12], a[13], a[14]
+    Ho, Wo = (H - 1) // stride + 1, (Wd - 1) // stride + 1
+    return 2.0 * B * Ho * Wo * Cout * 9 * Cin
+
+
+def cpu_baseline(arch, threads):
+    """Bounded CPU sample of the same workload with the ORACLE (kind 'port'): fp32 forwards of the SD1.5-size oracle UNet
+    on one 64x64x4 latent; one distillation image = 18 forward-equivalents."""
+    from oracle.unet_ref import CONFIGS, UNet2DConditionRef
+    torch.set_num_threads(threads)
+    cfg = CONFIGS[arch]
+    with torch.device('meta'):
+        net = UNet2DConditionRef(cfg)
+    net = net.to_empty(device='cpu')
+    with torch.no_grad():
+        for p in net.parameters():
+            p.normal_(0, 0.02) if p.ndim > 1 else p.zero_()
+        for m in net.modules():
+            if isinstance(m, (torch.nn.GroupNorm, torch.nn.LayerNorm)):
+                m.weight.fill_(1.0)
+        x = torch.randn(1, 4, 64, 64)
+        t = torch.tensor([625])
+        e = torch.randn(1, cfg.text_len, cfg.cross_attention_dim)
+        net(x, t, encoder_hidden_states=e)            # warm-up (page-in, oneDNN primitive creation)
+        n, t0 = 0, time.time()
+        while n < 2 or (time.time() - t0 < 12 and n < 6):
+            net(x, t, encoder_hidden_states=e)
+            n += 1
+        dt = (time.time() - t0) / n
+    return dict(value=1.0 / (18.0 * dt), unit='images/s', cores=threads, kind='port',
+                sample=f'{n} fp32 forwards of the {arch} oracle UNet (oracle/unet_ref.py) on 1 sample at 64x64x4, {dt:.2f} s each; '
+                       f'1 image = 18 forward-equivalents (5 fwd + 4 bwd passes, CFG on every branch)')
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--batch-gpu', type=int, default=8)
+    ap.add_argument('--arch', default='sd15')
+    ap.add_argument('--kappa', type=float, default=1.5)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-kernel-timing', action='store_true')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X: the product path has no CPU fallback')
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if world > 1:
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        torch.distributed.init_process_group('nccl', init_method='env://')
+    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
+
+    from sid_lsg_amd._lib import lib
+    from sid_lsg_amd.distributed import FlatGradReducer
+    from sid_lsg_amd.optim import FusedAdamEMA
+    from sid_lsg_amd.scheduler import DDPMScheduler
+    from sid_lsg_amd.sd_util import load_sd15
+    from sid_lsg_amd.sid_step import SiDStep
+    from sid_lsg_amd.text import TextConditioner
+    lib.load()
+
+    b = args.batch_gpu
+    lat = 64
+    phi, vae, sched, text_encoder, tokenizer = load_sd15(f'random:{args.arch}', None, dev, torch.bfloat16, seed=0)
+    psi = phi.clone_network()
+    G = phi.clone_network()
+    G_ema = phi.clone_network(with_grad_buffers=False)
+    text_encoder.to(torch.bfloat16)
+    cond = TextConditioner(tokenizer, text_encoder)
+    opt_f = FusedAdamEMA(psi.parameters(), lr=1e-6, betas=(0.0, 0.999), eps=1e-8)
+    opt_g = FusedAdamEMA(G.parameters(), lr=1e-6, betas=(0.0, 0.999), eps=1e-8)
+    step = SiDStep(G, psi, phi, G_ema, sched, opt_f, opt_g, alpha=1.0, cfg_train_fake=args.kappa, cfg_eval_fake=args.kappa,
+                   cfg_eval_real=args.kappa, batch_gpu_total=b, init_timestep=625,
+                   reducer=FlatGradReducer() if world > 1 else None, world_size=world)
+    batch_size = b * world
+    gen = torch.Generator(device=dev)
+
+    def one_iteration(it):
+        gen.manual_seed(1000 * rank + it)
+        inputs = dict(A=[], B=[])
+        for k, ph in enumerate(('A', 'B')):
+            prompts = synth_prompts(b, seed=(it * 2 + k) * world + rank)
+            z = torch.randn(b, 4, lat, lat, device=dev, generator=gen)
+            noise = torch.randn(b, 4, lat, lat, device=dev, generator=gen)
+            t = torch.randint(20, 980, (b,), device=dev, generator=gen)
+            inputs[ph].append(dict(z=z, noise=noise, t=t, cond=cond.encode(prompts), uncond=cond.uncond(b)))
+        half = min(50 * 1000, it * batch_size * 0.05)
+        beta = 0.5 ** (batch_size / max(half, 1e-8))
+        return step.iteration(inputs, ema_beta=beta)
+
+    def sync():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for it in range(args.warmup):
+        one_iteration(it)
+    sync()
+    timer = None
+    if not args.no_kernel_timing and rank == 0:
+        timer = KernelTimer(lib, 'sidlsg_conv3x3_bf16', conv_flops)
+        timer.__enter__()
+    t0 = time.time()
+    for it in range(args.warmup, args.warmup + args.steps):
+        lf, lg = one_iteration(it)
+    sync()
+    dt = time.time() - t0
+    if timer is not None:
+        timer.__exit__()
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        dt = float(tt)
+    if rank != 0:
+        return
+    value = args.steps * batch_size / dt
+    f_tflop = 2 * F_GMAC.get(args.arch, 0.0) / 1000.0
+    img_tflop = 18 * f_tflop if args.kappa != 1 else 11 * f_tflop
+    out = {
+        'metric': 'distillation images/sec (512^2, SD1.5, kappa=1.5)', 'value': value, 'unit': 'images/s', 'n_gpus': world,
+        'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1000.0, 'higher_is_better': True,
+        'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
+        'config': {'workload': f'{args.arch} SiD-LSG inner step, kappa={args.kappa} on all branches, 512x512 (64x64x4 latents), '
+                               f'batch_gpu={b}, fp32 masters + bf16 MFMA compute, Adam(beta1=0)+EMA, random-init weights',
+                   'global_batch': batch_size, 'parallelism': f'dp{world}'},
+        'step_tflops': value * img_tflop, 'step_mfma_frac': value * img_tflop / (PEAK_BF16_TFLOPS * world),
+        'loss_fake': float(lf), 'loss_G': float(lg),
+    }
+    if timer is not None:
+        r = timer.result()
+        ach = r['flops'] / (r['ms'] * 1e-3) / 1e12 if r['ms'] > 0 else 0.0
+        out['roofline'] = {'bound': 'mfma', 'kernel': 'gemm_bf16_kernel<128,*,1> (implicit-GEMM conv3x3 fwd + dgrad)',
+                           'achieved': ach, 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / PEAK_BF16_TFLOPS,
+                           'traffic': None, 'launches': r['launches'], 'avg_launch_ms': r['ms'] / max(r['launches'], 1),
+                           'algorithmic_tflop_per_launch': r['flops'] / max(r['launches'], 1) / 1e12}
+    if not args.no_cpu_baseline and world == 1:
+        out['cpu_baseline'] = cpu_baseline(args.arch, os.cpu_count() or 1)
+    print(json.dumps(out), flush=True)
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,210 @@
+"""`training_loop(**c)` with the reference's keyword surface (training/sid_training_loop.py:148-194), driving the
+HIP SiD step.  The per-iteration body is sid_lsg_amd.sid_step.SiDStep (= reference lines 383-571); this file is
+the minimal harness around it that the reference also has: dataset + prompt stream, network/optimizer
+construction by class name, accumulation rounds, EMA schedule, tick statistics (`stats_{alpha}.jsonl`,
+`Timing/sec_per_kimg`), snapshots (`network-snapshot-*.pkl`) and training-state dumps.
+
+Kept bit-for-bit in meaning: seeding (:238-239), batch_gpu / accumulation arithmetic (:246-250), the 16 consumed
+example prompt batches (:277-281), prompt dropout 10% iff kappa1 or kappa2 != 1 (:208-211, 393-396), RNG draw order
+inside a round (dropout flags, z, noise, t), EMA beta schedule (:553-558), `cur_nimg` accounting (:567).
+Not reproduced: preview PNG grids / FID metrics (cold path), torch.cuda.empty_cache +
+gc.collect every iteration (:384-385, a pure slowdown).
+"""
+import copy
+import json
+import os
+import pickle
+import time
+
+import numpy as np
+import psutil
+import torch
+
+from . import distributed as dist
+from .data import InfiniteSampler, prompt_batches
+from .dnnlib_util import EasyDict, construct_class_by_name, format_time
+from .distributed import FlatGradReducer
+from .sd_util import load_sd15
+from .sid_step import SiDStep
+from .text import TextConditioner
+
+
+class Stats:
+    """Per-tick scalar statistics (count/mean), the slice of torch_utils/training_stats.py the loop uses."""
+
+    def __init__(self):
+        self.acc = {}
+
+    def report(self, name, value):
+        n, s = self.acc.get(name, (0, 0.0))
+        self.acc[name] = (n + 1, s + float(value))
+        return value
+
+    def as_dict(self):
+        return {k: dict(num=n, mean=s / max(n, 1)) for k, (n, s) in self.acc.items()}
+
+    def reset(self):
+        self.acc = {}
+
+
+def training_loop(
+    run_dir='.', dataset_kwargs={}, data_loader_kwargs={}, network_kwargs={}, loss_kwargs={},
+    fake_score_optimizer_kwargs={}, g_optimizer_kwargs={}, augment_kwargs=None, seed=0, batch_size=512, batch_gpu=None,
+    total_kimg=200000, ema_halflife_kimg=500, ema_rampup_ratio=0.05, loss_scaling=1, loss_scaling_G=1, kimg_per_tick=50,
+    snapshot_ticks=50, state_dump_ticks=500, resume_pkl=None, resume_training=None, resume_kimg=0, alpha=1, tmax=980, tmin=20,
+    cudnn_benchmark=True, device=torch.device('cuda'), metrics=None, init_timestep=None, metric_pt_path=None,
+    metric_open_clip_path=None, metric_clip_path=None, pretrained_model_name_or_path='runwayml/stable-diffusion-v1-5',
+    pretrained_vae_model_name_or_path='runwayml/stable-diffusion-v1-5', fake_score_use_lora=False,
+    dataset_prompt_text_kwargs={}, cfg_train_fake=1, cfg_eval_fake=1, cfg_eval_real=1, num_steps=1, train_mode=True,
+    network_pkl=None, enable_xformers=True, gradient_checkpointing=False, resolution=512, on_iteration=None,
+):
+    if not train_mode:
+        raise NotImplementedError('evaluation mode (FID/CLIP metrics) is outside the hot-path scope (SURVEY.md section 8(f))')
+    rank, world = dist.get_rank(), dist.get_world_size()
+    dist.print0('Loading dataset...')
+    dataset_obj = construct_class_by_name(**dataset_prompt_text_kwargs)
+    dtype = torch.bfloat16   # compute dtype of the HIP path (masters fp32); network_kwargs.use_fp16 is accepted and ignored
+    use_dropout = (cfg_train_fake != 1 or cfg_eval_fake != 1)
+
+    if world > 1 and rank != 0:
+        torch.distributed.barrier()
+    unet, vae, noise_scheduler, text_encoder, tokenizer = load_sd15(
+        pretrained_model_name_or_path=pretrained_model_name_or_path, pretrained_vae_model_name_or_path=None, device=device,
+        weight_dtype=dtype, enable_xformers=enable_xformers, lora_config=None)
+    if world > 1 and rank == 0:
+        torch.distributed.barrier()
+    dist.print0('Loading network completed')
+
+    start_time = time.time()
+    np.random.seed((seed * world + rank) % (1 << 31))
+    torch.manual_seed(np.random.randint(1 << 31))
+    batch_gpu_total = batch_size // world
+    if batch_gpu is None or batch_gpu > batch_gpu_total:
+        batch_gpu = batch_gpu_total
+    rounds = batch_gpu_total // batch_gpu
+    assert batch_size == batch_gpu * rounds * world
+    lat = resolution // (2 ** (len(vae.config.block_out_channels) - 1))
+
+    sampler = InfiniteSampler(dataset_obj, rank=rank, num_replicas=world, seed=seed)
+    prompts_it = prompt_batches(dataset_obj, sampler, batch_gpu)
+    dist.print0('Example text prompts used for distillation:')
+    for i in range(16):
+        dist.print0(i, next(prompts_it))
+
+    true_score = unet.eval().requires_grad_(False)
+    fake_score = copy.deepcopy(true_score).train().requires_grad_(True)
+    G = copy.deepcopy(true_score).train().requires_grad_(True)
+    dist.print0('Setting up optimizer...')
+    opt_f = construct_class_by_name(params=fake_score.parameters(), **_hip_opt(fake_score_optimizer_kwargs))
+    opt_g = construct_class_by_name(params=G.parameters(), **_hip_opt(g_optimizer_kwargs))
+    G_ema = copy.deepcopy(G).eval().requires_grad_(False) if ema_halflife_kimg > 0 else G
+    if resume_training is not None:
+        data = torch.load(resume_training, map_location='cpu', weights_only=False)
+        fake_score.load_state_dict(_sd(data['fake_score'])); G.load_state_dict(_sd(data['G']))
+        if ema_halflife_kimg > 0:
+            G_ema.load_state_dict(_sd(data['G_ema']))
+        opt_f.load_state_dict(data['fake_score_optimizer_state']); opt_g.load_state_dict(data['g_optimizer_state'])
+        for net in (fake_score, G, G_ema):
+            net.refresh_compute_weights()
+        del data
+    if world > 1:   # what DDP's constructor does (:316-323): everybody starts from rank 0's weights
+        for net in (fake_score, G, G_ema):
+            torch.distributed.broadcast(net.flat_params, src=0)
+            net.refresh_compute_weights()
+    fake_score.eval().requires_grad_(False); G.eval().requires_grad_(False)
+
+    cond = TextConditioner(tokenizer, text_encoder)
+    step = SiDStep(G, fake_score, true_score, G_ema, noise_scheduler, opt_f, opt_g, alpha=alpha, cfg_train_fake=cfg_train_fake,
+                   cfg_eval_fake=cfg_eval_fake, cfg_eval_real=cfg_eval_real, loss_scaling=loss_scaling, loss_scaling_G=loss_scaling_G,
+                   batch_gpu_total=batch_gpu_total, init_timestep=init_timestep, reducer=FlatGradReducer() if world > 1 else None,
+                   world_size=world)
+
+    def make_round(dropout):
+        prompts = next(prompts_it)
+        if dropout:
+            flags = (torch.rand(len(prompts)) < 0.1).tolist()
+            prompts = ['' if f else p for f, p in zip(flags, prompts)]
+        z = torch.randn([len(prompts), 4, lat, lat], device=device, dtype=torch.float32)
+        noise = torch.randn_like(z)
+        t = torch.randint(tmin, tmax, (len(prompts),), device=device, dtype=torch.long)
+        return dict(z=z, noise=noise, t=t, cond=cond.encode(prompts), uncond=cond.uncond(len(prompts)))
+
+    dist.print0(f'Training for {total_kimg} kimg...')
+    stats = Stats()
+    cur_nimg, cur_tick = resume_kimg * 1000, 0
+    tick_start_nimg, tick_start_time = cur_nimg, time.time()
+    maintenance_time = tick_start_time - start_time
+    if world > 1:
+        torch.distributed.barrier()
+    dist.print0('Start Running')
+    while True:
+        inputs = dict(A=[make_round(use_dropout) for _ in range(rounds)])
+        loss_f = step.fake_update(inputs['A'])
+        inputs['B'] = [make_round(False) for _ in range(rounds)]
+        ema_beta = None
+        if ema_halflife_kimg > 0:
+            half = ema_halflife_kimg * 1000
+            if ema_rampup_ratio is not None:
+                half = min(half, cur_nimg * ema_rampup_ratio)
+            ema_beta = 0.5 ** (batch_size / max(half, 1e-8))
+        loss_g = step.generator_update(inputs['B'], ema_beta=ema_beta)
+        loss_f, loss_g = float(loss_f), float(loss_g)
+        stats.report('fake_score_Loss/loss', loss_f); stats.report('G_Loss/loss', loss_g)
+        if on_iteration is not None:
+            on_iteration(cur_nimg // batch_size, loss_f, loss_g)
+        cur_nimg += batch_size
+        done = cur_nimg >= total_kimg * 1000
+        if (not done) and (cur_tick != 0) and (cur_nimg < tick_start_nimg + kimg_per_tick * 1000):
+            continue
+
+        tick_end_time = time.time()
+        sec_per_kimg = (tick_end_time - tick_start_time) / (cur_nimg - tick_start_nimg) * 1e3
+        for k, v in (('Progress/tick', cur_tick), ('Progress/kimg', cur_nimg / 1e3), ('Timing/total_sec', tick_end_time - start_time),
+                     ('Timing/sec_per_tick', tick_end_time - tick_start_time), ('Timing/sec_per_kimg', sec_per_kimg),
+                     ('Timing/images_per_sec', 1e3 / sec_per_kimg), ('Timing/maintenance_sec', maintenance_time),
+                     ('Resources/cpu_mem_gb', psutil.Process(os.getpid()).memory_info().rss / 2 ** 30),
+                     ('Resources/peak_gpu_mem_gb', torch.cuda.max_memory_allocated(device) / 2 ** 30 if torch.cuda.is_available() else 0)):
+            stats.report(k, v)
+        dist.print0(f'tick {cur_tick:<5d} kimg {cur_nimg / 1e3:<9.1f} time {format_time(tick_end_time - start_time):<12s} '
+                    f'sec/tick {tick_end_time - tick_start_time:<7.1f} sec/kimg {sec_per_kimg:<7.2f} maintenance {maintenance_time:<6.1f} '
+                    f'loss_fake_score {loss_f:<6.2f} loss_G {loss_g:<6.2f}')
+        if torch.cuda.is_available():
+            torch.cuda.reset_peak_memory_stats()
+        if (not done) and dist.should_stop():
+            done = True
+        if snapshot_ticks is not None and (done or cur_tick % snapshot_ticks == 0) and cur_tick > 0 and rank == 0 and run_dir:
+            with open(os.path.join(run_dir, f'network-snapshot-{alpha:03f}-{cur_nimg // 1000:06d}.pkl'), 'wb') as f:
+                pickle.dump(dict(ema=G_ema), f)
+        if state_dump_ticks is not None and (done or cur_tick % state_dump_ticks == 0) and cur_tick != 0 and rank == 0 and run_dir:
+            torch.save(dict(fake_score=fake_score.state_dict(), G=G.state_dict(), G_ema=G_ema.state_dict(),
+                            fake_score_optimizer_state=opt_f.state_dict(), g_optimizer_state=opt_g.state_dict()),
+                       os.path.join(run_dir, f'training-state-{cur_nimg // 1000:06d}.pt'))
+        if rank == 0 and run_dir:
+            with open(os.path.join(run_dir, f'stats_{alpha:03f}.jsonl'), 'at') as f:
+                f.write(json.dumps(dict(stats.as_dict(), timestamp=time.time())) + '\n')
+        stats.reset()
+        dist.update_progress(cur_nimg // 1000, total_kimg)
+        cur_tick += 1
+        tick_start_nimg, tick_start_time = cur_nimg, time.time()
+        maintenance_time = tick_start_time - tick_end_time
+        if done:
+            break
+    dist.print0('\nExiting...')
+    return dict(G=G, fake_score=fake_score, G_ema=G_ema)
+
+
+def _hip_opt(kw):
+    """The reference CLI names torch.optim.Adam/AdamW (sid_train.py:219-226); the HIP step needs the fused flat-buffer
+    optimizer, which has the same hyper-parameter names.  Anything else is an error, never a silent substitute."""
+    kw = EasyDict(kw)
+    name = kw.get('class_name', 'sid_lsg_amd.optim.FusedAdamEMA')
+    mapping = {'torch.optim.Adam': 'sid_lsg_amd.optim.FusedAdamEMA', 'torch.optim.AdamW': 'sid_lsg_amd.optim.FusedAdamWEMA'}
+    name = mapping.get(name, name)
+    if not name.startswith('sid_lsg_amd.optim.'):
+        raise ValueError(f'optimizer {name} cannot drive the flat-buffer HIP step; use sid_lsg_amd.optim.FusedAdamEMA / FusedAdamWEMA')
+    kw['class_name'] = name
+    return kw
+
+
+def _sd(obj):
+    return obj.state_dict() if isinstance(obj, torch.nn.Module) else obj
