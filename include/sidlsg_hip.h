@@ -116,9 +116,9 @@ int sidlsg_concat2(void* a, void* b, void* out, long long M, int C1, int C2, int
 int sidlsg_sumpool2x2(const void* g, void* out, int B, int H, int W, int C, void* stream);   /* bwd of nearest x2 */
 int sidlsg_zero_insert2(const void* g, void* out, int B, int Ho, int Wo, int H, int W, int C, void* stream); /* bwd-data of stride 2: out [B][H][W][C] */
 int sidlsg_add_bf16(const void* a, const void* b, void* o, long long n, void* stream);
-int sidlsg_colsum_nchunks(int B, int rows_per_batch); /* host: ws = B*nchunks*N floats */
+int sidlsg_colsum_nchunks(int B, int rows_per_batch); /* host: grid.x of the reduction */
 int sidlsg_colsum(const void* g, int ldg, float* per_batch, float* total, float* ws, int B, int rows_per_batch, int N,
-                  void* stream); /* bias / time-embedding gradients */
+                  void* stream); /* bias / time-embedding gradients: per_batch[B][N] += (zero it first), total[N] +=; ws unused */
 int sidlsg_cast_f32_bf16(const float* x, void* y, long long n, void* stream);
 int sidlsg_cast_bf16_f32(const void* x, float* y, long long n, void* stream);
 int sidlsg_transpose_w(const float* src, void* dst, int N, int K, int T, void* stream); /* [N][T][K] -> [K][T rev][N] bf16 */

@@ -201,10 +201,11 @@ __global__ void add_bf16_kernel(const bf16* __restrict__ a, const bf16* __restri
     st8(o + i * 8, r);
 }
 
-// ---- column sums: part[b][chunk][N] = sum over the chunk's rows of g[b][row][N] -------------
-// 256 threads; columns are walked in passes of cpp 8-wide chunks, rows split over 256/cpp lanes.
-__global__ __launch_bounds__(256) void colsum_partial_kernel(const bf16* __restrict__ g, float* __restrict__ part,
-                                                             int rows_per_batch, int N, int ldg, int rows_per_chunk, int nch) {
+// ---- column sums of g [B][rows][N]: per_batch[b][n] += , total[n] += (fp32 atomics; callers zero per_batch) -----
+// grid (row chunks, B) fills the chip; 256 threads walk columns in passes of cpp 8-wide chunks, rows split over 256/cpp lanes.
+__global__ __launch_bounds__(256) void colsum_kernel(const bf16* __restrict__ g, float* __restrict__ per_batch,
+                                                     float* __restrict__ total, int rows_per_batch, int N, int ldg,
+                                                     int rows_per_chunk) {
     __shared__ float sm[256 * 8];
     const int N8 = N >> 3;
     const int cpp = N8 < 256 ? N8 : 256;
@@ -227,26 +228,14 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const bf16* __restr
             for (int e = 0; e < 8; e++) sm[(rl * cpp + ci) * 8 + e] = s[e];
         __syncthreads();
         for (int i = threadIdx.x; i < cpp * 8; i += 256) {
-            if (c0 * 8 + i >= N) continue;
+            const int col = c0 * 8 + i;
+            if (col >= N) continue;
             float t = 0.f;
             for (int r = 0; r < rows; r++) t += sm[r * cpp * 8 + i];
-            part[((size_t)b * nch + chunk) * N + c0 * 8 + i] = t;
+            if (per_batch) unsafeAtomicAdd(per_batch + (size_t)b * N + col, t);
+            if (total) unsafeAtomicAdd(total + col, t);
         }
     }
-}
-// out[b][n] (+)= sum_chunk part[b][chunk][n] ; and/or total[n] += sum_b sum_chunk
-__global__ void colsum_final_kernel(const float* __restrict__ part, float* __restrict__ per_batch, float* __restrict__ total,
-                                    int B, int nch, int N) {
-    const int n = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n >= N) return;
-    float tot = 0.f;
-    for (int b = 0; b < B; b++) {
-        float t = 0.f;
-        for (int k = 0; k < nch; k++) t += part[((size_t)b * nch + k) * N + n];
-        if (per_batch) per_batch[(size_t)b * N + n] = t;
-        tot += t;
-    }
-    if (total) total[n] += tot;
 }
 
 // ---- weights: fp32 master -> bf16 compute copies ---------------------------------------------
@@ -498,12 +487,12 @@ int sidlsg_colsum_nchunks(int B, int rows_per_batch) {
 }
 int sidlsg_colsum(const void* g, int ldg, float* per_batch, float* total, float* ws, int B, int rows_per_batch, int N,
                   void* stream) {
+    (void)ws;   // kept in the ABI; the reduction is single-pass with atomics (per_batch must be zeroed by the caller)
     if (N % 8 || N <= 0) return SIDLSG_EINVAL;
-    hipStream_t s = (hipStream_t)stream;
     const int nch = sidlsg_colsum_nchunks(B, rows_per_batch);
     const int rpc = (rows_per_batch + nch - 1) / nch;
-    hipLaunchKernelGGL(colsum_partial_kernel, dim3(nch, B), dim3(256), 0, s, (const bf16*)g, ws, rows_per_batch, N, ldg, rpc, nch);
-    hipLaunchKernelGGL(colsum_final_kernel, dim3((N + 255) / 256), dim3(256), 0, s, ws, per_batch, total, B, nch, N);
+    hipLaunchKernelGGL(colsum_kernel, dim3(nch, B), dim3(256), 0, (hipStream_t)stream, (const bf16*)g, per_batch, total,
+                       rows_per_batch, N, ldg, rpc);
     return sidlsg_last_error();
 }
 int sidlsg_cast_f32_bf16(const float* x, void* y, long long n, void* stream) {

@@ -13,6 +13,10 @@
 // 16x16x32 MFMAs; LDS double buffer, 128-byte rows with a 16-byte-chunk XOR swizzle
 // (chunk ^= (row>>1)&7) that makes every ds_read_b128 lane group conflict free;
 // global->register->LDS staging issued one K-tile ahead of the MFMAs.
+// Loads are branch-free: every operand is read through a buffer resource with the hardware
+// range check -- an out-of-image tap / row >= M / k >= K lane simply gets the OOB offset and
+// reads zeros.  Row offsets are computed once per tap (a wave-uniform event every Cin/64 tiles),
+// so the steady-state cost of the im2col is one v_add per 16-byte chunk.
 // The MFMA is issued "transposed" (rows = output channel, cols = pixel) and W-tile rows are
 // permuted per tile pair so that each lane ends up with 8 consecutive output channels of one
 // pixel: the epilogue stores 16 bytes per lane.
@@ -32,13 +36,20 @@ struct GemmParams {
     int H, Wd, Cin, Ho, Wo, stride, ups;
     float alpha;
     int flags;
+    unsigned a_bytes, w_bytes;   // sizes of the A / W allocations seen by the kernel (< 2 GiB)
 };
 
 enum { F_OUT_F32 = 1, F_SILU = 2, F_ACCUM = 4 };
 
 constexpr int BK = 64;
 constexpr int NTHREADS = 256;
+constexpr unsigned OOB = 0x80000000u;   // any offset >= 2 GiB is out of range for our buffers -> load returns 0
 
+DEVFN bf16x8 buf_ld8(__amdgpu_buffer_rsrc_t r, unsigned off) {
+    return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
+}
+
+// MODE 0: dense rows.  MODE 1: conv3x3 with Cin % 64 == 0 (a K-tile lies inside one tap).  MODE 2: conv3x3, any Cin % 8 == 0.
 template <int BM, int BN, int MODE>
 __global__ __launch_bounds__(NTHREADS) void gemm_bf16_kernel(GemmParams p) {
     constexpr int WMT = BM / 2, WNT = BN / 2;   // wave tile
@@ -64,58 +75,79 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_kernel(GemmParams p) {
     const int wm0 = (wave >> 1) * WMT, wn0 = (wave & 1) * WNT;
     const int kc = tid & 7, r0 = tid >> 3;
 
-    // ---- per-thread A row descriptors
-    const bf16* arow[AR];
-    int ahi[AR], awi[AR];
-    bool aok[AR];
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(p.A), 0, (int)p.a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(p.W), 0, (int)p.w_bytes, 0x00020000);
+
+    // ---- per-thread row descriptors (byte offsets; OOB = reads zeros)
+    const int Hs = p.ups ? (p.H >> 1) : p.H, Ws = p.ups ? (p.Wd >> 1) : p.Wd;
+    unsigned abase[AR];      // dense: row offset (+ chunk); conv: batch image offset (+ chunk)
+    int ahi[AR], awi[AR];    // conv: top-left input coordinate of the 3x3 window
+    unsigned arow[AR];       // conv MODE 1: current per-tap row offset
 #pragma unroll
     for (int i = 0; i < AR; i++) {
         const int m = m0 + r0 + 32 * i;
-        aok[i] = m < p.M;
-        const int mm = aok[i] ? m : 0;
+        const bool ok = m < p.M;
         if (MODE == 0) {
-            arow[i] = p.A + (size_t)mm * p.lda;
+            abase[i] = ok ? (unsigned)m * (unsigned)p.lda * 2u + kc * 16u : OOB;
             ahi[i] = awi[i] = 0;
         } else {
+            const int mm = ok ? m : 0;
             const int hw = p.Ho * p.Wo;
             const int b = mm / hw, rem = mm - b * hw;
             const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
-            const int Hs = p.ups ? (p.H >> 1) : p.H, Ws = p.ups ? (p.Wd >> 1) : p.Wd;
-            arow[i] = p.A + (size_t)b * Hs * Ws * p.lda;
-            ahi[i] = ho * p.stride - 1;
+            abase[i] = (unsigned)b * (unsigned)(Hs * Ws) * (unsigned)p.lda * 2u + kc * 16u;
+            ahi[i] = ok ? ho * p.stride - 1 : -100000;       // pushes every tap out of range
             awi[i] = wo * p.stride - 1;
         }
+        arow[i] = OOB;
     }
-    const bf16* brow[BR];
-    bool bok[BR];
+    unsigned bbase[BR];
 #pragma unroll
     for (int i = 0; i < BR; i++) {
         const int n = n0 + r0 + 32 * i;
-        bok[i] = n < p.N;
-        brow[i] = p.W + (size_t)(bok[i] ? n : 0) * p.K;
+        bbase[i] = n < p.N ? (unsigned)n * (unsigned)p.K * 2u + kc * 16u : OOB;
     }
 
+    auto tap_rows = [&](int tap) {   // MODE 1: wave-uniform tap -> per-row offsets
+        const int dh = tap / 3, dw = tap - dh * 3;
+#pragma unroll
+        for (int i = 0; i < AR; i++) {
+            int hi = ahi[i] + dh, wi = awi[i] + dw;
+            const bool ok = hi >= 0 && hi < p.H && wi >= 0 && wi < p.Wd;
+            if (p.ups) { hi >>= 1; wi >>= 1; }
+            arow[i] = ok ? abase[i] + (unsigned)(hi * Ws + wi) * (unsigned)p.lda * 2u : OOB;
+        }
+    };
+
     bf16x8 areg[AR], breg[BR];
+    int cur_tap = -1;
     auto load_tile = [&](int kt) {
-        const int k = kt * BK + kc * 8;
-        const bool kok = k < p.K;
+        const int k0 = kt * BK;
+        const bool kok = k0 + kc * 8 < p.K;
         if (MODE == 0) {
 #pragma unroll
-            for (int i = 0; i < AR; i++) areg[i] = (aok[i] && kok) ? ld8(arow[i] + k) : zero8();
+            for (int i = 0; i < AR; i++) areg[i] = buf_ld8(ra, kok ? abase[i] + (unsigned)k0 * 2u : OOB);
+        } else if (MODE == 1) {
+            const int tap = k0 / p.Cin;          // scalar
+            const int c0 = k0 - tap * p.Cin;
+            if (tap != cur_tap) { tap_rows(tap); cur_tap = tap; }
+#pragma unroll
+            for (int i = 0; i < AR; i++) areg[i] = buf_ld8(ra, arow[i] + (unsigned)c0 * 2u);
         } else {
+            const int k = k0 + kc * 8;
             const int tap = k / p.Cin, c = k - tap * p.Cin;
             const int dh = tap / 3, dw = tap - dh * 3;
-            const int Ws = p.ups ? (p.Wd >> 1) : p.Wd;
 #pragma unroll
             for (int i = 0; i < AR; i++) {
                 int hi = ahi[i] + dh, wi = awi[i] + dw;
-                const bool ok = aok[i] && kok && hi >= 0 && hi < p.H && wi >= 0 && wi < p.Wd;
+                const bool ok = kok && hi >= 0 && hi < p.H && wi >= 0 && wi < p.Wd;
                 if (p.ups) { hi >>= 1; wi >>= 1; }
-                areg[i] = ok ? ld8(arow[i] + (size_t)(hi * Ws + wi) * p.lda + c) : zero8();
+                // abase already contains kc*16 bytes; replace it by the channel offset of this chunk
+                areg[i] = buf_ld8(ra, ok ? abase[i] - kc * 16u + ((unsigned)(hi * Ws + wi) * (unsigned)p.lda + (unsigned)c) * 2u : OOB);
             }
         }
 #pragma unroll
-        for (int i = 0; i < BR; i++) breg[i] = (bok[i] && kok) ? ld8(brow[i] + k) : zero8();
+        for (int i = 0; i < BR; i++) breg[i] = buf_ld8(rw, kok ? bbase[i] + (unsigned)k0 * 2u : OOB);
     };
     auto store_tile = [&](int buf) {
         bf16* a = As + buf * BM * BK;
@@ -199,31 +231,44 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_kernel(GemmParams p) {
                 v[4 + r] = paired ? acc[(2 * pr + 1) < NT ? 2 * pr + 1 : 2 * pr][mi][r] : 0.f;
             }
             if (n >= p.N) continue;
+            if (vec_ok && n + cnt <= p.N) {
+                // vector path: 8 (4) consecutive channels, all in range
+                float bb[8] = {0, 0, 0, 0, 0, 0, 0, 0}, rr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                if (p.bias) {
+                    const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.bias + n);
+                    bb[0] = b0[0]; bb[1] = b0[1]; bb[2] = b0[2]; bb[3] = b0[3];
+                    if (cnt == 8) { const f32x4 b1 = *reinterpret_cast<const f32x4*>(p.bias + n + 4); bb[4] = b1[0]; bb[5] = b1[1]; bb[6] = b1[2]; bb[7] = b1[3]; }
+                }
+                if (rv) {
+                    const f32x4 b0 = *reinterpret_cast<const f32x4*>(rv + n);
+                    bb[0] += b0[0]; bb[1] += b0[1]; bb[2] += b0[2]; bb[3] += b0[3];
+                    if (cnt == 8) { const f32x4 b1 = *reinterpret_cast<const f32x4*>(rv + n + 4); bb[4] += b1[0]; bb[5] += b1[1]; bb[6] += b1[2]; bb[7] += b1[3]; }
+                }
+                if (p.res) {
+                    const bf16* rp = p.res + (size_t)m * p.ldres + n;
+                    if (cnt == 8) { const bf16x8 t = ld8(rp);
 #pragma unroll
-            for (int e = 0; e < 8; e++) {
-                if (e >= cnt) break;
-                const int nn = n + e;
-                if (nn < p.N) {
-                    float x = v[e] * p.alpha;
-                    if (p.bias) x += p.bias[nn];
-                    if (rv) x += rv[nn];
-                    if (p.res) x += bf2f(p.res[(size_t)m * p.ldres + nn]);
+                        for (int e = 0; e < 8; e++) rr[e] = bf2f(t[e]); }
+                    else { const bf16x4 t = *reinterpret_cast<const bf16x4*>(rp);
+#pragma unroll
+                        for (int e = 0; e < 4; e++) rr[e] = bf2f(t[e]); }
+                }
+#pragma unroll
+                for (int e = 0; e < 8; e++) {
+                    float x = v[e] * p.alpha + bb[e] + rr[e];
                     if (p.flags & F_SILU) x = silu_f(x);
                     v[e] = x;
                 }
-            }
-            if (p.flags & F_OUT_F32) {
-                float* c = reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n;
-                if (vec_ok && n + cnt <= p.N && !(p.flags & F_ACCUM)) {
-                    *reinterpret_cast<f32x4*>(c) = (f32x4){v[0], v[1], v[2], v[3]};
-                    if (cnt == 8) *reinterpret_cast<f32x4*>(c + 4) = (f32x4){v[4], v[5], v[6], v[7]};
+                if (p.flags & F_OUT_F32) {
+                    float* c = reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n;
+                    if (p.flags & F_ACCUM) {
+                        for (int e = 0; e < cnt; e++) c[e] += v[e];
+                    } else {
+                        *reinterpret_cast<f32x4*>(c) = (f32x4){v[0], v[1], v[2], v[3]};
+                        if (cnt == 8) *reinterpret_cast<f32x4*>(c + 4) = (f32x4){v[4], v[5], v[6], v[7]};
+                    }
                 } else {
-                    for (int e = 0; e < cnt; e++)
-                        if (n + e < p.N) c[e] = (p.flags & F_ACCUM) ? c[e] + v[e] : v[e];
-                }
-            } else {
-                bf16* c = reinterpret_cast<bf16*>(p.C) + (size_t)m * p.ldc + n;
-                if (vec_ok && n + cnt <= p.N) {
+                    bf16* c = reinterpret_cast<bf16*>(p.C) + (size_t)m * p.ldc + n;
                     if (cnt == 8) {
                         bf16x8 o;
 #pragma unroll
@@ -235,9 +280,23 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_kernel(GemmParams p) {
                         for (int e = 0; e < 4; e++) o[e] = f2bf(v[e]);
                         *reinterpret_cast<bf16x4*>(c) = o;
                     }
-                } else {
-                    for (int e = 0; e < cnt; e++)
-                        if (n + e < p.N) c[e] = f2bf(v[e]);
+                }
+            } else {
+                // ragged N: element-wise, guarded
+                for (int e = 0; e < cnt; e++) {
+                    const int nn = n + e;
+                    if (nn >= p.N) break;
+                    float x = v[e] * p.alpha;
+                    if (p.bias) x += p.bias[nn];
+                    if (rv) x += rv[nn];
+                    if (p.res) x += bf2f(p.res[(size_t)m * p.ldres + nn]);
+                    if (p.flags & F_SILU) x = silu_f(x);
+                    if (p.flags & F_OUT_F32) {
+                        float* c = reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + nn;
+                        *c = (p.flags & F_ACCUM) ? *c + x : x;
+                    } else {
+                        reinterpret_cast<bf16*>(p.C)[(size_t)m * p.ldc + nn] = f2bf(x);
+                    }
                 }
             }
         }
@@ -276,7 +335,6 @@ static int check_common(const GemmParams& p) {
     return SIDLSG_OK;
 }
 
-
 // ---------------------------------------------------------------------------------------------
 // Weight gradient:  dW[N][K] (+)= sum_m dY[m][N] * A[m][K]     (fp32 atomics, split over m)
 //
@@ -297,6 +355,7 @@ struct WgradParams {
     int M, N, K, ldy, lda;
     int H, Wd, Cin, Ho, Wo, stride, ups;
     int m_per_split;
+    unsigned a_bytes, y_bytes;
 };
 
 DEVFN int wg_swz(int row) { return (row & 3) | (((row >> 3) & 1) << 2); }
@@ -315,13 +374,17 @@ __global__ __launch_bounds__(NTHREADS) void wgrad_bf16_kernel(WgradParams p) {
     const int wn0 = (wave >> 1) * 64, wk0 = (wave & 1) * 64;
     const int c16 = tid & 15, r0 = tid >> 4;  // chunk column (8 elements) and first row
 
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(p.A), 0, (int)p.a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(p.dY), 0, (int)p.y_bytes, 0x00020000);
+
     // per-thread constants of the A (k) operand: k is fixed for the whole kernel
     const int kA = k0 + c16 * 8;
     const bool kok = kA < p.K;
     int tap = 0, cA = kA, dh = 0, dw = 0;
     if (MODE == 1) { tap = kA / p.Cin; cA = kA - tap * p.Cin; dh = tap / 3; dw = tap - dh * 3; }
     const int nY = n0 + c16 * 8;
-    const bool nok = nY < p.N;     // N % 8 == 0 or N < 8 handled by caller padding rule (N%4==0 -> scalar path below)
+    const bool nfull = nY + 8 <= p.N;   // whole 16-byte chunk in range (else: ragged N, element path)
+    const bool nany = nY < p.N;
     const int Hs = p.ups ? (p.H >> 1) : p.H, Ws = p.ups ? (p.Wd >> 1) : p.Wd;
     const int hw = (MODE == 1) ? p.Ho * p.Wo : 1;
 
@@ -331,16 +394,16 @@ __global__ __launch_bounds__(NTHREADS) void wgrad_bf16_kernel(WgradParams p) {
         for (int i = 0; i < 4; i++) {
             const int m = mb + r0 + 16 * i;
             const bool mok = m < mend;
-            if (nok && mok) {
-                if (nY + 8 <= p.N) yreg[i] = ld8(p.dY + (size_t)m * p.ldy + nY);
-                else {
-                    bf16x8 v = zero8();
+            if (nfull) {
+                yreg[i] = buf_ld8(ry, mok ? ((unsigned)m * (unsigned)p.ldy + (unsigned)nY) * 2u : OOB);
+            } else {
+                bf16x8 v = zero8();
+                if (nany && mok)
                     for (int e = 0; e < 8; e++) if (nY + e < p.N) v[e] = p.dY[(size_t)m * p.ldy + nY + e];
-                    yreg[i] = v;
-                }
-            } else yreg[i] = zero8();
+                yreg[i] = v;
+            }
             if (MODE == 0) {
-                xreg[i] = (kok && mok) ? ld8(p.A + (size_t)m * p.lda + kA) : zero8();
+                xreg[i] = buf_ld8(ra, (kok && mok) ? ((unsigned)m * (unsigned)p.lda + (unsigned)kA) * 2u : OOB);
             } else {
                 bool ok = kok && mok;
                 const int mm = mok ? m : 0;
@@ -349,7 +412,7 @@ __global__ __launch_bounds__(NTHREADS) void wgrad_bf16_kernel(WgradParams p) {
                 int hi = ho * p.stride - 1 + dh, wi = wo * p.stride - 1 + dw;
                 ok = ok && hi >= 0 && hi < p.H && wi >= 0 && wi < p.Wd;
                 if (p.ups) { hi >>= 1; wi >>= 1; }
-                xreg[i] = ok ? ld8(p.A + ((size_t)(b * Hs + hi) * Ws + wi) * p.lda + cA) : zero8();
+                xreg[i] = buf_ld8(ra, ok ? (((unsigned)(b * Hs + hi) * (unsigned)Ws + (unsigned)wi) * (unsigned)p.lda + (unsigned)cA) * 2u : OOB);
             }
         }
     };
@@ -372,13 +435,13 @@ __global__ __launch_bounds__(NTHREADS) void wgrad_bf16_kernel(WgradParams p) {
     typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
     auto tr_frag = [&](const bf16* tilebase, int mrow, int colbase) -> bf16x8 {
         // lane t=(li) of group lg addresses row mrow + 8*lg + (t>>2) (+4 for the 2nd read), 4 columns at (t&3)*4
-        const int ra = mrow + 8 * lg + (li >> 2);
-        const int rb = ra + 4;
+        const int rA = mrow + 8 * lg + (li >> 2);
+        const int rB = rA + 4;
         const int g = colbase >> 4;                  // 16-column granule of this fragment
-        const int ca = ((g ^ wg_swz(ra)) << 4) + (li & 3) * 4;
-        const int cb = ((g ^ wg_swz(rb)) << 4) + (li & 3) * 4;
-        s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(tilebase + ra * WG_T + ca));
-        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(tilebase + rb * WG_T + cb));
+        const int ca = ((g ^ wg_swz(rA)) << 4) + (li & 3) * 4;
+        const int cb = ((g ^ wg_swz(rB)) << 4) + (li & 3) * 4;
+        s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(tilebase + rA * WG_T + ca));
+        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(tilebase + rB * WG_T + cb));
         typedef short s16x8 __attribute__((ext_vector_type(8)));
         s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
         return __builtin_bit_cast(bf16x8, v);
@@ -439,6 +502,8 @@ static int launch_wgrad(WgradParams p, hipStream_t s) {
     return sidlsg_last_error();
 }
 
+static bool fits31(unsigned long long bytes) { return bytes < 0x7FFFFFFFull; }
+
 extern "C" {
 
 // Dense GEMM: C[M,N] = act(alpha * A[M,K] W[N,K]^T + bias[N] + rowvec[m/rpb,N] + res[M,N])
@@ -450,6 +515,9 @@ int sidlsg_gemm_bf16(const void* A, int lda, const void* W, void* C, int ldc, co
     p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldc = ldc; p.ldres = ldres; p.rows_per_batch = rows_per_batch;
     p.alpha = alpha; p.flags = flags;
     if (int e = check_common(p)) return e;
+    const unsigned long long ab = ((unsigned long long)(M - 1) * lda + K) * 2ull, wb = (unsigned long long)N * K * 2ull;
+    if (!fits31(ab) || !fits31(wb)) return SIDLSG_EINVAL;
+    p.a_bytes = (unsigned)ab; p.w_bytes = (unsigned)wb;
     return dispatch_gemm<0>(p, (hipStream_t)stream);
 }
 
@@ -469,7 +537,12 @@ int sidlsg_conv3x3_bf16(const void* X, int ldx, const void* W, void* Y, int ldc,
     p.M = B * p.Ho * p.Wo; p.N = Cout; p.K = 9 * Cin; p.lda = ldx; p.ldc = ldc; p.ldres = ldres;
     p.rows_per_batch = p.Ho * p.Wo; p.alpha = alpha; p.flags = flags;
     if (int e = check_common(p)) return e;
-    return dispatch_gemm<1>(p, (hipStream_t)stream);
+    const int Hs = ups ? H / 2 : H, Ws = ups ? Wd / 2 : Wd;
+    const unsigned long long ab = (((unsigned long long)B * Hs * Ws - 1) * ldx + Cin) * 2ull, wb = (unsigned long long)Cout * 9 * Cin * 2ull;
+    if (!fits31(ab) || !fits31(wb)) return SIDLSG_EINVAL;
+    p.a_bytes = (unsigned)ab; p.w_bytes = (unsigned)wb;
+    if (Cin % 64 == 0) return dispatch_gemm<1>(p, (hipStream_t)stream);
+    return dispatch_gemm<2>(p, (hipStream_t)stream);
 }
 
 // dW[N][K] += dY[M][N]^T A[M][K]   (dense: Linear / 1x1 conv weight gradient; fp32 accumulate)
@@ -477,6 +550,9 @@ int sidlsg_wgrad_bf16(const void* dY, int ldy, const void* A, int lda, float* dW
     if (M <= 0 || N <= 0 || K <= 0 || (K & 7) || (lda & 7) || !dY || !A || !dW) return SIDLSG_EINVAL;
     WgradParams p{};
     p.dY = (const bf16*)dY; p.A = (const bf16*)A; p.dW = dW; p.M = M; p.N = N; p.K = K; p.ldy = ldy; p.lda = lda;
+    const unsigned long long ab = ((unsigned long long)(M - 1) * lda + K) * 2ull, yb = ((unsigned long long)(M - 1) * ldy + N) * 2ull;
+    if (!fits31(ab) || !fits31(yb)) return SIDLSG_EINVAL;
+    p.a_bytes = (unsigned)ab; p.y_bytes = (unsigned)yb;
     return launch_wgrad<0>(p, (hipStream_t)stream);
 }
 
@@ -489,6 +565,10 @@ int sidlsg_conv3x3_wgrad_bf16(const void* dY, int ldy, const void* X, int ldx, f
     p.H = H; p.Wd = Wd; p.Cin = Cin; p.stride = stride; p.ups = ups;
     p.Ho = (H + 2 - 3) / stride + 1; p.Wo = (Wd + 2 - 3) / stride + 1;
     p.M = B * p.Ho * p.Wo; p.N = Cout; p.K = 9 * Cin;
+    const int Hs = ups ? H / 2 : H, Ws = ups ? Wd / 2 : Wd;
+    const unsigned long long ab = (((unsigned long long)B * Hs * Ws - 1) * ldx + Cin) * 2ull, yb = ((unsigned long long)(p.M - 1) * ldy + Cout) * 2ull;
+    if (!fits31(ab) || !fits31(yb)) return SIDLSG_EINVAL;
+    p.a_bytes = (unsigned)ab; p.y_bytes = (unsigned)yb;
     return launch_wgrad<1>(p, (hipStream_t)stream);
 }
 

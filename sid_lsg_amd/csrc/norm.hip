@@ -129,6 +129,16 @@ __global__ void gn_bwd_stats_kernel(const bf16* __restrict__ x, const bf16* __re
         float t = 0.f;
         for (int r = 0; r < g.rows; r++) t += sm[(size_t)r * g.C * 2 + i];
         part[((size_t)b * g.nch + chunk) * g.C * 2 + i] = t;
+        sm[i] = t;   // row 0 now holds the block totals (each i is owned by exactly one thread)
+    }
+    __syncthreads();
+    // gamma-weighted group partials for this (sample, chunk): what gn_bwd_apply needs
+    float* gpart = part + (size_t)gridDim.y * g.nch * g.C * 2;
+    for (int grp = threadIdx.x; grp < g.G; grp += blockDim.x) {
+        float s1 = 0.f, s2 = 0.f;
+        for (int ch = grp * g.cpg; ch < (grp + 1) * g.cpg; ch++) { s2 += gamma[ch] * sm[ch * 2]; s1 += gamma[ch] * sm[ch * 2 + 1]; }
+        gpart[(((size_t)b * g.nch + chunk) * g.G + grp) * 2] = s1;
+        gpart[(((size_t)b * g.nch + chunk) * g.G + grp) * 2 + 1] = s2;
     }
 }
 
@@ -140,9 +150,10 @@ __global__ void gn_bwd_apply_kernel(const bf16* __restrict__ x, const bf16* __re
     const int b = blockIdx.y, chunk = blockIdx.x;
     for (int grp = threadIdx.x; grp < g.G; grp += blockDim.x) {
         float s1 = 0.f, s2 = 0.f;
+        const float* gpart = part + (size_t)gridDim.y * g.nch * g.C * 2;
         for (int k = 0; k < g.nch; k++) {
-            const float* o = part + ((size_t)b * g.nch + k) * g.C * 2;
-            for (int ch = grp * g.cpg; ch < (grp + 1) * g.cpg; ch++) { s2 += gamma[ch] * o[ch * 2]; s1 += gamma[ch] * o[ch * 2 + 1]; }
+            const float* o = gpart + (((size_t)b * g.nch + k) * g.G + grp) * 2;
+            s1 += o[0]; s2 += o[1];
         }
         const float n = (float)g.cpg * (float)g.HW;
         sm[grp] = s1 / n; sm[g.G + grp] = s2 / n;
@@ -174,13 +185,21 @@ __global__ void gn_bwd_apply_kernel(const bf16* __restrict__ x, const bf16* __re
 
 // out[j*ostride + ooff] += sum_p part[p*X + j*2 + sel]  style reductions are expressed with this:
 // out[i] (+)= sum_{p<P} part[p*pstride + i*istride + ioff],  i < n
+// grid.y splits P so the reduction fills the chip; partial sums are combined with fp32 atomics (out is += anyway).
 __global__ void colsum_reduce_kernel(const float* __restrict__ part, float* __restrict__ out, int P, size_t pstride,
                                      int istride, int ioff, int n, int accumulate) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    const int per = (P + gridDim.y - 1) / gridDim.y;
+    const int p0 = blockIdx.y * per, p1 = min(P, p0 + per);
     float t = 0.f;
-    for (int p = 0; p < P; p++) t += part[(size_t)p * pstride + (size_t)i * istride + ioff];
-    out[i] = accumulate ? out[i] + t : t;
+    for (int p = p0; p < p1; p++) t += part[(size_t)p * pstride + (size_t)i * istride + ioff];
+    if (accumulate) { if (p1 > p0) unsafeAtomicAdd(out + i, t); }
+    else out[i] = t;     // accumulate == 0 is only used with gridDim.y == 1
+}
+static dim3 reduce_grid(int n, int P) {
+    int split = (P + 15) / 16; if (split > 64) split = 64; if (split < 1) split = 1;
+    return dim3((n + 255) / 256, split);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -319,7 +338,7 @@ extern "C" {
 // workspace sizes (in floats) a caller must provide
 int sidlsg_groupnorm_ws_floats(int B, int HW, int C, int G) {
     GnGeom g; if (gn_geom(g, B, HW, C, G)) return -1;
-    return B * g.nch * C * 2;   // large enough for fwd (G*2 per chunk) and bwd (C*2 per chunk)
+    return B * g.nch * (C * 2 + G * 2);   // bwd: per-channel partials [B][nch][C][2] + group partials [B][nch][G][2]
 }
 int sidlsg_groupnorm_nchunks(int B, int HW, int C, int G) {
     GnGeom g; if (gn_geom(g, B, HW, C, G)) return -1;
@@ -352,8 +371,8 @@ int sidlsg_groupnorm_bwd(const void* x, const void* dy, const float* stats, cons
                        (const bf16*)x, (const bf16*)dy, stats, gamma, beta, ws, (bf16*)dx, g, silu);
     if (dgamma && dbeta) {
         const int P = B * g.nch;
-        hipLaunchKernelGGL(colsum_reduce_kernel, dim3((C + 255) / 256), dim3(256), 0, s, ws, dgamma, P, (size_t)C * 2, 2, 0, C, 1);
-        hipLaunchKernelGGL(colsum_reduce_kernel, dim3((C + 255) / 256), dim3(256), 0, s, ws, dbeta, P, (size_t)C * 2, 2, 1, C, 1);
+        hipLaunchKernelGGL(colsum_reduce_kernel, reduce_grid(C, P), dim3(256), 0, s, ws, dgamma, P, (size_t)C * 2, 2, 0, C, 1);
+        hipLaunchKernelGGL(colsum_reduce_kernel, reduce_grid(C, P), dim3(256), 0, s, ws, dbeta, P, (size_t)C * 2, 2, 1, C, 1);
     }
     return sidlsg_last_error();
 }
@@ -382,8 +401,8 @@ int sidlsg_layernorm_bwd(const void* x, const void* dy, const float* stats, cons
     hipLaunchKernelGGL(ln_bwd_kernel, dim3(nb), dim3(256), pg ? (size_t)4 * C * 2 * sizeof(float) : 0, s, (const bf16*)x,
                        (const bf16*)dy, stats, gamma, (bf16*)dx, pg ? ws : nullptr, rows, C, rpb);
     if (pg) {
-        hipLaunchKernelGGL(colsum_reduce_kernel, dim3((C + 255) / 256), dim3(256), 0, s, ws, dgamma, nb, (size_t)C * 2, 2, 0, C, 1);
-        hipLaunchKernelGGL(colsum_reduce_kernel, dim3((C + 255) / 256), dim3(256), 0, s, ws, dbeta, nb, (size_t)C * 2, 2, 1, C, 1);
+        hipLaunchKernelGGL(colsum_reduce_kernel, reduce_grid(C, nb), dim3(256), 0, s, ws, dgamma, nb, (size_t)C * 2, 2, 0, C, 1);
+        hipLaunchKernelGGL(colsum_reduce_kernel, reduce_grid(C, nb), dim3(256), 0, s, ws, dbeta, nb, (size_t)C * 2, 2, 1, C, 1);
     }
     return sidlsg_last_error();
 }

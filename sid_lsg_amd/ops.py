@@ -71,10 +71,8 @@ def colsum(g2d, rows_per_batch, per_batch=False, total=None):
     """g2d: [B*rows_per_batch, N] bf16.  total (fp32 [N]) is accumulated in place; returns per-batch sums if asked."""
     R, N = g2d.shape
     B = R // rows_per_batch
-    nch = lib.sidlsg_colsum_nchunks.raw(B, rows_per_batch)
-    ws = torch.empty(B * nch * N, device=g2d.device, dtype=F32)
-    pb = torch.empty((B, N), device=g2d.device, dtype=F32) if per_batch else None
-    lib.sidlsg_colsum(_p(g2d), g2d.stride(0), _p(pb), _p(total), _p(ws), B, rows_per_batch, N, _s())
+    pb = torch.zeros((B, N), device=g2d.device, dtype=F32) if per_batch else None
+    lib.sidlsg_colsum(_p(g2d), g2d.stride(0), _p(pb), _p(total), None, B, rows_per_batch, N, _s())
     return pb
 
 
