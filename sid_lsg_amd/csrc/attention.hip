@@ -11,12 +11,16 @@
 // (replicated over the 4 lane groups), so the online rescale is a per-lane scalar.
 // Head dims that are not multiples of 32 use one trailing 16-wide MFMA (d=40 -> 32+16 padded with
 // zeros, d=80 -> 64+16); nothing is padded in HBM.
+// K/V (or Q/dO) tiles are prefetched global->registers one tile ahead of the MFMAs and committed
+// to the single LDS buffer after the compute phase, so HBM/L2 latency hides under the MFMAs.
+// Loads are branch-free buffer loads (rows past the sequence end read zeros).
 //
 // Backward = two kernels without atomics:
 //   attn_dq   : same loop as forward (per query block, over key tiles): dQ^T = K^T dS^T
 //   attn_dkdv : per key block, over query tiles, in the non-transposed orientation
 //               S[query][key] so that P / dS are B operands of the contractions over queries.
 #include "common.h"
+#include <stdlib.h>
 
 struct AttnParams {
     const bf16 *Q, *K, *V, *dO;
@@ -31,6 +35,14 @@ struct AttnParams {
 };
 
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+constexpr unsigned A_OOB = 0x80000000u;
+
+DEVFN __amdgpu_buffer_rsrc_t mk_rsrc(const bf16* p) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(p), 0, 0x7FFFFFFF, 0x00020000);
+}
+DEVFN bf16x8 bld8(__amdgpu_buffer_rsrc_t r, unsigned off) {
+    return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
+}
 
 template <int DP>
 struct Frag {
@@ -90,21 +102,36 @@ DEVFN bf16x8 pack_p(f32x4 a, f32x4 b) {
     return o;
 }
 
-template <int DP>
-DEVFN void load_tile_lds(bf16* dst, int LD, const bf16* src, long long ld, int row0, int nrows, int tile_rows, int D) {
-    constexpr int C8 = DP / 8;
-    for (int idx = threadIdx.x; idx < tile_rows * C8; idx += blockDim.x) {
-        const int r = idx / C8, c = (idx - r * C8) * 8;
-        const bool ok = (row0 + r) < nrows && c < D;
-        st8(dst + r * LD + c, ok ? ld8(src + (long long)(row0 + r) * ld + c) : zero8());
+// register-staged tile: ROWS x DP (zero padded past D / past nrows), 256 threads
+template <int DP, int ROWS>
+struct TileRegs {
+    static constexpr int C8 = DP / 8;
+    static constexpr int TCH = ROWS * C8;
+    static constexpr int PER = (TCH + 255) / 256;
+    bf16x8 v[PER];
+    DEVFN void load(__amdgpu_buffer_rsrc_t rs, long long ld, int row0, int nrows, int D) {
+#pragma unroll
+        for (int j = 0; j < PER; j++) {
+            const int idx = threadIdx.x + 256 * j;
+            const int r = idx / C8, c = (idx - r * C8) * 8;
+            const bool ok = idx < TCH && (row0 + r) < nrows && c < D;
+            v[j] = bld8(rs, ok ? (unsigned)(((long long)(row0 + r) * ld + c) * 2) : A_OOB);
+        }
     }
-}
+    DEVFN void store(bf16* dst, int LD) const {
+#pragma unroll
+        for (int j = 0; j < PER; j++) {
+            const int idx = threadIdx.x + 256 * j;
+            const int r = idx / C8, c = (idx - r * C8) * 8;
+            if (idx < TCH) st8(dst + r * LD + c, v[j]);
+        }
+    }
+};
 
 constexpr int AT_KT = 64;   // keys per LDS tile
-constexpr int AT_QB = 128;  // queries per block (4 waves x 32)
 
-// MODE 0: forward (O, LSE).  MODE 1: dQ.
-template <int DP, int MODE>
+// MODE 0: forward (O, LSE).  MODE 1: dQ.   QT = 16-query tiles per wave (block = 4 waves * QT * 16 queries)
+template <int DP, int QT, int MODE>
 __global__ __launch_bounds__(256) void attn_q_kernel(AttnParams p) {
     constexpr int LD = DP + 8;
     constexpr int DT = DP / 16;
@@ -112,18 +139,19 @@ __global__ __launch_bounds__(256) void attn_q_kernel(AttnParams p) {
     __shared__ __attribute__((aligned(16))) bf16 Vs[AT_KT * LD];
     const int b = blockIdx.z, h = blockIdx.y;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lg = lane >> 4;
-    const int q0 = blockIdx.x * AT_QB + wave * 32;
+    const int q0 = (blockIdx.x * 4 + wave) * (QT * 16);
     const bf16* Qb = p.Q + b * p.bsq + (long long)h * p.D;
-    const bf16* Kb = p.K + b * p.bsk + (long long)h * p.D;
-    const bf16* Vb = p.V + b * p.bsv + (long long)h * p.D;
+    const __amdgpu_buffer_rsrc_t rk = mk_rsrc(p.K + b * p.bsk + (long long)h * p.D);
+    const __amdgpu_buffer_rsrc_t rv = mk_rsrc(p.V + b * p.bsv + (long long)h * p.D);
 
-    Frag<DP> fq[2], fdo[2];
-    float lse[2] = {0.f, 0.f}, dl[2] = {0.f, 0.f};
+    Frag<DP> fq[QT], fdo[MODE == 1 ? QT : 1];
+    float lse[QT], dl[QT];
 #pragma unroll
-    for (int qt = 0; qt < 2; qt++) {
+    for (int qt = 0; qt < QT; qt++) {
         const int q = q0 + qt * 16 + li;
         const bool ok = q < p.Nq;
         frag_from_global<DP>(fq[qt], Qb + (long long)(ok ? q : 0) * p.ldq, lg, p.D, ok);
+        lse[qt] = dl[qt] = 0.f;
         if (MODE == 1) {
             const bf16* dOb = p.dO + b * p.bso + (long long)h * p.D;
             frag_from_global<DP>(fdo[qt], dOb + (long long)(ok ? q : 0) * p.ldo, lg, p.D, ok);
@@ -131,73 +159,94 @@ __global__ __launch_bounds__(256) void attn_q_kernel(AttnParams p) {
             dl[qt] = ok ? p.delta[((long long)b * p.H + h) * p.Nq + q] : 0.f;
         }
     }
-    f32x4 o[DT][2];
+    f32x4 o[DT][QT];
 #pragma unroll
-    for (int i = 0; i < DT; i++) { o[i][0] = (f32x4){0, 0, 0, 0}; o[i][1] = (f32x4){0, 0, 0, 0}; }
-    float m[2] = {-INFINITY, -INFINITY}, l[2] = {0.f, 0.f};
+    for (int i = 0; i < DT; i++)
+#pragma unroll
+        for (int qt = 0; qt < QT; qt++) o[i][qt] = (f32x4){0, 0, 0, 0};
+    float m[QT], l[QT];
+#pragma unroll
+    for (int qt = 0; qt < QT; qt++) { m[qt] = -INFINITY; l[qt] = 0.f; }
 
+    TileRegs<DP, AT_KT> tk, tv;
+    tk.load(rk, p.ldk, 0, p.Nk, p.D);
+    tv.load(rv, p.ldv, 0, p.Nk, p.D);
+    tk.store(Ks, LD);
+    tv.store(Vs, LD);
+    __syncthreads();
     for (int k0 = 0; k0 < p.Nk; k0 += AT_KT) {
-        __syncthreads();
-        load_tile_lds<DP>(Ks, LD, Kb, p.ldk, k0, p.Nk, AT_KT, p.D);
-        load_tile_lds<DP>(Vs, LD, Vb, p.ldv, k0, p.Nk, AT_KT, p.D);
-        __syncthreads();
-        f32x4 s[4][2];
+        const bool more = k0 + AT_KT < p.Nk;
+        if (more) { tk.load(rk, p.ldk, k0 + AT_KT, p.Nk, p.D); tv.load(rv, p.ldv, k0 + AT_KT, p.Nk, p.D); }
+        f32x4 s[4][QT];
 #pragma unroll
         for (int kt = 0; kt < 4; kt++) {
             Frag<DP> fk;
             frag_from_lds<DP>(fk, Ks + (kt * 16 + li) * LD, lg);
 #pragma unroll
-            for (int qt = 0; qt < 2; qt++) s[kt][qt] = mma_d<DP>((f32x4){0, 0, 0, 0}, fk, fq[qt]);
+            for (int qt = 0; qt < QT; qt++) s[kt][qt] = mma_d<DP>((f32x4){0, 0, 0, 0}, fk, fq[qt]);
         }
-        // scores -> probabilities (keys of this lane: k0 + kt*16 + lg*4 + r)
+        // scores -> probabilities (keys of this lane: k0 + kt*16 + lg*4 + r).  The softmax is the VALU-bound part
+        // at d=40: raw v_exp_f32, scale folded into one FMA, masking only on the ragged last tile, and the
+        // running-max rescale of O deferred until the max grows by > 2^8 (LSE stays exact: m + log2(l)).
+        if (k0 + AT_KT > p.Nk) {
 #pragma unroll
-        for (int qt = 0; qt < 2; qt++) {
-            if (MODE == 0) {
-                float mx = -INFINITY;
+            for (int kt = 0; kt < 4; kt++)
 #pragma unroll
-                for (int kt = 0; kt < 4; kt++)
+                for (int r = 0; r < 4; r++)
+                    if (k0 + kt * 16 + lg * 4 + r >= p.Nk) {
 #pragma unroll
-                    for (int r = 0; r < 4; r++) {
-                        const int key = k0 + kt * 16 + lg * 4 + r;
-                        const float v = key < p.Nk ? s[kt][qt][r] * p.scale2 : -INFINITY;
-                        s[kt][qt][r] = v;
-                        mx = fmaxf(mx, v);
+                        for (int qt = 0; qt < QT; qt++) s[kt][qt][r] = -INFINITY;
                     }
+        }
+#pragma unroll
+        for (int qt = 0; qt < QT; qt++) {
+            if (MODE == 0) {
+                float mx = fmaxf(fmaxf(s[0][qt][0], s[0][qt][1]), fmaxf(s[0][qt][2], s[0][qt][3]));
+#pragma unroll
+                for (int kt = 1; kt < 4; kt++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) mx = fmaxf(mx, s[kt][qt][r]);
                 mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
                 mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-                const float mn = fmaxf(m[qt], mx);
-                const float msafe = mn == -INFINITY ? 0.f : mn;
-                const float alpha = exp2f(m[qt] - msafe);
+                mx *= p.scale2;                                    // scale2 > 0: max commutes with the scaling
+                if (__any(mx > m[qt] + 8.0f)) {                    // wave-uniform: rescale everything held at the old max
+                    const float mn = fmaxf(m[qt], mx);
+                    const float alpha = __builtin_amdgcn_exp2f(m[qt] - mn);   // m = -inf on the first tile -> 0
+                    l[qt] *= alpha;
+                    m[qt] = mn;
+#pragma unroll
+                    for (int i = 0; i < DT; i++) o[i][qt] *= alpha;
+                }
+                const float nm = -m[qt];
                 float sum = 0.f;
 #pragma unroll
                 for (int kt = 0; kt < 4; kt++)
 #pragma unroll
-                    for (int r = 0; r < 4; r++) { const float e = exp2f(s[kt][qt][r] - msafe); s[kt][qt][r] = e; sum += e; }
-                l[qt] = l[qt] * alpha + sum;
-                m[qt] = mn;
-#pragma unroll
-                for (int i = 0; i < DT; i++) o[i][qt] *= alpha;
+                    for (int r = 0; r < 4; r++) {
+                        const float e = __builtin_amdgcn_exp2f(fmaf(s[kt][qt][r], p.scale2, nm));
+                        s[kt][qt][r] = e;
+                        sum += e;
+                    }
+                l[qt] += sum;
             } else {
+                const float nl = -lse[qt];
 #pragma unroll
                 for (int kt = 0; kt < 4; kt++)
 #pragma unroll
-                    for (int r = 0; r < 4; r++) {
-                        const int key = k0 + kt * 16 + lg * 4 + r;
-                        s[kt][qt][r] = key < p.Nk ? exp2f(s[kt][qt][r] * p.scale2 - lse[qt]) : 0.f;
-                    }
+                    for (int r = 0; r < 4; r++) s[kt][qt][r] = __builtin_amdgcn_exp2f(fmaf(s[kt][qt][r], p.scale2, nl));
             }
         }
         if (MODE == 1) {
-            // dP^T = V dO^T ; dS^T = P^T * (dP^T - delta) * scale   (overwrites s)
+            // dP^T = V dO^T ; dS^T = P^T * (dP^T - delta)   (overwrites s; the d^-1/2 factor is applied in the epilogue)
 #pragma unroll
             for (int kt = 0; kt < 4; kt++) {
                 Frag<DP> fv;
                 frag_from_lds<DP>(fv, Vs + (kt * 16 + li) * LD, lg);
 #pragma unroll
-                for (int qt = 0; qt < 2; qt++) {
+                for (int qt = 0; qt < QT; qt++) {
                     const f32x4 dp = mma_d<DP>((f32x4){0, 0, 0, 0}, fv, fdo[qt]);
 #pragma unroll
-                    for (int r = 0; r < 4; r++) s[kt][qt][r] = s[kt][qt][r] * (dp[r] - dl[qt]) * p.scale;
+                    for (int r = 0; r < 4; r++) s[kt][qt][r] *= (dp[r] - dl[qt]);
                 }
             }
         }
@@ -205,22 +254,28 @@ __global__ __launch_bounds__(256) void attn_q_kernel(AttnParams p) {
         const bf16* T2 = MODE == 0 ? Vs : Ks;
 #pragma unroll
         for (int kb = 0; kb < 2; kb++) {
-            bf16x8 pb[2];
+            bf16x8 pb[QT];
 #pragma unroll
-            for (int qt = 0; qt < 2; qt++) pb[qt] = pack_p(s[2 * kb][qt], s[2 * kb + 1][qt]);
+            for (int qt = 0; qt < QT; qt++) pb[qt] = pack_p(s[2 * kb][qt], s[2 * kb + 1][qt]);
 #pragma unroll
             for (int dt = 0; dt < DT; dt++) {
                 const bf16x8 fa = tr_frag32(T2, LD, kb * 32, dt * 16, li, lg);
 #pragma unroll
-                for (int qt = 0; qt < 2; qt++) o[dt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, pb[qt], o[dt][qt], 0, 0, 0);
+                for (int qt = 0; qt < QT; qt++) o[dt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, pb[qt], o[dt][qt], 0, 0, 0);
             }
+        }
+        __syncthreads();                 // everyone finished reading this tile
+        if (more) {
+            tk.store(Ks, LD);
+            tv.store(Vs, LD);
+            __syncthreads();
         }
     }
     // epilogue: lane holds, for query li of tile qt, d = dt*16 + lg*4 + r
 #pragma unroll
-    for (int qt = 0; qt < 2; qt++) {
+    for (int qt = 0; qt < QT; qt++) {
         const int q = q0 + qt * 16 + li;
-        float inv = 1.f;
+        float inv = MODE == 1 ? p.scale : 1.f;     // dQ = d^-1/2 * sum_k dS' K
         if (MODE == 0) {
             float lt = l[qt];
             lt += __shfl_xor(lt, 16, 64);
@@ -241,75 +296,115 @@ __global__ __launch_bounds__(256) void attn_q_kernel(AttnParams p) {
     }
 }
 
-// dK, dV: block = 64 keys (wave w owns keys 16w..16w+15), loop over 32-query tiles.
-constexpr int AK_QT = 32;
-template <int DP>
+// dK, dV: block = 4 waves * KT * 16 keys (wave owns KT key tiles), loop over 64-query tiles.
+constexpr int AK_QT = 64;
+template <int DP, int KT>
 __global__ __launch_bounds__(256) void attn_dkdv_kernel(AttnParams p) {
     constexpr int LD = DP + 8;
     constexpr int DT = DP / 16;
     __shared__ __attribute__((aligned(16))) bf16 Qs[AK_QT * LD];
     __shared__ __attribute__((aligned(16))) bf16 dOs[AK_QT * LD];
-    __shared__ float lse_s[AK_QT], dl_s[AK_QT];
+    __shared__ float lse_s[2][AK_QT], dl_s[2][AK_QT];
     const int b = blockIdx.z, h = blockIdx.y;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lg = lane >> 4;
-    const int key = blockIdx.x * 64 + wave * 16 + li;
-    const bool kok = key < p.Nk;
-    const bf16* Qb = p.Q + b * p.bsq + (long long)h * p.D;
-    const bf16* dOb = p.dO + b * p.bso + (long long)h * p.D;
-    Frag<DP> fk, fv;  // B operands: (k = d, col = key)
-    frag_from_global<DP>(fk, p.K + b * p.bsk + (long long)(kok ? key : 0) * p.ldk + (long long)h * p.D, lg, p.D, kok);
-    frag_from_global<DP>(fv, p.V + b * p.bsv + (long long)(kok ? key : 0) * p.ldv + (long long)h * p.D, lg, p.D, kok);
-    f32x4 dk[DT], dv[DT];
+    const int key0 = (blockIdx.x * 4 + wave) * (KT * 16);
+    const __amdgpu_buffer_rsrc_t rq = mk_rsrc(p.Q + b * p.bsq + (long long)h * p.D);
+    const __amdgpu_buffer_rsrc_t rdo = mk_rsrc(p.dO + b * p.bso + (long long)h * p.D);
+    const float* LSEb = p.LSE + ((long long)b * p.H + h) * p.Nq;
+    const float* DLb = p.delta + ((long long)b * p.H + h) * p.Nq;
+    Frag<DP> fk[KT], fv[KT];  // B operands: (k = d, col = key)
+    bool kok[KT];
 #pragma unroll
-    for (int i = 0; i < DT; i++) { dk[i] = (f32x4){0, 0, 0, 0}; dv[i] = (f32x4){0, 0, 0, 0}; }
+    for (int kt = 0; kt < KT; kt++) {
+        const int key = key0 + kt * 16 + li;
+        kok[kt] = key < p.Nk;
+        frag_from_global<DP>(fk[kt], p.K + b * p.bsk + (long long)(kok[kt] ? key : 0) * p.ldk + (long long)h * p.D, lg, p.D, kok[kt]);
+        frag_from_global<DP>(fv[kt], p.V + b * p.bsv + (long long)(kok[kt] ? key : 0) * p.ldv + (long long)h * p.D, lg, p.D, kok[kt]);
+    }
+    f32x4 dk[KT][DT], dv[KT][DT];
+#pragma unroll
+    for (int kt = 0; kt < KT; kt++)
+#pragma unroll
+        for (int i = 0; i < DT; i++) { dk[kt][i] = (f32x4){0, 0, 0, 0}; dv[kt][i] = (f32x4){0, 0, 0, 0}; }
 
-    for (int q0 = 0; q0 < p.Nq; q0 += AK_QT) {
-        __syncthreads();
-        load_tile_lds<DP>(Qs, LD, Qb, p.ldq, q0, p.Nq, AK_QT, p.D);
-        load_tile_lds<DP>(dOs, LD, dOb, p.ldo, q0, p.Nq, AK_QT, p.D);
+    TileRegs<DP, AK_QT> tq, tdo;
+    float lse_r = 0.f, dl_r = 0.f;
+    auto prefetch = [&](int q0) {
+        tq.load(rq, p.ldq, q0, p.Nq, p.D);
+        tdo.load(rdo, p.ldo, q0, p.Nq, p.D);
         if (threadIdx.x < AK_QT) {
             const int q = q0 + threadIdx.x;
-            lse_s[threadIdx.x] = q < p.Nq ? p.LSE[((long long)b * p.H + h) * p.Nq + q] : 0.f;
-            dl_s[threadIdx.x] = q < p.Nq ? p.delta[((long long)b * p.H + h) * p.Nq + q] : 0.f;
+            lse_r = q < p.Nq ? LSEb[q] : INFINITY;   // padded query rows contribute p = exp2(-inf) = 0
+            dl_r = q < p.Nq ? DLb[q] : 0.f;
         }
-        __syncthreads();
-        f32x4 pp[2], ds[2];
+    };
+    prefetch(0);
+    tq.store(Qs, LD); tdo.store(dOs, LD);
+    if (threadIdx.x < AK_QT) { lse_s[0][threadIdx.x] = lse_r; dl_s[0][threadIdx.x] = dl_r; }
+    __syncthreads();
+    int pb_ = 0;
+    for (int q0 = 0; q0 < p.Nq; q0 += AK_QT) {
+        const bool more = q0 + AK_QT < p.Nq;
+        if (more) prefetch(q0 + AK_QT);
+        f32x4 pp[KT][4], ds[KT][4];
 #pragma unroll
-        for (int qt = 0; qt < 2; qt++) {
+        for (int qt = 0; qt < 4; qt++) {
             Frag<DP> fq, fdo;  // A operands: (row = query, k = d)
             frag_from_lds<DP>(fq, Qs + (qt * 16 + li) * LD, lg);
             frag_from_lds<DP>(fdo, dOs + (qt * 16 + li) * LD, lg);
-            const f32x4 s = mma_d<DP>((f32x4){0, 0, 0, 0}, fq, fk);    // S[q][key]: lane col=key li, rows q = lg*4+r
-            const f32x4 dp = mma_d<DP>((f32x4){0, 0, 0, 0}, fdo, fv);
 #pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const int ql = qt * 16 + lg * 4 + r;
-                const bool ok = kok && (q0 + ql) < p.Nq;
-                const float pr = ok ? exp2f(s[r] * p.scale2 - lse_s[ql]) : 0.f;
-                pp[qt][r] = pr;
-                ds[qt][r] = pr * (dp[r] - dl_s[ql]) * p.scale;
+            for (int kt = 0; kt < KT; kt++) {
+                const f32x4 s = mma_d<DP>((f32x4){0, 0, 0, 0}, fq, fk[kt]);    // S[q][key]: lane col=key li, rows q = lg*4+r
+                const f32x4 dp = mma_d<DP>((f32x4){0, 0, 0, 0}, fdo, fv[kt]);
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int ql = qt * 16 + lg * 4 + r;
+                    // padded queries (q >= Nq) carry lse = +inf (set at prefetch) -> exp2(-inf) = 0; padded keys are
+                    // never stored.  The d^-1/2 factor of dS is applied to dK in the epilogue.
+                    const float pr = __builtin_amdgcn_exp2f(fmaf(s[r], p.scale2, -lse_s[pb_][ql]));
+                    pp[kt][qt][r] = pr;
+                    ds[kt][qt][r] = pr * (dp[r] - dl_s[pb_][ql]);
+                }
             }
         }
-        const bf16x8 pb = pack_p(pp[0], pp[1]), dsb = pack_p(ds[0], ds[1]);
 #pragma unroll
-        for (int dt = 0; dt < DT; dt++) {
-            const bf16x8 fa = tr_frag32(dOs, LD, 0, dt * 16, li, lg);   // dO^T (rows d, k = queries)
-            dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, pb, dv[dt], 0, 0, 0);
-            const bf16x8 fb = tr_frag32(Qs, LD, 0, dt * 16, li, lg);    // Q^T
-            dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb, dsb, dk[dt], 0, 0, 0);
+        for (int half = 0; half < 2; half++)
+#pragma unroll
+            for (int dt = 0; dt < DT; dt++) {
+                const bf16x8 fa = tr_frag32(dOs, LD, 32 * half, dt * 16, li, lg);   // dO^T (rows d, k = queries)
+                const bf16x8 fb = tr_frag32(Qs, LD, 32 * half, dt * 16, li, lg);    // Q^T
+#pragma unroll
+                for (int kt = 0; kt < KT; kt++) {
+                    const bf16x8 pbv = pack_p(pp[kt][2 * half], pp[kt][2 * half + 1]);
+                    const bf16x8 dsb = pack_p(ds[kt][2 * half], ds[kt][2 * half + 1]);
+                    dv[kt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, pbv, dv[kt][dt], 0, 0, 0);
+                    dk[kt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb, dsb, dk[kt][dt], 0, 0, 0);
+                }
+            }
+        __syncthreads();
+        if (more) {
+            tq.store(Qs, LD); tdo.store(dOs, LD);
+            pb_ ^= 1;
+            if (threadIdx.x < AK_QT) { lse_s[pb_][threadIdx.x] = lse_r; dl_s[pb_][threadIdx.x] = dl_r; }
+            __syncthreads();
         }
     }
-    if (!kok) return;
-    bf16* dKp = p.dK + b * p.bsk + (long long)key * p.ldk + (long long)h * p.D;
-    bf16* dVp = p.dV + b * p.bsv + (long long)key * p.ldv + (long long)h * p.D;
 #pragma unroll
-    for (int dt = 0; dt < DT; dt++) {
-        const int d = dt * 16 + lg * 4;
-        if (d + 4 <= p.D) {
-            bf16x4 a = {f2bf(dk[dt][0]), f2bf(dk[dt][1]), f2bf(dk[dt][2]), f2bf(dk[dt][3])};
-            bf16x4 c = {f2bf(dv[dt][0]), f2bf(dv[dt][1]), f2bf(dv[dt][2]), f2bf(dv[dt][3])};
-            *reinterpret_cast<bf16x4*>(dKp + d) = a;
-            *reinterpret_cast<bf16x4*>(dVp + d) = c;
+    for (int kt = 0; kt < KT; kt++) {
+        if (!kok[kt]) continue;
+        const int key = key0 + kt * 16 + li;
+        bf16* dKp = p.dK + b * p.bsk + (long long)key * p.ldk + (long long)h * p.D;
+        bf16* dVp = p.dV + b * p.bsv + (long long)key * p.ldv + (long long)h * p.D;
+#pragma unroll
+        for (int dt = 0; dt < DT; dt++) {
+            const int d = dt * 16 + lg * 4;
+            if (d + 4 <= p.D) {
+                bf16x4 a = {f2bf(dk[kt][dt][0] * p.scale), f2bf(dk[kt][dt][1] * p.scale), f2bf(dk[kt][dt][2] * p.scale),
+                            f2bf(dk[kt][dt][3] * p.scale)};
+                bf16x4 c = {f2bf(dv[kt][dt][0]), f2bf(dv[kt][dt][1]), f2bf(dv[kt][dt][2]), f2bf(dv[kt][dt][3])};
+                *reinterpret_cast<bf16x4*>(dKp + d) = a;
+                *reinterpret_cast<bf16x4*>(dVp + d) = c;
+            }
         }
     }
 }
@@ -331,25 +426,31 @@ __global__ void attn_delta_kernel(const bf16* __restrict__ dO, const bf16* __res
     delta[idx] = t;
 }
 
-template <int DP>
+template <int DP, int QT, int KT>
 static int launch_attn(const AttnParams& p, int mode, hipStream_t s) {
-    if (mode == 0) hipLaunchKernelGGL((attn_q_kernel<DP, 0>), dim3((p.Nq + AT_QB - 1) / AT_QB, p.H, p.B), dim3(256), 0, s, p);
-    else if (mode == 1) hipLaunchKernelGGL((attn_q_kernel<DP, 1>), dim3((p.Nq + AT_QB - 1) / AT_QB, p.H, p.B), dim3(256), 0, s, p);
-    else hipLaunchKernelGGL((attn_dkdv_kernel<DP>), dim3((p.Nk + 63) / 64, p.H, p.B), dim3(256), 0, s, p);
+    const int qb = 4 * QT * 16, kb = 4 * KT * 16;
+    if (mode == 0) hipLaunchKernelGGL((attn_q_kernel<DP, QT, 0>), dim3((p.Nq + qb - 1) / qb, p.H, p.B), dim3(256), 0, s, p);
+    else if (mode == 1) hipLaunchKernelGGL((attn_q_kernel<DP, QT, 1>), dim3((p.Nq + qb - 1) / qb, p.H, p.B), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((attn_dkdv_kernel<DP, KT>), dim3((p.Nk + kb - 1) / kb, p.H, p.B), dim3(256), 0, s, p);
     return sidlsg_last_error();
 }
 static int dispatch_attn(const AttnParams& p, int mode, hipStream_t s) {
     if (p.D % 8 || p.D <= 0 || p.D > 160) return SIDLSG_EINVAL;
     const int dp = (p.D + 15) / 16 * 16;
+    // long sequences + small heads: 64 queries (32 keys) per wave; otherwise 32 (16) to bound registers / keep the grid full
+    // Measured on MI355X (N=4096, d=40, B=16): 64 queries/wave at 1 wave/SIMD is ~3x SLOWER than 32 queries/wave at
+    // 2 waves/SIMD -- the softmax VALU work only overlaps MFMA across waves.  Kept behind an env switch for A/B runs.
+    static const bool allow_big = getenv("SIDLSG_ATTN_BIG") && atoi(getenv("SIDLSG_ATTN_BIG")) != 0;
+    const bool big = allow_big && (mode == 2 ? p.Nk : p.Nq) >= 1024;
     switch (dp) {
-        case 16: return launch_attn<16>(p, mode, s);
-        case 32: return launch_attn<32>(p, mode, s);
-        case 48: return launch_attn<48>(p, mode, s);
-        case 64: return launch_attn<64>(p, mode, s);
-        case 80: return launch_attn<80>(p, mode, s);
-        case 96: return launch_attn<96>(p, mode, s);
-        case 128: return launch_attn<128>(p, mode, s);
-        case 160: return launch_attn<160>(p, mode, s);
+        case 16: return launch_attn<16, 2, 1>(p, mode, s);
+        case 32: return launch_attn<32, 2, 1>(p, mode, s);
+        case 48: return big ? launch_attn<48, 4, 2>(p, mode, s) : launch_attn<48, 2, 1>(p, mode, s);
+        case 64: return big ? launch_attn<64, 4, 2>(p, mode, s) : launch_attn<64, 2, 1>(p, mode, s);
+        case 80: return launch_attn<80, 2, 1>(p, mode, s);
+        case 96: return launch_attn<96, 2, 1>(p, mode, s);
+        case 128: return launch_attn<128, 2, 1>(p, mode, s);
+        case 160: return launch_attn<160, 2, 1>(p, mode, s);
     }
     return SIDLSG_EINVAL;
 }
