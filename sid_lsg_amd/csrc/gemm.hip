@@ -321,9 +321,14 @@ template <int MODE>
 static int dispatch_gemm(const GemmParams& p, hipStream_t s) {
     // N multiple of 160 (every SD channel count is a multiple of 320) -> exact 160-wide tiles;
     // otherwise 128-wide; narrow outputs (conv_out, dgrad of conv_in) -> 64-wide.
+    // Small pixel counts (8x8 / 16x16 stages, small batches) would give < 256 tiles = idle CUs:
+    // fall back to 64-row and then 64x64 tiles until the grid covers the chip.
     if (p.N <= 64) return launch_gemm<128, 64, MODE>(p, s);
-    if (p.N % 160 == 0) return launch_gemm<128, 160, MODE>(p, s);
-    return launch_gemm<128, 128, MODE>(p, s);
+    auto tiles = [&](int bm, int bn) { return (long long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn); };
+    const bool n160 = p.N % 160 == 0;
+    if (tiles(128, n160 ? 160 : 128) >= 384) return n160 ? launch_gemm<128, 160, MODE>(p, s) : launch_gemm<128, 128, MODE>(p, s);
+    if (tiles(64, n160 ? 160 : 128) >= 384) return n160 ? launch_gemm<64, 160, MODE>(p, s) : launch_gemm<64, 128, MODE>(p, s);
+    return launch_gemm<64, 64, MODE>(p, s);
 }
 
 static int check_common(const GemmParams& p) {
