@@ -21,6 +21,7 @@
 // permuted per tile pair so that each lane ends up with 8 consecutive output channels of one
 // pixel: the epilogue stores 16 bytes per lane.
 #include "common.h"
+#include <stdlib.h>
 
 struct GemmParams {
     const bf16* A;        // dense: [M][lda]; conv: NHWC image [B][Hs][Ws][ldx]
@@ -50,6 +51,102 @@ DEVFN bf16x8 buf_ld8(__amdgpu_buffer_rsrc_t r, unsigned off) {
 }
 
 // MODE 0: dense rows.  MODE 1: conv3x3 with Cin % 64 == 0 (a K-tile lies inside one tap).  MODE 2: conv3x3, any Cin % 8 == 0.
+// Shared epilogue: lane (lg, li) holds, for pixel row m = mbase + mi*16 + li, 8 (or 4) consecutive channels per tile pair.
+template <int MT, int NT>
+DEVFN void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[NT][MT], int mbase, int nbase, int li, int lg) {
+    const int m0 = mbase, wm0 = 0, n0 = nbase, wn0 = 0;
+    // ---- epilogue: lane (lg, li) holds, for pixel row m = .. + li, 8 (or 4) consecutive channels
+    const bool vec_ok = (p.N & 7) == 0;
+#pragma unroll
+    for (int mi = 0; mi < MT; mi++) {
+        const int m = m0 + wm0 + mi * 16 + li;
+        if (m >= p.M) continue;
+        const float* rv = p.rowvec ? p.rowvec + (size_t)(m / p.rows_per_batch) * p.N : nullptr;
+#pragma unroll
+        for (int pr = 0; pr < (NT + 1) / 2; pr++) {
+            const bool paired = (2 * pr + 1) < NT;
+            const int cnt = paired ? 8 : 4;
+            const int n = n0 + wn0 + 32 * pr + lg * cnt;
+            float v[8];
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                v[r] = acc[2 * pr][mi][r];
+                v[4 + r] = paired ? acc[(2 * pr + 1) < NT ? 2 * pr + 1 : 2 * pr][mi][r] : 0.f;
+            }
+            if (n >= p.N) continue;
+            if (vec_ok && n + cnt <= p.N) {
+                // vector path: 8 (4) consecutive channels, all in range
+                float bb[8] = {0, 0, 0, 0, 0, 0, 0, 0}, rr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                if (p.bias) {
+                    const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.bias + n);
+                    bb[0] = b0[0]; bb[1] = b0[1]; bb[2] = b0[2]; bb[3] = b0[3];
+                    if (cnt == 8) { const f32x4 b1 = *reinterpret_cast<const f32x4*>(p.bias + n + 4); bb[4] = b1[0]; bb[5] = b1[1]; bb[6] = b1[2]; bb[7] = b1[3]; }
+                }
+                if (rv) {
+                    const f32x4 b0 = *reinterpret_cast<const f32x4*>(rv + n);
+                    bb[0] += b0[0]; bb[1] += b0[1]; bb[2] += b0[2]; bb[3] += b0[3];
+                    if (cnt == 8) { const f32x4 b1 = *reinterpret_cast<const f32x4*>(rv + n + 4); bb[4] += b1[0]; bb[5] += b1[1]; bb[6] += b1[2]; bb[7] += b1[3]; }
+                }
+                if (p.res) {
+                    const bf16* rp = p.res + (size_t)m * p.ldres + n;
+                    if (cnt == 8) { const bf16x8 t = ld8(rp);
+#pragma unroll
+                        for (int e = 0; e < 8; e++) rr[e] = bf2f(t[e]); }
+                    else { const bf16x4 t = *reinterpret_cast<const bf16x4*>(rp);
+#pragma unroll
+                        for (int e = 0; e < 4; e++) rr[e] = bf2f(t[e]); }
+                }
+#pragma unroll
+                for (int e = 0; e < 8; e++) {
+                    float x = v[e] * p.alpha + bb[e] + rr[e];
+                    if (p.flags & F_SILU) x = silu_f(x);
+                    v[e] = x;
+                }
+                if (p.flags & F_OUT_F32) {
+                    float* c = reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n;
+                    if (p.flags & F_ACCUM) {
+                        for (int e = 0; e < cnt; e++) c[e] += v[e];
+                    } else {
+                        *reinterpret_cast<f32x4*>(c) = (f32x4){v[0], v[1], v[2], v[3]};
+                        if (cnt == 8) *reinterpret_cast<f32x4*>(c + 4) = (f32x4){v[4], v[5], v[6], v[7]};
+                    }
+                } else {
+                    bf16* c = reinterpret_cast<bf16*>(p.C) + (size_t)m * p.ldc + n;
+                    if (cnt == 8) {
+                        bf16x8 o;
+#pragma unroll
+                        for (int e = 0; e < 8; e++) o[e] = f2bf(v[e]);
+                        st8(c, o);
+                    } else {
+                        bf16x4 o;
+#pragma unroll
+                        for (int e = 0; e < 4; e++) o[e] = f2bf(v[e]);
+                        *reinterpret_cast<bf16x4*>(c) = o;
+                    }
+                }
+            } else {
+                // ragged N: element-wise, guarded
+                for (int e = 0; e < cnt; e++) {
+                    const int nn = n + e;
+                    if (nn >= p.N) break;
+                    float x = v[e] * p.alpha;
+                    if (p.bias) x += p.bias[nn];
+                    if (rv) x += rv[nn];
+                    if (p.res) x += bf2f(p.res[(size_t)m * p.ldres + nn]);
+                    if (p.flags & F_SILU) x = silu_f(x);
+                    if (p.flags & F_OUT_F32) {
+                        float* c = reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + nn;
+                        *c = (p.flags & F_ACCUM) ? *c + x : x;
+                    } else {
+                        reinterpret_cast<bf16*>(p.C)[(size_t)m * p.ldc + nn] = f2bf(x);
+                    }
+                }
+            }
+        }
+    }
+}
+
+
 template <int BM, int BN, int MODE>
 __global__ __launch_bounds__(NTHREADS) void gemm_bf16_kernel(GemmParams p) {
     constexpr int WMT = BM / 2, WNT = BN / 2;   // wave tile
@@ -212,95 +309,196 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_kernel(GemmParams p) {
         __syncthreads();
     }
 
-    // ---- epilogue: lane (lg, li) holds, for pixel row m = .. + li, 8 (or 4) consecutive channels
-    const bool vec_ok = (p.N & 7) == 0;
+    gemm_epilogue<MT, NT>(p, acc, m0 + wm0, n0 + wn0, li, lg);
+}
+
+// ---------------------------------------------------------------------------------------------
+// "v2" main loop for large grids: 256 x 160 x 64 tile, 8 waves (4 x 2, same 64 x 80 wave tile), a 3-stage LDS ring
+// (3 x 52 KiB = 156 KiB, one block per CU) filled by direct-to-LDS loads (global_load_lds_dwordx4: no staging
+// registers, no ds_write pass).  Tile kt+2 is in flight while tile kt is multiplied: a load has two K-tiles of
+// MFMA work to hide behind, with ONE raw s_barrier per K-tile and a counted s_waitcnt vmcnt(N) that leaves the
+// younger tile's loads outstanding across the barrier (MI355X guide: "Pipelining across barriers").
+// The LDS image is lane-linear per wave instruction (8 rows x 128 B), so the bank swizzle is applied to the
+// SOURCE address (lane fetches chunk (lane&7) ^ swz(row)) and again on the fragment read.  Out-of-image taps /
+// rows >= M read a 16-byte zero page instead of being branched around.
+__device__ __attribute__((aligned(16))) unsigned g_zero_page[64];
+
+constexpr int V2_BM = 256, V2_BN = 160, V2_THREADS = 512, V2_STAGES = 3;
+constexpr int V2_STAGE_ELEMS = (V2_BM + V2_BN) * BK;
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+template <int MODE>   // 0 dense, 1 conv3x3 with Cin % 64 == 0
+__global__ __launch_bounds__(V2_THREADS, 2) void gemm_v2_kernel(GemmParams p) {
+    constexpr int MT = 4, NT = 5;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    bf16* ring = reinterpret_cast<bf16*>(smem);
+
+    const int tiles_n = (p.N + V2_BN - 1) / V2_BN;
+    const int tiles_m = (p.M + V2_BM - 1) / V2_BM;
+    const int nblk = tiles_n * tiles_m;
+    int bid = blockIdx.x;
+    {
+        const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int m0 = (bid / tiles_n) * V2_BM;
+    const int n0 = (bid % tiles_n) * V2_BN;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 80;
+    const int li = lane & 15, lg = lane >> 4;
+    const int lrow = lane >> 3, lslot = lane & 7;
+    const char* zero = reinterpret_cast<const char*>(g_zero_page);
+
+    // ---- loader state.  A: wave w fills rows [32w, 32w+32) with 4 instructions of 8 rows; B: 8-row groups w, w+8, w+16 (< 20)
+    const int Hs = p.ups ? (p.H >> 1) : p.H, Ws = p.ups ? (p.Wd >> 1) : p.Wd;
+    const char* abase[4];
+    int ahi[4], awi[4];
+    const char* arow[4];
+    bool aval[4];
 #pragma unroll
-    for (int mi = 0; mi < MT; mi++) {
-        const int m = m0 + wm0 + mi * 16 + li;
-        if (m >= p.M) continue;
-        const float* rv = p.rowvec ? p.rowvec + (size_t)(m / p.rows_per_batch) * p.N : nullptr;
+    for (int j = 0; j < 4; j++) {
+        const int r = wave * 32 + j * 8 + lrow;
+        const int kcs = lslot ^ ((r >> 1) & 7);          // the 16-byte chunk this lane must fetch for its LDS slot
+        const int m = m0 + r;
+        const bool ok = m < p.M;
+        if (MODE == 0) {
+            abase[j] = reinterpret_cast<const char*>(p.A) + ((size_t)(ok ? m : 0) * p.lda + kcs * 8) * 2;
+            aval[j] = ok; arow[j] = abase[j]; ahi[j] = awi[j] = 0;
+        } else {
+            const int mm = ok ? m : 0;
+            const int hw = p.Ho * p.Wo;
+            const int b = mm / hw, rem = mm - b * hw;
+            const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+            abase[j] = reinterpret_cast<const char*>(p.A) + ((size_t)b * Hs * Ws * p.lda + kcs * 8) * 2;
+            ahi[j] = ok ? ho * p.stride - 1 : -100000;
+            awi[j] = wo * p.stride - 1;
+            aval[j] = false; arow[j] = zero;
+        }
+    }
+    const char* bbase[3];
+    bool bval[3], bact[3];
 #pragma unroll
-        for (int pr = 0; pr < (NT + 1) / 2; pr++) {
-            const bool paired = (2 * pr + 1) < NT;
-            const int cnt = paired ? 8 : 4;
-            const int n = n0 + wn0 + 32 * pr + lg * cnt;
-            float v[8];
+    for (int j = 0; j < 3; j++) {
+        const int g = wave + 8 * j;
+        bact[j] = g < V2_BN / 8;                               // wave-uniform
+        const int r = g * 8 + lrow;
+        const int kcs = lslot ^ ((r >> 1) & 7);
+        const int n = n0 + r;
+        bval[j] = bact[j] && n < p.N;
+        bbase[j] = reinterpret_cast<const char*>(p.W) + ((size_t)(bval[j] ? n : 0) * p.K + kcs * 8) * 2;
+    }
+    // the k offset of this lane's chunk inside a K-tile depends on the (swizzled) chunk index of each row; for the K-tail test
+    // (dense only, K % 64 != 0) use the largest chunk index conservatively per row below.
+    const int nk = (p.K + BK - 1) / BK;
+    int cur_tap = -1;
+
+    auto issue = [&](int t, int stage) {
+        bf16* sa = ring + stage * V2_STAGE_ELEMS;
+        bf16* sb = sa + V2_BM * BK;
+        const bool live = t < nk;
+        const int k0 = t * BK;
+        int c0 = 0;
+        if (MODE == 1 && live) {
+            const int tap = k0 / p.Cin;
+            c0 = k0 - tap * p.Cin;
+            if (tap != cur_tap) {
+                cur_tap = tap;
+                const int dh = tap / 3, dw = tap - dh * 3;
 #pragma unroll
-            for (int r = 0; r < 4; r++) {
-                v[r] = acc[2 * pr][mi][r];
-                v[4 + r] = paired ? acc[(2 * pr + 1) < NT ? 2 * pr + 1 : 2 * pr][mi][r] : 0.f;
-            }
-            if (n >= p.N) continue;
-            if (vec_ok && n + cnt <= p.N) {
-                // vector path: 8 (4) consecutive channels, all in range
-                float bb[8] = {0, 0, 0, 0, 0, 0, 0, 0}, rr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-                if (p.bias) {
-                    const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.bias + n);
-                    bb[0] = b0[0]; bb[1] = b0[1]; bb[2] = b0[2]; bb[3] = b0[3];
-                    if (cnt == 8) { const f32x4 b1 = *reinterpret_cast<const f32x4*>(p.bias + n + 4); bb[4] = b1[0]; bb[5] = b1[1]; bb[6] = b1[2]; bb[7] = b1[3]; }
-                }
-                if (rv) {
-                    const f32x4 b0 = *reinterpret_cast<const f32x4*>(rv + n);
-                    bb[0] += b0[0]; bb[1] += b0[1]; bb[2] += b0[2]; bb[3] += b0[3];
-                    if (cnt == 8) { const f32x4 b1 = *reinterpret_cast<const f32x4*>(rv + n + 4); bb[4] += b1[0]; bb[5] += b1[1]; bb[6] += b1[2]; bb[7] += b1[3]; }
-                }
-                if (p.res) {
-                    const bf16* rp = p.res + (size_t)m * p.ldres + n;
-                    if (cnt == 8) { const bf16x8 t = ld8(rp);
-#pragma unroll
-                        for (int e = 0; e < 8; e++) rr[e] = bf2f(t[e]); }
-                    else { const bf16x4 t = *reinterpret_cast<const bf16x4*>(rp);
-#pragma unroll
-                        for (int e = 0; e < 4; e++) rr[e] = bf2f(t[e]); }
-                }
-#pragma unroll
-                for (int e = 0; e < 8; e++) {
-                    float x = v[e] * p.alpha + bb[e] + rr[e];
-                    if (p.flags & F_SILU) x = silu_f(x);
-                    v[e] = x;
-                }
-                if (p.flags & F_OUT_F32) {
-                    float* c = reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n;
-                    if (p.flags & F_ACCUM) {
-                        for (int e = 0; e < cnt; e++) c[e] += v[e];
-                    } else {
-                        *reinterpret_cast<f32x4*>(c) = (f32x4){v[0], v[1], v[2], v[3]};
-                        if (cnt == 8) *reinterpret_cast<f32x4*>(c + 4) = (f32x4){v[4], v[5], v[6], v[7]};
-                    }
-                } else {
-                    bf16* c = reinterpret_cast<bf16*>(p.C) + (size_t)m * p.ldc + n;
-                    if (cnt == 8) {
-                        bf16x8 o;
-#pragma unroll
-                        for (int e = 0; e < 8; e++) o[e] = f2bf(v[e]);
-                        st8(c, o);
-                    } else {
-                        bf16x4 o;
-#pragma unroll
-                        for (int e = 0; e < 4; e++) o[e] = f2bf(v[e]);
-                        *reinterpret_cast<bf16x4*>(c) = o;
-                    }
-                }
-            } else {
-                // ragged N: element-wise, guarded
-                for (int e = 0; e < cnt; e++) {
-                    const int nn = n + e;
-                    if (nn >= p.N) break;
-                    float x = v[e] * p.alpha;
-                    if (p.bias) x += p.bias[nn];
-                    if (rv) x += rv[nn];
-                    if (p.res) x += bf2f(p.res[(size_t)m * p.ldres + nn]);
-                    if (p.flags & F_SILU) x = silu_f(x);
-                    if (p.flags & F_OUT_F32) {
-                        float* c = reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + nn;
-                        *c = (p.flags & F_ACCUM) ? *c + x : x;
-                    } else {
-                        reinterpret_cast<bf16*>(p.C)[(size_t)m * p.ldc + nn] = f2bf(x);
-                    }
+                for (int j = 0; j < 4; j++) {
+                    int hi = ahi[j] + dh, wi = awi[j] + dw;
+                    aval[j] = hi >= 0 && hi < p.H && wi >= 0 && wi < p.Wd;
+                    if (p.ups) { hi >>= 1; wi >>= 1; }
+                    arow[j] = abase[j] + (size_t)(hi * Ws + wi) * p.lda * 2;
                 }
             }
         }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int r = wave * 32 + j * 8 + lrow;
+            const int kcs = lslot ^ ((r >> 1) & 7);
+            const bool kok = k0 + kcs * 8 < p.K;
+            const char* src = (live && aval[j] && kok) ? arow[j] + (size_t)(MODE == 0 ? k0 : c0) * 2 : zero;
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sa + (wave * 32 + j * 8) * BK), 16, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            if (bact[j]) {
+                const int g = wave + 8 * j;
+                const int r = g * 8 + lrow;
+                const int kcs = lslot ^ ((r >> 1) & 7);
+                const bool kok = k0 + kcs * 8 < p.K;
+                const char* src = (live && bval[j] && kok) ? bbase[j] + (size_t)k0 * 2 : zero;
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sb + g * 8 * BK), 16, 0, 0);
+            }
+        }
+    };
+
+    f32x4 acc[NT][MT];
+#pragma unroll
+    for (int i = 0; i < NT; i++)
+#pragma unroll
+        for (int j = 0; j < MT; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    int wrow[NT];
+#pragma unroll
+    for (int ni = 0; ni < NT; ni++) {
+        const bool paired = (ni | 1) < NT;
+        wrow[ni] = wn0 + (paired ? 32 * (ni >> 1) + (li >> 2) * 8 + (ni & 1) * 4 + (li & 3) : 16 * ni + li);
     }
+
+    issue(0, 0);
+    issue(1, 1);
+    int st_cur = 0, st_nxt = 2;
+    for (int kt = 0; kt < nk; kt++) {
+        // tile kt landed for THIS wave once at most the younger tile's loads are outstanding (7 per tile for waves 0-3, 6 for 4-7)
+        if (wave < 4) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        __builtin_amdgcn_s_barrier();            // everyone's part of tile kt is in LDS; everyone is done reading tile kt-1
+        asm volatile("" ::: "memory");
+        issue(kt + 2, st_nxt);                   // refill the stage tile kt-1 lived in (dummy zero loads past the end keep the count fixed)
+        const bf16* a = ring + st_cur * V2_STAGE_ELEMS;
+        const bf16* b = a + V2_BM * BK;
+#pragma unroll
+        for (int kk = 0; kk < 2; kk++) {
+            bf16x8 fa[MT], fw[NT];
+            const int ch = kk * 4 + lg;
+#pragma unroll
+            for (int mi = 0; mi < MT; mi++) {
+                const int r = wm0 + mi * 16 + li;
+                fa[mi] = *reinterpret_cast<const bf16x8*>(a + r * BK + ((ch ^ ((r >> 1) & 7)) << 3));
+            }
+#pragma unroll
+            for (int ni = 0; ni < NT; ni++) {
+                const int r = wrow[ni];
+                fw[ni] = *reinterpret_cast<const bf16x8*>(b + r * BK + ((ch ^ ((r >> 1) & 7)) << 3));
+            }
+#pragma unroll
+            for (int ni = 0; ni < NT; ni++)
+#pragma unroll
+                for (int mi = 0; mi < MT; mi++)
+                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[ni], fa[mi], acc[ni][mi], 0, 0, 0);
+        }
+        st_cur = st_cur == V2_STAGES - 1 ? 0 : st_cur + 1;
+        st_nxt = st_nxt == V2_STAGES - 1 ? 0 : st_nxt + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the trailing dummy loads before the LDS is released
+    gemm_epilogue<MT, NT>(p, acc, m0 + wm0, n0 + wn0, li, lg);
+}
+
+template <int MODE>
+static int launch_gemm_v2(const GemmParams& p, hipStream_t s) {
+    const int tiles = ((p.M + V2_BM - 1) / V2_BM) * ((p.N + V2_BN - 1) / V2_BN);
+    const size_t lds = (size_t)V2_STAGES * V2_STAGE_ELEMS * sizeof(bf16);
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_v2_kernel<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((gemm_v2_kernel<MODE>), dim3(tiles), dim3(V2_THREADS), lds, s, p);
+    return sidlsg_last_error();
 }
 
 template <int BM, int BN, int MODE>
@@ -324,6 +522,13 @@ static int dispatch_gemm(const GemmParams& p, hipStream_t s) {
     // Small pixel counts (8x8 / 16x16 stages, small batches) would give < 256 tiles = idle CUs:
     // fall back to 64-row and then 64x64 tiles until the grid covers the chip.
     if (p.N <= 64) return launch_gemm<128, 64, MODE>(p, s);
+    {   // large grids with 160-multiple N: the deeper-pipelined 256x160 direct-to-LDS kernel (SIDLSG_GEMM_V2=0 disables it)
+        static const bool v2_on = !(getenv("SIDLSG_GEMM_V2") && atoi(getenv("SIDLSG_GEMM_V2")) == 0);
+        const long long t2 = (long long)((p.M + V2_BM - 1) / V2_BM) * ((p.N + V2_BN - 1) / V2_BN);
+        static const long long v2_min = getenv("SIDLSG_GEMM_V2_MIN_TILES") ? atoll(getenv("SIDLSG_GEMM_V2_MIN_TILES")) : 512;  // tests force 1
+        // measured: v2 wins 3-8% on long-K shapes with >= 2 full waves of tiles, loses on short K / partial waves
+        if (v2_on && MODE != 2 && p.N % 160 == 0 && t2 >= v2_min && (p.K >= 640 || v2_min == 1)) return launch_gemm_v2<MODE == 2 ? 0 : MODE>(p, s);
+    }
     auto tiles = [&](int bm, int bn) { return (long long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn); };
     const bool n160 = p.N % 160 == 0;
     if (tiles(128, n160 ? 160 : 128) >= 384) return n160 ? launch_gemm<128, 160, MODE>(p, s) : launch_gemm<128, 128, MODE>(p, s);
