@@ -598,8 +598,22 @@ __global__ __launch_bounds__(NTHREADS) void wgrad_bf16_kernel(WgradParams p) {
     const int Hs = p.ups ? (p.H >> 1) : p.H, Ws = p.ups ? (p.Wd >> 1) : p.Wd;
     const int hw = (MODE == 1) ? p.Ho * p.Wo : 1;
 
+    // conv: (b, ho, wo) of each of this thread's 4 rows, advanced by WG_MB pixels per step (no per-step divisions)
+    int pb[4], pho[4], pwo[4];
+    const int d_b = WG_MB / hw, d_rem = WG_MB - d_b * hw;
+    const int d_ho = (MODE == 1) ? d_rem / p.Wo : 0, d_wo = (MODE == 1) ? d_rem - d_ho * p.Wo : 0;
+    if (MODE == 1) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int m = mbeg + r0 + 16 * i;
+            pb[i] = m / hw;
+            const int rem = m - pb[i] * hw;
+            pho[i] = rem / p.Wo;
+            pwo[i] = rem - pho[i] * p.Wo;
+        }
+    }
     bf16x8 yreg[4], xreg[4];
-    auto load_tile = [&](int mb) {
+    auto load_tile = [&](int mb) {      // called with mb = mbeg, mbeg + WG_MB, ... in order
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             const int m = mb + r0 + 16 * i;
@@ -616,13 +630,16 @@ __global__ __launch_bounds__(NTHREADS) void wgrad_bf16_kernel(WgradParams p) {
                 xreg[i] = buf_ld8(ra, (kok && mok) ? ((unsigned)m * (unsigned)p.lda + (unsigned)kA) * 2u : OOB);
             } else {
                 bool ok = kok && mok;
-                const int mm = mok ? m : 0;
-                const int b = mm / hw, rem = mm - b * hw;
-                const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+                const int b = pb[i], ho = pho[i], wo = pwo[i];
                 int hi = ho * p.stride - 1 + dh, wi = wo * p.stride - 1 + dw;
                 ok = ok && hi >= 0 && hi < p.H && wi >= 0 && wi < p.Wd;
                 if (p.ups) { hi >>= 1; wi >>= 1; }
                 xreg[i] = buf_ld8(ra, ok ? (((unsigned)(b * Hs + hi) * (unsigned)Ws + (unsigned)wi) * (unsigned)p.lda + (unsigned)cA) * 2u : OOB);
+                // advance this row by WG_MB pixels: (b, ho, wo) += (d_b, d_ho, d_wo) with single carries
+                int nwo = wo + d_wo, nho = ho + d_ho, nb = b + d_b;
+                if (nwo >= p.Wo) { nwo -= p.Wo; nho += 1; }
+                if (nho >= p.Ho) { nho -= p.Ho; nb += 1; }
+                pwo[i] = nwo; pho[i] = nho; pb[i] = nb;
             }
         }
     };
