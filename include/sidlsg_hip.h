@@ -44,6 +44,11 @@ int sidlsg_conv3x3_bf16(const void* X, int ldx, const void* W, void* Y, int ldc,
                         const float* rowvec, int B, int H, int Wd, int Cin, int Cout, int stride, int ups, float alpha,
                         int flags, void* stream);
 
+/* Optional fp32 scratch (device memory owned by the caller): per-split partial-sum slabs for split-K GEMMs/convs with few
+ * output tiles and long K (8x8 / 16x16 stages) and for the pixel-split weight gradients (without it they fall back to
+ * fp32 atomics, ~2-3x slower on MI355X).  Global per process; calls that use it must be on one stream.  NULL disables. */
+int sidlsg_set_workspace(void* ptr, long long bytes);
+
 /* weight gradients (autograd of the two ops above in the reference: loss.backward(),
  * sid_training_loop.py:450,533).  dW[N][K] += dY[M][N]^T A[M][K], fp32 atomics. */
 int sidlsg_wgrad_bf16(const void* dY, int ldy, const void* A, int lda, float* dW, int M, int N, int K, void* stream);

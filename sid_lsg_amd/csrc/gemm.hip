@@ -38,6 +38,8 @@ struct GemmParams {
     float alpha;
     int flags;
     unsigned a_bytes, w_bytes;   // sizes of the A / W allocations seen by the kernel (< 2 GiB)
+    int kt_per_split;            // split-K: K-tiles per blockIdx.y slice (0 = no split)
+    float* ws;                   // split-K: fp32 [splits][M][N] partial-sum slabs
 };
 
 enum { F_OUT_F32 = 1, F_SILU = 2, F_ACCUM = 4 };
@@ -276,12 +278,14 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_kernel(GemmParams p) {
         wrow[ni] = wn0 + (paired ? 32 * (ni >> 1) + (li >> 2) * 8 + (ni & 1) * 4 + (li & 3) : 16 * ni + li);
     }
 
-    const int nk = (p.K + BK - 1) / BK;
-    load_tile(0);
+    const int nk_all = (p.K + BK - 1) / BK;
+    const int kt_begin = p.kt_per_split ? blockIdx.y * p.kt_per_split : 0;
+    const int nk = p.kt_per_split ? min(nk_all, kt_begin + p.kt_per_split) : nk_all;
+    load_tile(kt_begin);
     store_tile(0);
     __syncthreads();
-    for (int kt = 0; kt < nk; kt++) {
-        const int buf = kt & 1;
+    for (int kt = kt_begin; kt < nk; kt++) {
+        const int buf = (kt - kt_begin) & 1;
         if (kt + 1 < nk) load_tile(kt + 1);
         const bf16* a = As + buf * BM * BK;
         const bf16* b = Bs + buf * BN * BK;
@@ -309,8 +313,59 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_kernel(GemmParams p) {
         __syncthreads();
     }
 
+    if (p.kt_per_split) {
+        // split-K: raw fp32 partial sums into the workspace; gemm_finish_kernel applies the epilogue
+#pragma unroll
+        for (int mi = 0; mi < MT; mi++) {
+            const int m = m0 + wm0 + mi * 16 + li;
+            if (m >= p.M) continue;
+#pragma unroll
+            for (int ni = 0; ni < NT; ni++) {
+                const bool paired = (ni | 1) < NT;
+                const int nb = n0 + wn0 + (paired ? 32 * (ni >> 1) + lg * 8 + (ni & 1) * 4 : 16 * ni + lg * 4);
+                float* dst = p.ws + ((size_t)blockIdx.y * p.M + m) * p.N + nb;     // this split's slab: plain 16-byte stores
+                if (nb + 4 <= p.N) *reinterpret_cast<f32x4*>(dst) = acc[ni][mi];
+                else
+                    for (int r = 0; r < 4; r++)
+                        if (nb + r < p.N) dst[r] = acc[ni][mi][r];
+            }
+        }
+        return;
+    }
     gemm_epilogue<MT, NT>(p, acc, m0 + wm0, n0 + wn0, li, lg);
 }
+
+// epilogue of a split-K GEMM: C = act(alpha * sum_s slab_s + bias + rowvec + res)
+__global__ void gemm_finish_kernel(GemmParams p) {
+    if (blockIdx.y != 0) return;
+    const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i >= (size_t)p.M * p.N) return;
+    const int m = (int)(i / p.N), n = (int)(i - (size_t)m * p.N);      // N % 4 == 0 on this path
+    f32x4 v = *reinterpret_cast<const f32x4*>(p.ws + i);
+    const int nsp = (int)gridDim.y;                       // number of K splits (slabs)
+    for (int sidx = 1; sidx < nsp; sidx++) v += *reinterpret_cast<const f32x4*>(p.ws + (size_t)sidx * p.M * p.N + i);
+    const float* rv = p.rowvec ? p.rowvec + (size_t)(m / p.rows_per_batch) * p.N : nullptr;
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+        float x = v[e] * p.alpha;
+        if (p.bias) x += p.bias[n + e];
+        if (rv) x += rv[n + e];
+        if (p.res) x += bf2f(p.res[(size_t)m * p.ldres + n + e]);
+        if (p.flags & F_SILU) x = silu_f(x);
+        v[e] = x;
+    }
+    if (p.flags & F_OUT_F32) {
+        float* c = reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n;
+        if (p.flags & F_ACCUM) { for (int e = 0; e < 4; e++) c[e] += v[e]; }
+        else *reinterpret_cast<f32x4*>(c) = v;
+    } else {
+        bf16x4 o = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
+        *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16*>(p.C) + (size_t)m * p.ldc + n) = o;
+    }
+}
+
+static float* g_ws = nullptr;          // set by sidlsg_set_workspace (host-allocated device memory, zero-initialised)
+static long long g_ws_bytes = 0;
 
 // ---------------------------------------------------------------------------------------------
 // "v2" main loop for large grids: 256 x 160 x 64 tile, 8 waves (4 x 2, same 64 x 80 wave tile), a 3-stage LDS ring
@@ -511,7 +566,13 @@ static int launch_gemm(const GemmParams& p, hipStream_t s) {
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done = true;
     }
-    hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, MODE>), dim3(tiles), dim3(NTHREADS), lds, s, p);
+    const int nk = (p.K + BK - 1) / BK;
+    const int splits = p.kt_per_split ? (nk + p.kt_per_split - 1) / p.kt_per_split : 1;
+    hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, MODE>), dim3(tiles, splits), dim3(NTHREADS), lds, s, p);
+    if (p.kt_per_split) {
+        const size_t n4 = ((size_t)p.M * p.N + 3) / 4;
+        hipLaunchKernelGGL(gemm_finish_kernel, dim3((unsigned)((n4 + 255) / 256), splits), dim3(256), 0, s, p);   // grid.y only carries the split count
+    }
     return sidlsg_last_error();
 }
 
@@ -531,6 +592,23 @@ static int dispatch_gemm(const GemmParams& p, hipStream_t s) {
     }
     auto tiles = [&](int bm, int bn) { return (long long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn); };
     const bool n160 = p.N % 160 == 0;
+    {   // few output tiles but a long contraction (8x8 / 16x16 stages): split K over blockIdx.y with the big tile
+        const long long t = tiles(128, n160 ? 160 : 128);
+        const int nk = (p.K + BK - 1) / BK;
+        if (t < 256 && nk >= 32 && (p.N & 3) == 0 && g_ws && (long long)p.M * p.N * 8 <= g_ws_bytes) {
+            int splits = (int)((512 + t - 1) / t);
+            const long long cap = g_ws_bytes / ((long long)p.M * p.N * 4);
+            if (splits > cap) splits = (int)cap;
+            if (splits > nk / 8) splits = nk / 8;
+            if (splits > 16) splits = 16;
+            if (splits >= 2) {
+                GemmParams q = p;
+                q.kt_per_split = (nk + splits - 1) / splits;
+                q.ws = g_ws;
+                return n160 ? launch_gemm<128, 160, MODE>(q, s) : launch_gemm<128, 128, MODE>(q, s);
+            }
+        }
+    }
     if (tiles(128, n160 ? 160 : 128) >= 384) return n160 ? launch_gemm<128, 160, MODE>(p, s) : launch_gemm<128, 128, MODE>(p, s);
     if (tiles(64, n160 ? 160 : 128) >= 384) return n160 ? launch_gemm<64, 160, MODE>(p, s) : launch_gemm<64, 128, MODE>(p, s);
     return launch_gemm<64, 64, MODE>(p, s);
@@ -566,6 +644,8 @@ struct WgradParams {
     int H, Wd, Cin, Ho, Wo, stride, ups;
     int m_per_split;
     unsigned a_bytes, y_bytes;
+    float* ws;        // [splits][N][K] slabs when splits > 1 and a workspace is available (else fp32 atomics)
+    int nsplits;
 };
 
 DEVFN int wg_swz(int row) { return (row & 3) | (((row >> 3) & 1) << 2); }
@@ -708,10 +788,31 @@ __global__ __launch_bounds__(NTHREADS) void wgrad_bf16_kernel(WgradParams p) {
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 const int n = n0 + wn0 + 16 * i + lg * 4 + r;
-                if (n < p.N) unsafeAtomicAdd(p.dW + (size_t)n * p.K + k, acc[i][j][r]);
+                if (n >= p.N) continue;
+                const size_t e = (size_t)n * p.K + k;
+                if (p.nsplits == 1) p.dW[e] += acc[i][j][r];                                  // sole owner of this element
+                else if (p.ws) p.ws[(size_t)blockIdx.y * p.N * p.K + e] = acc[i][j][r];      // slab, reduced by wgrad_reduce_kernel
+                else unsafeAtomicAdd(p.dW + e, acc[i][j][r]);
             }
         }
 }
+
+// dW[i] += sum_s slab[s][i]
+__global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dW, size_t n, int splits) {
+    const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i + 4 <= n) {
+        f32x4 v = *reinterpret_cast<const f32x4*>(dW + i);
+        for (int sidx = 0; sidx < splits; sidx++) v += *reinterpret_cast<const f32x4*>(ws + (size_t)sidx * n + i);
+        *reinterpret_cast<f32x4*>(dW + i) = v;
+    } else {
+        for (size_t j = i; j < n; j++) {
+            float v = dW[j];
+            for (int sidx = 0; sidx < splits; sidx++) v += ws[(size_t)sidx * n + j];
+            dW[j] = v;
+        }
+    }
+}
+
 
 template <int MODE>
 static int launch_wgrad(WgradParams p, hipStream_t s) {
@@ -724,14 +825,39 @@ static int launch_wgrad(WgradParams p, hipStream_t s) {
     int mps = (p.M + splits - 1) / splits;
     mps = (mps + WG_MB - 1) / WG_MB * WG_MB;
     splits = (p.M + mps - 1) / mps;
+    const long long nk = (long long)p.N * p.K;
+    if (splits > 1 && g_ws) {                       // cap the split count by the slab space
+        const long long cap = g_ws_bytes / (nk * 4);
+        if (cap < 2) { p.ws = nullptr; }
+        else {
+            if (splits > cap) {
+                splits = (int)cap;
+                mps = (p.M + splits - 1) / splits;
+                mps = (mps + WG_MB - 1) / WG_MB * WG_MB;
+                splits = (p.M + mps - 1) / mps;
+            }
+            p.ws = g_ws;
+        }
+    }
     p.m_per_split = mps;
+    p.nsplits = splits;
     hipLaunchKernelGGL((wgrad_bf16_kernel<MODE>), dim3(tiles, splits), dim3(NTHREADS), 0, s, p);
+    if (splits > 1 && p.ws)
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((nk / 4 + 256) / 256)), dim3(256), 0, s, p.ws, p.dW, (size_t)nk, splits);
     return sidlsg_last_error();
 }
 
 static bool fits31(unsigned long long bytes) { return bytes < 0x7FFFFFFFull; }
 
 extern "C" {
+
+// Optional scratch for split-K GEMMs and weight gradients: `ptr` = device memory of `bytes` bytes, owned by the
+// caller, used by every later sidlsg_gemm_bf16 / sidlsg_conv3x3_bf16 call of this process (one stream at a time).
+// Pass NULL/0 to disable split-K.
+int sidlsg_set_workspace(void* ptr, long long bytes) {
+    g_ws = (float*)ptr; g_ws_bytes = ptr ? bytes : 0;
+    return SIDLSG_OK;
+}
 
 // Dense GEMM: C[M,N] = act(alpha * A[M,K] W[N,K]^T + bias[N] + rowvec[m/rpb,N] + res[M,N])
 int sidlsg_gemm_bf16(const void* A, int lda, const void* W, void* C, int ldc, const float* bias, const void* res,

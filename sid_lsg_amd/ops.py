@@ -41,6 +41,19 @@ def _wants_grad(p):
 
 
 # ------------------------------------------------------------------------------------------------
+_workspace = {}
+
+
+def ensure_workspace(device, nbytes=512 << 20):
+    """fp32 split-K scratch for the small-pixel-count convs/GEMMs (allocated once per device through torch's allocator)."""
+    key = torch.device(device).index or 0
+    if key not in _workspace:
+        ws = torch.empty(nbytes // 4, device=device, dtype=F32)
+        lib.sidlsg_set_workspace(ws.data_ptr(), ws.numel() * 4)
+        _workspace[key] = ws
+    return _workspace[key]
+
+
 # raw launches
 def gemm(a, w16, out=None, bias=None, res=None, rowvec=None, rows_per_batch=1, alpha=1.0, out_f32=False, lda=None):
     """C[M,N] = alpha*A[M,K] W[N,K]^T + bias + rowvec[m//rpb] + res"""
@@ -48,6 +61,7 @@ def gemm(a, w16, out=None, bias=None, res=None, rowvec=None, rows_per_batch=1, a
     K = w16.shape[1]
     N = w16.shape[0]
     lda = a.stride(0) if lda is None else lda
+    ensure_workspace(a.device)
     if out is None:
         out = torch.empty((M, N), device=a.device, dtype=F32 if out_f32 else BF16)
     lib.sidlsg_gemm_bf16(_p(a), lda, _p(w16), _p(out), out.stride(0), _p(bias), _p(res), res.stride(0) if res is not None else 0,
@@ -61,6 +75,7 @@ def conv3x3(x, w16, bias=None, res=None, rowvec=None, stride=1, ups=0, out_f32=F
     H, W = (2 * Hs, 2 * Ws) if ups else (Hs, Ws)
     Cout = w16.shape[0]
     Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    ensure_workspace(x.device)
     out = torch.empty((B, Ho, Wo, Cout), device=x.device, dtype=F32 if out_f32 else BF16)
     lib.sidlsg_conv3x3_bf16(_p(x), Cin, _p(w16), _p(out), Cout, _p(bias), _p(res), Cout if res is not None else 0, _p(rowvec),
                             B, H, W, Cin, Cout, stride, ups, 1.0, 1 if out_f32 else 0, _s())

@@ -41,7 +41,8 @@ def close(got, ref, tol, name=''):
 
 
 # ----------------------------------------------------------------------------------------------
-@pytest.mark.parametrize('M,N,K', [(256, 320, 320), (1000, 136, 72), (4096, 960, 320), (77 * 2, 640, 768), (130, 8, 2880), (64, 2560, 320)])
+@pytest.mark.parametrize('M,N,K', [(256, 320, 320), (1000, 136, 72), (4096, 960, 320), (77 * 2, 640, 768), (130, 8, 2880), (64, 2560, 320),
+                                   (1000, 1280, 2560), (300, 136, 4096)])   # last two: split-K path (few tiles, long K)
 def test_gemm(dev, M, N, K):
     from sid_lsg_amd import ops
     a, w = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5)
@@ -58,7 +59,8 @@ def test_gemm(dev, M, N, K):
 
 
 CONV_CASES = [(2, 16, 16, 64, 160, 1, 0), (2, 16, 16, 64, 128, 2, 0), (1, 8, 8, 128, 64, 1, 1), (2, 12, 20, 8, 320, 1, 0),
-              (2, 8, 8, 320, 8, 1, 0), (1, 64, 64, 320, 320, 1, 0), (3, 9, 7, 72, 40, 2, 0)]
+              (2, 8, 8, 320, 8, 1, 0), (1, 64, 64, 320, 320, 1, 0), (3, 9, 7, 72, 40, 2, 0),
+              (2, 8, 8, 1280, 320, 1, 0), (1, 16, 16, 640, 160, 1, 1)]      # last two: split-K conv (8x8 / 16x16 stages)
 
 
 def conv_ref(x, w, stride, ups):
