@@ -213,9 +213,13 @@ def main():
     if timer is not None:
         r = timer.result()
         ach = r['flops'] / (r['ms'] * 1e-3) / 1e12 if r['ms'] > 0 else 0.0
-        out['roofline'] = {'bound': 'mfma', 'kernel': 'gemm_bf16_kernel<128,*,1> (implicit-GEMM conv3x3 fwd + dgrad)',
+        traffic = None   # HBM-side bytes per launch from the committed PMC summary (separate rocprofv3 --pmc passes, gfx950-corrected)
+        pmc = os.path.join(ROOT, 'profiles', 'r01_conv_pmc.json')
+        if os.path.isfile(pmc):
+            traffic = json.load(open(pmc)).get('avg_hbm_side_bytes_per_launch')
+        out['roofline'] = {'bound': 'mfma', 'kernel': 'implicit-GEMM conv3x3 fwd + dgrad (gemm_bf16_kernel<*,*,1|2>, gemm_v2_kernel<1>)',
                            'achieved': ach, 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / PEAK_BF16_TFLOPS,
-                           'traffic': None, 'launches': r['launches'], 'avg_launch_ms': r['ms'] / max(r['launches'], 1),
+                           'traffic': traffic, 'launches': r['launches'], 'avg_launch_ms': r['ms'] / max(r['launches'], 1),
                            'algorithmic_tflop_per_launch': r['flops'] / max(r['launches'], 1) / 1e12}
     if not args.no_cpu_baseline and world == 1:
         # torch's CPU backend degrades badly when oversubscribed on many-core hosts (256 threads: 160 s per forward);
