@@ -33,7 +33,17 @@ __global__ void gn_stats_kernel(const bf16* __restrict__ x, float* __restrict__ 
 #pragma unroll
     for (int e = 0; e < 8; e++) s[e] = q[e] = 0.f;
     const bf16* xb = x + (size_t)b * g.HW * g.C + cc * 8;
-    for (int p = p0 + rl; p < p1; p += g.rows) {
+    int p = p0 + rl;
+    for (; p + 3 * g.rows < p1; p += 4 * g.rows) {        // 4 independent 16-byte loads in flight per thread
+        bf16x8 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) v[u] = ld8(xb + (size_t)(p + u * g.rows) * g.C);
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+#pragma unroll
+            for (int e = 0; e < 8; e++) { const float f = bf2f(v[u][e]); s[e] += f; q[e] += f * f; }
+    }
+    for (; p < p1; p += g.rows) {
         const bf16x8 v = ld8(xb + (size_t)p * g.C);
 #pragma unroll
         for (int e = 0; e < 8; e++) { const float f = bf2f(v[e]); s[e] += f; q[e] += f * f; }
@@ -83,7 +93,24 @@ __global__ void gn_apply_kernel(const bf16* __restrict__ x, const float* __restr
     }
     const int p0 = chunk * g.ppb, p1 = min(g.HW, p0 + g.ppb);
     const size_t base = (size_t)b * g.HW * g.C + cc * 8;
-    for (int p = p0 + rl; p < p1; p += g.rows) {
+    int p = p0 + rl;
+    for (; p + 3 * g.rows < p1; p += 4 * g.rows) {
+        bf16x8 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) v[u] = ld8(x + base + (size_t)(p + u * g.rows) * g.C);
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            bf16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                float f = bf2f(v[u][e]) * sc[e] + sh[e];
+                if (act) f = silu_f(f);
+                o[e] = f2bf(f);
+            }
+            st8(y + base + (size_t)(p + u * g.rows) * g.C, o);
+        }
+    }
+    for (; p < p1; p += g.rows) {
         const bf16x8 v = ld8(x + base + (size_t)p * g.C);
         bf16x8 o;
 #pragma unroll
@@ -111,7 +138,22 @@ __global__ void gn_bwd_stats_kernel(const bf16* __restrict__ x, const bf16* __re
     }
     const int p0 = chunk * g.ppb, p1 = min(g.HW, p0 + g.ppb);
     const size_t base = (size_t)b * g.HW * g.C + cc * 8;
-    for (int p = p0 + rl; p < p1; p += g.rows) {
+    int p = p0 + rl;
+    for (; p + g.rows < p1; p += 2 * g.rows) {            // 4 independent loads (2 pixels x {x, dy}) in flight
+        bf16x8 xv[2], dv[2];
+#pragma unroll
+        for (int u = 0; u < 2; u++) { xv[u] = ld8(x + base + (size_t)(p + u * g.rows) * g.C); dv[u] = ld8(dy + base + (size_t)(p + u * g.rows) * g.C); }
+#pragma unroll
+        for (int u = 0; u < 2; u++)
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                const float xh = (bf2f(xv[u][e]) - mu[e]) * rs[e];
+                float d = bf2f(dv[u][e]);
+                if (act) d *= silu_grad_f(xh * ga[e] + be[e]);
+                a[e] += d * xh; c[e] += d;
+            }
+    }
+    for (; p < p1; p += g.rows) {
         const bf16x8 xv = ld8(x + base + (size_t)p * g.C), dv = ld8(dy + base + (size_t)p * g.C);
 #pragma unroll
         for (int e = 0; e < 8; e++) {
@@ -169,7 +211,25 @@ __global__ void gn_bwd_apply_kernel(const bf16* __restrict__ x, const bf16* __re
     }
     const int p0 = chunk * g.ppb, p1 = min(g.HW, p0 + g.ppb);
     const size_t base = (size_t)b * g.HW * g.C + cc * 8;
-    for (int p = p0 + rl; p < p1; p += g.rows) {
+    int p = p0 + rl;
+    for (; p + g.rows < p1; p += 2 * g.rows) {
+        bf16x8 xv[2], dv[2];
+#pragma unroll
+        for (int u = 0; u < 2; u++) { xv[u] = ld8(x + base + (size_t)(p + u * g.rows) * g.C); dv[u] = ld8(dy + base + (size_t)(p + u * g.rows) * g.C); }
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            bf16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                const float xh = (bf2f(xv[u][e]) - mu[e]) * rs[e];
+                float d = bf2f(dv[u][e]);
+                if (act) d *= silu_grad_f(xh * ga[e] + be[e]);
+                o[e] = f2bf(rs[e] * (d * ga[e] - m1[e] - xh * m2[e]));
+            }
+            st8(dx + base + (size_t)(p + u * g.rows) * g.C, o);
+        }
+    }
+    for (; p < p1; p += g.rows) {
         const bf16x8 xv = ld8(x + base + (size_t)p * g.C), dv = ld8(dy + base + (size_t)p * g.C);
         bf16x8 o;
 #pragma unroll

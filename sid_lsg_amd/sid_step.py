@@ -49,49 +49,69 @@ class SiDStep:
         loss.backward()                                                             # :449-450
         return loss.detach()
 
-    def fake_update(self, rounds):
+    def fake_backward(self, rounds):
+        """Forward/backward of phase A over all accumulation rounds; leaves the gradients in psi.flat_grads."""
         self.G.requires_grad_(False)
         self.psi.requires_grad_(True)                                               # :389
         loss = None
         for r in rounds:
             loss = self.fake_round(r)
         self.psi.requires_grad_(False)                                              # :455
+        return loss
+
+    def fake_update(self, rounds):
+        loss = self.fake_backward(rounds)
         self._optimizer_step(self.psi, self.opt_fake, ema_beta=None)                # :458-462
         return loss
 
     # ---- phase B: generator --------------------------------------------------------------------
-    def generator_round(self, r):
+    def generator_round(self, r, before_fake_eval=None):
         images = hip_generate(self.G, r['z'], r['cond'], self._init_t(len(r['z']), r['z'].device), self.sched)  # :488-491
         guided = (self.k2 != 1) or (self.k4 != 1)
         prep = hip_prepare_denoise(images, r['noise'], r['t'], r['cond'], r.get('uncond'), self.sched, guided)
         k2 = self.k2 if guided else 1.0
         k4 = self.k4 if guided else 1.0
-        y_fake = hip_denoise(self.psi, prep, k2, predict_x0=True)                   # :496-499
+        # teacher first: neither G's forward nor phi's reads psi, so a pending psi gradient exchange / optimizer step
+        # (before_fake_eval) overlaps with them.  y_real and y_fake are independent: the order does not change the math.
         y_real = hip_denoise(self.phi, prep, k4, predict_x0=True)                   # :503-506
+        if before_fake_eval is not None:
+            before_fake_eval()
+        y_fake = hip_denoise(self.psi, prep, k2, predict_x0=True)                   # :496-499
         loss = ops.sid_generator_loss(images, y_real, y_fake, self.alpha, self.lsg / self.bgt)   # :508-530
         loss.backward()                                                             # :532-533
         return loss.detach()
 
-    def generator_update(self, rounds, ema_beta=None):
+    def generator_update(self, rounds, ema_beta=None, before_fake_eval=None):
         self.G.requires_grad_(True)                                                 # :468
         self.psi.requires_grad_(False)
         loss = None
-        for r in rounds:
-            loss = self.generator_round(r)
+        for i, r in enumerate(rounds):
+            loss = self.generator_round(r, before_fake_eval if i == 0 else None)
         self.G.requires_grad_(False)                                                # :538
         self._optimizer_step(self.G, self.opt_G, ema_beta=ema_beta)                 # :541-565
         return loss
 
     # ---- optimizer + data-parallel exchange ------------------------------------------------------
-    def _optimizer_step(self, net, opt, ema_beta):
+    def _optimizer_step(self, net, opt, ema_beta, started=False):
         if self.reducer is not None and self.world > 1:
-            self.reducer.start(net.flat_grads)      # few large all-reduce(SUM) on the comm stream
+            if not started:
+                self.reducer.start(net.flat_grads)  # few large all-reduce(SUM) on the comm stream
             self.reducer.wait()
         opt.step(ema_beta=ema_beta)                 # nan_to_num, /world, Adam, EMA, bf16 copy, zero_grad: one kernel
         net.refresh_compute_weights(cast=False)     # backward-data operands (transposed bf16 weights)
 
     def iteration(self, inputs, ema_beta=None):
-        """inputs: dict(A=[rounds], B=[rounds]).  Returns (loss_fake, loss_G) as device scalars."""
-        lf = self.fake_update(inputs['A'])
-        lg = self.generator_update(inputs['B'], ema_beta=ema_beta)
+        """inputs: dict(A=[rounds], B=[rounds]).  Returns (loss_fake, loss_G) as device scalars.
+
+        Same result as fake_update(); generator_update(), but the psi gradient all-reduce + optimizer step are issued
+        after phase A's backward and only WAITED for right before psi is evaluated in phase B, i.e. they overlap with
+        the generator forward and the teacher forward of the first phase-B round."""
+        lf = self.fake_backward(inputs['A'])
+        overlap = self.reducer is not None and self.world > 1
+        if overlap:
+            self.reducer.start(self.psi.flat_grads)
+
+        def finish_fake():
+            self._optimizer_step(self.psi, self.opt_fake, ema_beta=None, started=overlap)
+        lg = self.generator_update(inputs['B'], ema_beta=ema_beta, before_fake_eval=finish_fake)
         return lf, lg

@@ -138,8 +138,8 @@ def training_loop(
         torch.distributed.barrier()
     dist.print0('Start Running')
     while True:
+        # RNG order of the reference: all phase-A draws, then all phase-B draws (the compute in between consumes no RNG)
         inputs = dict(A=[make_round(use_dropout) for _ in range(rounds)])
-        loss_f = step.fake_update(inputs['A'])
         inputs['B'] = [make_round(False) for _ in range(rounds)]
         ema_beta = None
         if ema_halflife_kimg > 0:
@@ -147,7 +147,7 @@ def training_loop(
             if ema_rampup_ratio is not None:
                 half = min(half, cur_nimg * ema_rampup_ratio)
             ema_beta = 0.5 ** (batch_size / max(half, 1e-8))
-        loss_g = step.generator_update(inputs['B'], ema_beta=ema_beta)
+        loss_f, loss_g = step.iteration(inputs, ema_beta=ema_beta)
         loss_f, loss_g = float(loss_f), float(loss_g)
         stats.report('fake_score_Loss/loss', loss_f); stats.report('G_Loss/loss', loss_g)
         if on_iteration is not None:

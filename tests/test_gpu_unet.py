@@ -183,3 +183,37 @@ def test_sid_iteration_matches_oracle(dev, kappa, alpha):
         if n in ('conv_in.weight', 'conv_out.bias', 'mid_block.attentions.0.proj_in.weight'):
             e, _ = rel_err(p, ema_r[n])
             assert e < 1e-3, f'EMA weights {n}'
+
+
+def test_training_loop_end_to_end(dev, tmp_path):
+    """The reference-shaped entry point `training_loop(**c)` (sid_training_loop.py:148-194 keyword surface) on a tiny net:
+    prompt dataset by class name, optimizers by class name, 2 accumulation rounds, EMA, stats jsonl, state dump + resume."""
+    import json
+    from sid_lsg_amd.dnnlib_util import EasyDict
+    from sid_lsg_amd.training_loop import training_loop
+    pdir = tmp_path / 'prompts'
+    pdir.mkdir()
+    (pdir / 'aesthetics_6_plus.txt').write_text('\n'.join(f'a photo of object number {i}' for i in range(40)) + '\n')
+    run = tmp_path / 'run'
+    run.mkdir()
+    losses = []
+    kw = dict(run_dir=str(run), network_kwargs=EasyDict(use_fp16=False),
+              dataset_prompt_text_kwargs=EasyDict(class_name='sid_lsg_amd.data.PromptDataset', path=str(pdir), resolution=64, prompt_only=True),
+              fake_score_optimizer_kwargs=EasyDict(class_name='torch.optim.Adam', lr=1e-5, betas=[0.0, 0.999], eps=1e-8),
+              g_optimizer_kwargs=EasyDict(class_name='sid_lsg_amd.optim.FusedAdamEMA', lr=1e-5, betas=[0.0, 0.999], eps=1e-8),
+              seed=1, batch_size=4, batch_gpu=2, total_kimg=0.012, ema_halflife_kimg=50, kimg_per_tick=1, snapshot_ticks=None,
+              state_dump_ticks=1, alpha=1.0, tmax=980, tmin=20, device=dev, metrics=None, init_timestep=625,
+              pretrained_model_name_or_path='random:tiny', cfg_train_fake=1.5, cfg_eval_fake=1.5, cfg_eval_real=1.5, resolution=64,
+              on_iteration=lambda it, lf, lg: losses.append((lf, lg)))
+    out = training_loop(**kw)
+    assert len(losses) == 3 and all(np.isfinite(v) for pair in losses for v in pair)
+    rows = [json.loads(l) for l in open(run / 'stats_1.000000.jsonl')]
+    assert 'Timing/sec_per_kimg' in rows[-1] and 'G_Loss/loss' in rows[-1]
+    state = run / 'training-state-000000.pt'
+    assert state.exists()
+    # G moved away from the EMA copy; the EMA lags behind G
+    g, e = out['G'].flat_params, out['G_ema'].flat_params
+    assert float((g - e).abs().max()) > 0
+    # resume from the dumped state runs
+    kw.update(resume_training=str(state), total_kimg=0.004)
+    training_loop(**kw)
