@@ -149,8 +149,8 @@ DEVFN void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[NT][MT], int mbase, i
 }
 
 
-template <int BM, int BN, int MODE>
-__global__ __launch_bounds__(NTHREADS) void gemm_bf16_kernel(GemmParams p) {
+template <int BM, int BN, int MODE, int VAR = 0>
+__global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_kernel(GemmParams p) {   // 2 blocks/CU: <= 256 registers
     constexpr int WMT = BM / 2, WNT = BN / 2;   // wave tile
     constexpr int MT = WMT / 16, NT = WNT / 16;
     constexpr int AR = BM / 32, BR = BN / 32;   // 16B chunks per thread per tile
@@ -245,8 +245,10 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_kernel(GemmParams p) {
                 areg[i] = buf_ld8(ra, ok ? abase[i] - kc * 16u + ((unsigned)(hi * Ws + wi) * (unsigned)p.lda + (unsigned)c) * 2u : OOB);
             }
         }
+        if (!(VAR & 128)) {
 #pragma unroll
-        for (int i = 0; i < BR; i++) breg[i] = buf_ld8(rw, kok ? bbase[i] + (unsigned)k0 * 2u : OOB);
+            for (int i = 0; i < BR; i++) breg[i] = buf_ld8(rw, kok ? bbase[i] + (unsigned)k0 * 2u : OOB);
+        }
     };
     auto store_tile = [&](int buf) {
         bf16* a = As + buf * BM * BK;
@@ -256,10 +258,12 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_kernel(GemmParams p) {
             const int r = r0 + 32 * i;
             st8(a + r * BK + ((kc ^ ((r >> 1) & 7)) << 3), areg[i]);
         }
+        if (!(VAR & 128)) {
 #pragma unroll
-        for (int i = 0; i < BR; i++) {
-            const int r = r0 + 32 * i;
-            st8(b + r * BK + ((kc ^ ((r >> 1) & 7)) << 3), breg[i]);
+            for (int i = 0; i < BR; i++) {
+                const int r = r0 + 32 * i;
+                st8(b + r * BK + ((kc ^ ((r >> 1) & 7)) << 3), breg[i]);
+            }
         }
     };
 
@@ -281,36 +285,75 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_kernel(GemmParams p) {
     const int nk_all = (p.K + BK - 1) / BK;
     const int kt_begin = p.kt_per_split ? blockIdx.y * p.kt_per_split : 0;
     const int nk = p.kt_per_split ? min(nk_all, kt_begin + p.kt_per_split) : nk_all;
-    load_tile(kt_begin);
-    store_tile(0);
-    __syncthreads();
-    for (int kt = kt_begin; kt < nk; kt++) {
-        const int buf = (kt - kt_begin) & 1;
-        if (kt + 1 < nk) load_tile(kt + 1);
+
+    // VAR & 128: weight fragments bypass LDS (buffer loads in MFMA fragment layout, served by L2): LDS carries only the A tile
+    unsigned woff[NT];
+#pragma unroll
+    for (int ni = 0; ni < NT; ni++) {
+        const int n = n0 + wrow[ni];
+        woff[ni] = n < p.N ? (unsigned)n * (unsigned)p.K * 2u : OOB;
+    }
+    auto read_frags = [&](int kt, int buf, int kk, bf16x8 (&fa)[MT], bf16x8 (&fw)[NT]) {
         const bf16* a = As + buf * BM * BK;
         const bf16* b = Bs + buf * BN * BK;
+        const int ch = kk * 4 + lg;
+        if (VAR & 128) {
+            const int k = kt * BK + ch * 8;
+            const unsigned ko = k < p.K ? (unsigned)k * 2u : OOB;
 #pragma unroll
-        for (int kk = 0; kk < 2; kk++) {
-            bf16x8 fa[MT], fw[NT];
-            const int ch = kk * 4 + lg;
+            for (int ni = 0; ni < NT; ni++) fw[ni] = buf_ld8(rw, woff[ni] + ko);
+        }
 #pragma unroll
-            for (int mi = 0; mi < MT; mi++) {
-                const int r = wm0 + mi * 16 + li;
-                fa[mi] = *reinterpret_cast<const bf16x8*>(a + r * BK + ((ch ^ ((r >> 1) & 7)) << 3));
-            }
+        for (int mi = 0; mi < MT; mi++) {
+            const int r = wm0 + mi * 16 + li;
+            fa[mi] = *reinterpret_cast<const bf16x8*>(a + r * BK + ((ch ^ ((r >> 1) & 7)) << 3));
+        }
+        if (!(VAR & 128)) {
 #pragma unroll
             for (int ni = 0; ni < NT; ni++) {
                 const int r = wrow[ni];
                 fw[ni] = *reinterpret_cast<const bf16x8*>(b + r * BK + ((ch ^ ((r >> 1) & 7)) << 3));
             }
-#pragma unroll
-            for (int ni = 0; ni < NT; ni++)
-#pragma unroll
-                for (int mi = 0; mi < MT; mi++)
-                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[ni], fa[mi], acc[ni][mi], 0, 0, 0);
         }
-        if (kt + 1 < nk) store_tile(buf ^ 1);
-        __syncthreads();
+    };
+    auto mfma_block = [&](const bf16x8 (&fa)[MT], const bf16x8 (&fw)[NT]) {
+#pragma unroll
+        for (int ni = 0; ni < NT; ni++)
+#pragma unroll
+            for (int mi = 0; mi < MT; mi++)
+                acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[ni], fa[mi], acc[ni][mi], 0, 0, 0);
+    };
+
+    // Software pipeline (one barrier per K-tile, no exposed LDS latency):
+    //   A: issue the kk=1 fragment reads of the current LDS buffer, run the kk=0 MFMAs on the fragments prefetched earlier
+    //   B: commit the staged next tile (global -> registers, in flight since the previous D) to the other LDS buffer
+    //   C: barrier   (the current buffer is now fully in registers, the next one fully written)
+    //   D: issue the kk=0 fragment reads of the NEXT buffer and the global loads of the tile after it
+    //   E: run the kk=1 MFMAs, which cover the latencies of D
+    bf16x8 fa0[MT], fw0[NT], fa1[MT], fw1[NT];
+    load_tile(kt_begin);
+    store_tile(0);
+    __syncthreads();
+    read_frags(kt_begin, 0, 0, fa0, fw0);
+    if (kt_begin + 1 < nk) load_tile(kt_begin + 1);
+    for (int kt = kt_begin; kt < nk; kt++) {
+        const int buf = (kt - kt_begin) & 1;
+        const bool more = kt + 1 < nk;
+        read_frags(kt, buf, 1, fa1, fw1);          // A
+        if (!(VAR & 32)) mfma_block(fa0, fw0);
+        if (more && !(VAR & 16)) store_tile(buf ^ 1);         // B
+        __syncthreads();                       // C
+        if (more) {                            // D
+            read_frags(kt + 1, buf ^ 1, 0, fa0, fw0);
+            if (kt + 2 < nk && !(VAR & 64)) load_tile(kt + 2);
+        }
+        if (!(VAR & 32)) mfma_block(fa1, fw1);                  // E
+        if (VAR & 32) {   // ablation: keep the fragment reads alive without MFMAs
+#pragma unroll
+            for (int mi = 0; mi < MT; mi++) { asm volatile("" :: "v"(fa0[mi]), "v"(fa1[mi])); }
+#pragma unroll
+            for (int ni = 0; ni < NT; ni++) { asm volatile("" :: "v"(fw0[ni]), "v"(fw1[ni])); }
+        }
     }
 
     if (p.kt_per_split) {
@@ -384,7 +427,7 @@ constexpr int V2_STAGE_ELEMS = (V2_BM + V2_BN) * BK;
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-template <int MODE>   // 0 dense, 1 conv3x3 with Cin % 64 == 0
+template <int MODE, int VAR = 0>   // 0 dense, 1 conv3x3 with Cin % 64 == 0
 __global__ __launch_bounds__(V2_THREADS, 2) void gemm_v2_kernel(GemmParams p) {
     constexpr int MT = 4, NT = 5;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -509,11 +552,12 @@ __global__ __launch_bounds__(V2_THREADS, 2) void gemm_v2_kernel(GemmParams p) {
     int st_cur = 0, st_nxt = 2;
     for (int kt = 0; kt < nk; kt++) {
         // tile kt landed for THIS wave once at most the younger tile's loads are outstanding (7 per tile for waves 0-3, 6 for 4-7)
-        if (wave < 4) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+        if (VAR & 64) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (wave < 4) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         __builtin_amdgcn_s_barrier();            // everyone's part of tile kt is in LDS; everyone is done reading tile kt-1
         asm volatile("" ::: "memory");
-        issue(kt + 2, st_nxt);                   // refill the stage tile kt-1 lived in (dummy zero loads past the end keep the count fixed)
+        if (!(VAR & 64) || kt == 0) issue(kt + 2, st_nxt);   // refill the stage tile kt-1 lived in (dummy zero loads past the end keep the count fixed)
         const bf16* a = ring + st_cur * V2_STAGE_ELEMS;
         const bf16* b = a + V2_BM * BK;
 #pragma unroll
@@ -530,11 +574,18 @@ __global__ __launch_bounds__(V2_THREADS, 2) void gemm_v2_kernel(GemmParams p) {
                 const int r = wrow[ni];
                 fw[ni] = *reinterpret_cast<const bf16x8*>(b + r * BK + ((ch ^ ((r >> 1) & 7)) << 3));
             }
+            if (!(VAR & 32)) {
 #pragma unroll
-            for (int ni = 0; ni < NT; ni++)
+                for (int ni = 0; ni < NT; ni++)
 #pragma unroll
-                for (int mi = 0; mi < MT; mi++)
-                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[ni], fa[mi], acc[ni][mi], 0, 0, 0);
+                    for (int mi = 0; mi < MT; mi++)
+                        acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[ni], fa[mi], acc[ni][mi], 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int mi = 0; mi < MT; mi++) asm volatile("" :: "v"(fa[mi]));
+#pragma unroll
+                for (int ni = 0; ni < NT; ni++) asm volatile("" :: "v"(fw[ni]));
+            }
         }
         st_cur = st_cur == V2_STAGES - 1 ? 0 : st_cur + 1;
         st_nxt = st_nxt == V2_STAGES - 1 ? 0 : st_nxt + 1;
@@ -543,32 +594,241 @@ __global__ __launch_bounds__(V2_THREADS, 2) void gemm_v2_kernel(GemmParams p) {
     gemm_epilogue<MT, NT>(p, acc, m0 + wm0, n0 + wn0, li, lg);
 }
 
-template <int MODE>
+template <int MODE, int VAR = 0>
 static int launch_gemm_v2(const GemmParams& p, hipStream_t s) {
     const int tiles = ((p.M + V2_BM - 1) / V2_BM) * ((p.N + V2_BN - 1) / V2_BN);
     const size_t lds = (size_t)V2_STAGES * V2_STAGE_ELEMS * sizeof(bf16);
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_v2_kernel<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_v2_kernel<MODE, VAR>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done = true;
     }
-    hipLaunchKernelGGL((gemm_v2_kernel<MODE>), dim3(tiles), dim3(V2_THREADS), lds, s, p);
+    hipLaunchKernelGGL((gemm_v2_kernel<MODE, VAR>), dim3(tiles), dim3(V2_THREADS), lds, s, p);
     return sidlsg_last_error();
 }
 
-template <int BM, int BN, int MODE>
+// ---------------------------------------------------------------------------------------------
+// "v3": the 128 x 160 x 64 tile / 4 waves / 2 blocks per CU structure of gemm_bf16_kernel, but tiles are staged by
+// direct-to-LDS loads (global_load_lds_dwordx4 + zero page, source-side swizzle as in v2): the ds_write commit phase --
+// measured at ~25 % of the kernel and not overlapped with MFMA -- and the staging registers disappear.
+// Schedule per K-tile (2 LDS buffers, one raw barrier):
+//   A: issue the kk=1 fragment reads of the current buffer; kk=0 MFMAs (fragments were prefetched in the previous D)
+//   C: s_waitcnt vmcnt(0) (this wave's DMA of tile kt+1 has landed) ; s_barrier
+//   D: issue the kk=0 fragment reads of tile kt+1 and the DMA of tile kt+2 into the buffer just vacated
+//   E: kk=1 MFMAs (cover D's latencies)
+template <int MODE>   // 0 dense, 1 conv3x3 with Cin % 64 == 0
+__global__ __launch_bounds__(NTHREADS, 2) void gemm_v3_kernel(GemmParams p) {
+    constexpr int BM = 128, BN = 160, MT = 4, NT = 5;
+    constexpr int STAGE = (BM + BN) * BK;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    bf16* ring = reinterpret_cast<bf16*>(smem);
+
+    const int tiles_n = (p.N + BN - 1) / BN;
+    const int tiles_m = (p.M + BM - 1) / BM;
+    const int nblk = tiles_n * tiles_m;
+    int bid = blockIdx.x;
+    {
+        const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int m0 = (bid / tiles_n) * BM;
+    const int n0 = (bid % tiles_n) * BN;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 80;
+    const int li = lane & 15, lg = lane >> 4;
+    const int lrow = lane >> 3, lslot = lane & 7;
+    const char* zero = reinterpret_cast<const char*>(g_zero_page);
+
+    const int Hs = p.ups ? (p.H >> 1) : p.H, Ws = p.ups ? (p.Wd >> 1) : p.Wd;
+    const char* abase[4];
+    int ahi[4], awi[4];
+    const char* arow[4];
+    bool aval[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int r = wave * 32 + j * 8 + lrow;
+        const int kcs = lslot ^ ((r >> 1) & 7);
+        const int m = m0 + r;
+        const bool ok = m < p.M;
+        if (MODE == 0) {
+            abase[j] = reinterpret_cast<const char*>(p.A) + ((size_t)(ok ? m : 0) * p.lda + kcs * 8) * 2;
+            aval[j] = ok; arow[j] = abase[j]; ahi[j] = awi[j] = 0;
+        } else {
+            const int mm = ok ? m : 0;
+            const int hw = p.Ho * p.Wo;
+            const int b = mm / hw, rem = mm - b * hw;
+            const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+            abase[j] = reinterpret_cast<const char*>(p.A) + ((size_t)b * Hs * Ws * p.lda + kcs * 8) * 2;
+            ahi[j] = ok ? ho * p.stride - 1 : -100000;
+            awi[j] = wo * p.stride - 1;
+            aval[j] = false; arow[j] = zero;
+        }
+    }
+    const char* bbase[5];
+    bool bval[5];
+#pragma unroll
+    for (int j = 0; j < 5; j++) {
+        const int g = wave + 4 * j;                 // 20 groups of 8 weight rows, 5 per wave
+        const int r = g * 8 + lrow;
+        const int kcs = lslot ^ ((r >> 1) & 7);
+        const int n = n0 + r;
+        bval[j] = n < p.N;
+        bbase[j] = reinterpret_cast<const char*>(p.W) + ((size_t)(bval[j] ? n : 0) * p.K + kcs * 8) * 2;
+    }
+    const int nk_all = (p.K + BK - 1) / BK;
+    const int kt_begin = p.kt_per_split ? blockIdx.y * p.kt_per_split : 0;
+    const int nk = p.kt_per_split ? min(nk_all, kt_begin + p.kt_per_split) : nk_all;
+    int cur_tap = -1;
+
+    auto issue = [&](int t, int buf) {          // 9 global_load_lds per wave
+        bf16* sa = ring + buf * STAGE;
+        bf16* sb = sa + BM * BK;
+        const int k0 = t * BK;
+        int c0 = 0;
+        if (MODE == 1) {
+            const int tap = k0 / p.Cin;
+            c0 = k0 - tap * p.Cin;
+            if (tap != cur_tap) {
+                cur_tap = tap;
+                const int dh = tap / 3, dw = tap - dh * 3;
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    int hi = ahi[j] + dh, wi = awi[j] + dw;
+                    aval[j] = hi >= 0 && hi < p.H && wi >= 0 && wi < p.Wd;
+                    if (p.ups) { hi >>= 1; wi >>= 1; }
+                    arow[j] = abase[j] + (size_t)(hi * Ws + wi) * p.lda * 2;
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int r = wave * 32 + j * 8 + lrow;
+            const int kcs = lslot ^ ((r >> 1) & 7);
+            const bool kok = k0 + kcs * 8 < p.K;
+            const char* src = (aval[j] && kok) ? arow[j] + (size_t)(MODE == 0 ? k0 : c0) * 2 : zero;
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sa + (wave * 32 + j * 8) * BK), 16, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < 5; j++) {
+            const int g = wave + 4 * j;
+            const int r = g * 8 + lrow;
+            const int kcs = lslot ^ ((r >> 1) & 7);
+            const bool kok = k0 + kcs * 8 < p.K;
+            const char* src = (bval[j] && kok) ? bbase[j] + (size_t)k0 * 2 : zero;
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sb + g * 8 * BK), 16, 0, 0);
+        }
+    };
+
+    f32x4 acc[NT][MT];
+#pragma unroll
+    for (int i = 0; i < NT; i++)
+#pragma unroll
+        for (int j = 0; j < MT; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    int wrow[NT];
+#pragma unroll
+    for (int ni = 0; ni < NT; ni++) {
+        const bool paired = (ni | 1) < NT;
+        wrow[ni] = wn0 + (paired ? 32 * (ni >> 1) + (li >> 2) * 8 + (ni & 1) * 4 + (li & 3) : 16 * ni + li);
+    }
+    auto read_frags = [&](int buf, int kk, bf16x8 (&fa)[MT], bf16x8 (&fw)[NT]) {
+        const bf16* a = ring + buf * STAGE;
+        const bf16* b = a + BM * BK;
+        const int ch = kk * 4 + lg;
+#pragma unroll
+        for (int mi = 0; mi < MT; mi++) {
+            const int r = wm0 + mi * 16 + li;
+            fa[mi] = *reinterpret_cast<const bf16x8*>(a + r * BK + ((ch ^ ((r >> 1) & 7)) << 3));
+        }
+#pragma unroll
+        for (int ni = 0; ni < NT; ni++) {
+            const int r = wrow[ni];
+            fw[ni] = *reinterpret_cast<const bf16x8*>(b + r * BK + ((ch ^ ((r >> 1) & 7)) << 3));
+        }
+    };
+    auto mfma_block = [&](const bf16x8 (&fa)[MT], const bf16x8 (&fw)[NT]) {
+#pragma unroll
+        for (int ni = 0; ni < NT; ni++)
+#pragma unroll
+            for (int mi = 0; mi < MT; mi++)
+                acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[ni], fa[mi], acc[ni][mi], 0, 0, 0);
+    };
+
+    bf16x8 fa0[MT], fw0[NT], fa1[MT], fw1[NT];
+    issue(kt_begin, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    read_frags(0, 0, fa0, fw0);
+    if (kt_begin + 1 < nk) issue(kt_begin + 1, 1);
+    for (int kt = kt_begin; kt < nk; kt++) {
+        const int buf = (kt - kt_begin) & 1;
+        const bool more = kt + 1 < nk;
+        read_frags(buf, 1, fa1, fw1);                          // A
+        mfma_block(fa0, fw0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // C: my share of tile kt+1 is in LDS
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (more) {                                            // D
+            read_frags(buf ^ 1, 0, fa0, fw0);
+            if (kt + 2 < nk) issue(kt + 2, buf);
+        }
+        mfma_block(fa1, fw1);                                  // E
+    }
+
+    if (p.kt_per_split) {
+#pragma unroll
+        for (int mi = 0; mi < MT; mi++) {
+            const int m = m0 + wm0 + mi * 16 + li;
+            if (m >= p.M) continue;
+#pragma unroll
+            for (int ni = 0; ni < NT; ni++) {
+                const bool paired = (ni | 1) < NT;
+                const int nb = n0 + wn0 + (paired ? 32 * (ni >> 1) + lg * 8 + (ni & 1) * 4 : 16 * ni + lg * 4);
+                float* dst = p.ws + ((size_t)blockIdx.y * p.M + m) * p.N + nb;
+                if (nb + 4 <= p.N) *reinterpret_cast<f32x4*>(dst) = acc[ni][mi];
+                else
+                    for (int r = 0; r < 4; r++)
+                        if (nb + r < p.N) dst[r] = acc[ni][mi][r];
+            }
+        }
+        return;
+    }
+    gemm_epilogue<MT, NT>(p, acc, m0 + wm0, n0 + wn0, li, lg);
+}
+
+template <int MODE>
+static int launch_gemm_v3(const GemmParams& p, hipStream_t s) {
+    const int tiles = ((p.M + 127) / 128) * ((p.N + 159) / 160);
+    const size_t lds = (size_t)2 * (128 + 160) * BK * sizeof(bf16);
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_v3_kernel<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_done = true;
+    }
+    const int nk = (p.K + BK - 1) / BK;
+    const int splits = p.kt_per_split ? (nk + p.kt_per_split - 1) / p.kt_per_split : 1;
+    hipLaunchKernelGGL((gemm_v3_kernel<MODE>), dim3(tiles, splits), dim3(NTHREADS), lds, s, p);
+    if (p.kt_per_split) {
+        const size_t n4 = ((size_t)p.M * p.N + 3) / 4;
+        hipLaunchKernelGGL(gemm_finish_kernel, dim3((unsigned)((n4 + 255) / 256), splits), dim3(256), 0, s, p);
+    }
+    return sidlsg_last_error();
+}
+
+template <int BM, int BN, int MODE, int VAR = 0>
 static int launch_gemm(const GemmParams& p, hipStream_t s) {
     const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
     const size_t lds = (size_t)2 * (BM + BN) * BK * sizeof(bf16);
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<BM, BN, MODE>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<BM, BN, MODE, VAR>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done = true;
     }
     const int nk = (p.K + BK - 1) / BK;
     const int splits = p.kt_per_split ? (nk + p.kt_per_split - 1) / p.kt_per_split : 1;
-    hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, MODE>), dim3(tiles, splits), dim3(NTHREADS), lds, s, p);
+    hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, MODE, VAR>), dim3(tiles, splits), dim3(NTHREADS), lds, s, p);
     if (p.kt_per_split) {
         const size_t n4 = ((size_t)p.M * p.N + 3) / 4;
         hipLaunchKernelGGL(gemm_finish_kernel, dim3((unsigned)((n4 + 255) / 256), splits), dim3(256), 0, s, p);   // grid.y only carries the split count
@@ -588,14 +848,21 @@ static int dispatch_gemm(const GemmParams& p, hipStream_t s) {
         const long long t2 = (long long)((p.M + V2_BM - 1) / V2_BM) * ((p.N + V2_BN - 1) / V2_BN);
         static const long long v2_min = getenv("SIDLSG_GEMM_V2_MIN_TILES") ? atoll(getenv("SIDLSG_GEMM_V2_MIN_TILES")) : 512;  // tests force 1
         // measured: v2 wins 3-8% on long-K shapes with >= 2 full waves of tiles, loses on short K / partial waves
-        if (v2_on && MODE != 2 && p.N % 160 == 0 && t2 >= v2_min && (p.K >= 640 || v2_min == 1)) return launch_gemm_v2<MODE == 2 ? 0 : MODE>(p, s);
+        if (v2_on && MODE != 2 && p.N % 160 == 0 && t2 >= v2_min && (p.K >= 640 || v2_min == 1)) {
+            static const int v2var = getenv("SIDLSG_GEMM_V2VAR") ? atoi(getenv("SIDLSG_GEMM_V2VAR")) : 0;
+            if (v2var == 32) return launch_gemm_v2<MODE == 2 ? 0 : MODE, 32>(p, s);
+            if (v2var == 64) return launch_gemm_v2<MODE == 2 ? 0 : MODE, 64>(p, s);
+            if (v2var == 96) return launch_gemm_v2<MODE == 2 ? 0 : MODE, 96>(p, s);
+            return launch_gemm_v2<MODE == 2 ? 0 : MODE>(p, s);
+        }
     }
     auto tiles = [&](int bm, int bn) { return (long long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn); };
     const bool n160 = p.N % 160 == 0;
-    {   // few output tiles but a long contraction (8x8 / 16x16 stages): split K over blockIdx.y with the big tile
+    static const int v3_on = getenv("SIDLSG_GEMM_V3") ? atoi(getenv("SIDLSG_GEMM_V3")) : 1;
+    {   // few output tiles but a long contraction (8x8 / 16x16 stages, small batches): split K over blockIdx.y with the big tile
         const long long t = tiles(128, n160 ? 160 : 128);
         const int nk = (p.K + BK - 1) / BK;
-        if (t < 256 && nk >= 32 && (p.N & 3) == 0 && g_ws && (long long)p.M * p.N * 8 <= g_ws_bytes) {
+        if (t < 384 && nk >= 32 && (p.N & 3) == 0 && g_ws && (long long)p.M * p.N * 8 <= g_ws_bytes) {
             int splits = (int)((512 + t - 1) / t);
             const long long cap = g_ws_bytes / ((long long)p.M * p.N * 4);
             if (splits > cap) splits = (int)cap;
@@ -605,11 +872,23 @@ static int dispatch_gemm(const GemmParams& p, hipStream_t s) {
                 GemmParams q = p;
                 q.kt_per_split = (nk + splits - 1) / splits;
                 q.ws = g_ws;
+                if (n160 && v3_on && MODE != 2) return launch_gemm_v3<MODE == 2 ? 0 : MODE>(q, s);
                 return n160 ? launch_gemm<128, 160, MODE>(q, s) : launch_gemm<128, 128, MODE>(q, s);
             }
         }
     }
-    if (tiles(128, n160 ? 160 : 128) >= 384) return n160 ? launch_gemm<128, 160, MODE>(p, s) : launch_gemm<128, 128, MODE>(p, s);
+    if (tiles(128, n160 ? 160 : 128) >= 384) {
+        if (n160 && v3_on && MODE != 2) return launch_gemm_v3<MODE == 2 ? 0 : MODE>(p, s);
+        static const int var = getenv("SIDLSG_GEMM_VAR") ? atoi(getenv("SIDLSG_GEMM_VAR")) : 0;   // scheduling experiments (A/B)
+        if (n160 && var == 2) return launch_gemm<128, 160, MODE, 2>(p, s);
+        if (n160 && var == 128) return launch_gemm<128, 160, MODE, 128>(p, s);
+        if (n160 && var == 16) return launch_gemm<128, 160, MODE, 16>(p, s);   // ablations: 16 no LDS commit, 32 no MFMA, 64 no global loads
+        if (n160 && var == 32) return launch_gemm<128, 160, MODE, 32>(p, s);
+        if (n160 && var == 64) return launch_gemm<128, 160, MODE, 64>(p, s);
+        if (n160 && var == 80) return launch_gemm<128, 160, MODE, 80>(p, s);
+        if (n160 && var == 96) return launch_gemm<128, 160, MODE, 96>(p, s);
+        return n160 ? launch_gemm<128, 160, MODE>(p, s) : launch_gemm<128, 128, MODE>(p, s);
+    }
     if (tiles(64, n160 ? 160 : 128) >= 384) return n160 ? launch_gemm<64, 160, MODE>(p, s) : launch_gemm<64, 128, MODE>(p, s);
     return launch_gemm<64, 64, MODE>(p, s);
 }
