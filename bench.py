@@ -217,7 +217,7 @@ def main():
         pmc = os.path.join(ROOT, 'profiles', 'r01_conv_pmc.json')
         if os.path.isfile(pmc):
             traffic = json.load(open(pmc)).get('avg_hbm_side_bytes_per_launch')
-        out['roofline'] = {'bound': 'mfma', 'kernel': 'implicit-GEMM conv3x3 fwd + dgrad (gemm_bf16_kernel<*,*,1|2>, gemm_v2_kernel<1>)',
+        out['roofline'] = {'bound': 'mfma', 'kernel': 'implicit-GEMM conv3x3 fwd + dgrad (gemm_v3_kernel<1>, gemm_bf16_kernel<*,*,1|2>)',
                            'achieved': ach, 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / PEAK_BF16_TFLOPS,
                            'traffic': traffic, 'launches': r['launches'], 'avg_launch_ms': r['ms'] / max(r['launches'], 1),
                            'algorithmic_tflop_per_launch': r['flops'] / max(r['launches'], 1) / 1e12}
