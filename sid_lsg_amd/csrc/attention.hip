@@ -21,6 +21,7 @@
 //               S[query][key] so that P / dS are B operands of the contractions over queries.
 #include "common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 struct AttnParams {
     const bf16 *Q, *K, *V, *dO;
@@ -44,19 +45,23 @@ DEVFN bf16x8 bld8(__amdgpu_buffer_rsrc_t r, unsigned off) {
     return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
 }
 
+// One MFMA operand row of a head: ceil(DP/32) K=32 slices.  Head dims that are not multiples of 32 (d=40 -> DP=48,
+// d=80) zero-pad the last slice instead of using a trailing 16x16x16 MFMA: the K=16 instruction costs the same 4
+// passes as the K=32 one on gfx950, and chaining it behind a K=32 result needed a separate accumulator + VALU adds
+// (a 16x16x32 result forwarded into the SrcC of a 16x16x16 MFMA gave wrong sums, see git history / DESIGN.md).
+// Every contraction pairs one operand read from global memory (exact zeros past D) with one read from an LDS tile
+// whose row is over-read by up to N32*32 - DP columns: pad columns are zeroed once per block and the over-read of
+// the next row meets zeros on the other side, so only finiteness of the LDS contents matters.
 template <int DP>
 struct Frag {
-    static constexpr int N32 = DP / 32;
-    static constexpr bool TAIL = (DP % 32) != 0;
-    bf16x8 w[N32 > 0 ? N32 : 1];
-    s16x4 t;
+    static constexpr int N32 = (DP + 31) / 32;
+    bf16x8 w[N32];
 };
 
 template <int DP>
 DEVFN void frag_from_lds(Frag<DP>& f, const bf16* row, int lg) {
 #pragma unroll
     for (int s = 0; s < Frag<DP>::N32; s++) f.w[s] = *reinterpret_cast<const bf16x8*>(row + s * 32 + lg * 8);
-    if (Frag<DP>::TAIL) f.t = *reinterpret_cast<const s16x4*>(row + Frag<DP>::N32 * 32 + lg * 4);
 }
 template <int DP>
 DEVFN void frag_from_global(Frag<DP>& f, const bf16* row, int lg, int D, bool ok) {
@@ -65,25 +70,25 @@ DEVFN void frag_from_global(Frag<DP>& f, const bf16* row, int lg, int D, bool ok
         const int d0 = s * 32 + lg * 8;
         f.w[s] = (ok && d0 + 8 <= D) ? ld8(row + d0) : zero8();
     }
-    if (Frag<DP>::TAIL) {
-        const int d0 = Frag<DP>::N32 * 32 + lg * 4;
-        s16x4 z = {0, 0, 0, 0};
-        f.t = (ok && d0 + 4 <= D) ? *reinterpret_cast<const s16x4*>(row + d0) : z;
-    }
 }
-// NOTE: the K=16 tail gets its OWN accumulator chain and is added with VALU.  Feeding the result of a
-// 16x16x32 MFMA directly into the SrcC of a 16x16x16 MFMA (as hipcc 7.2 schedules it, back to back, no
-// wait states) produced wrong sums on gfx950 (tests: D=40/80 failed while D=16 and D=32/64/160 passed).
 template <int DP>
 DEVFN f32x4 mma_d(f32x4 acc, const Frag<DP>& a, const Frag<DP>& b) {
 #pragma unroll
     for (int s = 0; s < Frag<DP>::N32; s++) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.w[s], b.w[s], acc, 0, 0, 0);
-    if (Frag<DP>::TAIL) {
-        const f32x4 tail = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a.t, b.t, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-        if (Frag<DP>::N32 > 0) acc += tail; else acc = tail;
-    }
     return acc;
 }
+// LDS tile of ROWS x (DP + 8) bf16 plus slack for the over-read of the last row; pad columns and slack zeroed here
+// (disjoint from what TileRegs::store writes, so the caller's first barrier covers it).
+template <int DP, int ROWS>
+DEVFN void lds_tile_init(bf16* tile) {
+    constexpr int LD = DP + 8;
+    for (int r = threadIdx.x; r < ROWS + 2; r += 256) {
+        bf16* p = r < ROWS ? tile + r * LD + DP : tile + ROWS * LD + (r - ROWS) * 8;
+        st8(p, zero8());
+    }
+}
+template <int DP, int ROWS>
+constexpr int lds_tile_elems() { return ROWS * (DP + 8) + 16; }
 
 // A operand = X^T for a row-major LDS tile X[row][LD]: rows r0 + {4g..4g+3} and r0 + 16 + {4g..4g+3},
 // columns c0..c0+15 -> lane i gets column c0+i, the 8 rows in the order that matches pack_p().
@@ -118,31 +123,50 @@ struct TileRegs {
             v[j] = bld8(rs, ok ? (unsigned)(((long long)(row0 + r) * ld + c) * 2) : A_OOB);
         }
     }
-    DEVFN void store(bf16* dst, int LD) const {
+    // ones_col >= 0: element [r][ones_col] is written as 1.0 (a zero-pad column of the tile): the MFMA that contracts
+    // the tile against the probabilities then yields their row sum in that output row for free.
+    DEVFN void store(bf16* dst, int LD, int ones_col = -1) const {
 #pragma unroll
         for (int j = 0; j < PER; j++) {
             const int idx = threadIdx.x + 256 * j;
             const int r = idx / C8, c = (idx - r * C8) * 8;
-            if (idx < TCH) st8(dst + r * LD + c, v[j]);
+            bf16x8 x = v[j];
+            if (c == ones_col) x[0] = f2bf(1.0f);
+            if (idx < TCH) st8(dst + r * LD + c, x);
         }
     }
 };
 
+// max of three: pattern-matched to v_max3_f32.  attention.hip is compiled with -fno-honor-nans so that llvm.maxnum
+// does not put a canonicalising v_max x,x on every MFMA output.  (Do NOT use inline asm on MFMA results: the
+// compiler cannot see the operands of an asm statement when it inserts the MFMA->VALU wait states, and short
+// MFMA chains (d <= 48) then read stale registers.)
+DEVFN float fmax3(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
+DEVFN float fmax2(float a, float b) { return fmaxf(a, b); }
+
 constexpr int AT_KT = 64;   // keys per LDS tile
 
 // MODE 0: forward (O, LSE).  MODE 1: dQ.   QT = 16-query tiles per wave (block = 4 waves * QT * 16 queries)
-template <int DP, int QT, int MODE>
+// ONES (forward, D == DP - 8 only): V's first pad column holds 1.0, so O^T row D accumulates the softmax
+// denominator inside the P.V MFMAs (and is rescaled with O); the 16 VALU adds per query tile disappear.
+// K/V tiles are double buffered in LDS: one barrier per key tile.
+template <int DP, int QT, int MODE, bool ONES>
 __global__ __launch_bounds__(256) void attn_q_kernel(AttnParams p) {
+    static_assert(!ONES || (MODE == 0 && DP % 16 == 0), "ones column: forward only");
     constexpr int LD = DP + 8;
     constexpr int DT = DP / 16;
-    __shared__ __attribute__((aligned(16))) bf16 Ks[AT_KT * LD];
-    __shared__ __attribute__((aligned(16))) bf16 Vs[AT_KT * LD];
+    constexpr int TE = lds_tile_elems<DP, AT_KT>();
+    __shared__ __attribute__((aligned(16))) bf16 Ks[2][TE];
+    __shared__ __attribute__((aligned(16))) bf16 Vs[2][TE];
     const int b = blockIdx.z, h = blockIdx.y;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lg = lane >> 4;
     const int q0 = (blockIdx.x * 4 + wave) * (QT * 16);
     const bf16* Qb = p.Q + b * p.bsq + (long long)h * p.D;
     const __amdgpu_buffer_rsrc_t rk = mk_rsrc(p.K + b * p.bsk + (long long)h * p.D);
     const __amdgpu_buffer_rsrc_t rv = mk_rsrc(p.V + b * p.bsv + (long long)h * p.D);
+    const int ones_col = ONES ? p.D : -1;
+#pragma unroll
+    for (int i = 0; i < 2; i++) { lds_tile_init<DP, AT_KT>(Ks[i]); lds_tile_init<DP, AT_KT>(Vs[i]); }
 
     Frag<DP> fq[QT], fdo[MODE == 1 ? QT : 1];
     float lse[QT], dl[QT];
@@ -171,24 +195,29 @@ __global__ __launch_bounds__(256) void attn_q_kernel(AttnParams p) {
     TileRegs<DP, AT_KT> tk, tv;
     tk.load(rk, p.ldk, 0, p.Nk, p.D);
     tv.load(rv, p.ldv, 0, p.Nk, p.D);
-    tk.store(Ks, LD);
-    tv.store(Vs, LD);
+    tk.store(Ks[0], LD);
+    tv.store(Vs[0], LD, ones_col);
     __syncthreads();
-    for (int k0 = 0; k0 < p.Nk; k0 += AT_KT) {
+    int buf = 0;
+    // The tile body is instantiated twice: full tiles (no masking code at all; the compiler otherwise if-converts
+    // the ragged-tile test into ~90 predicated VALU ops per tile in a VALU-bound loop) and the ragged last tile.
+    auto tile = [&](const int k0, auto ragged) {
         const bool more = k0 + AT_KT < p.Nk;
         if (more) { tk.load(rk, p.ldk, k0 + AT_KT, p.Nk, p.D); tv.load(rv, p.ldv, k0 + AT_KT, p.Nk, p.D); }
+        const bf16* Kt = Ks[buf];
+        const bf16* Vt = Vs[buf];
         f32x4 s[4][QT];
 #pragma unroll
         for (int kt = 0; kt < 4; kt++) {
             Frag<DP> fk;
-            frag_from_lds<DP>(fk, Ks + (kt * 16 + li) * LD, lg);
+            frag_from_lds<DP>(fk, Kt + (kt * 16 + li) * LD, lg);
 #pragma unroll
             for (int qt = 0; qt < QT; qt++) s[kt][qt] = mma_d<DP>((f32x4){0, 0, 0, 0}, fk, fq[qt]);
         }
         // scores -> probabilities (keys of this lane: k0 + kt*16 + lg*4 + r).  The softmax is the VALU-bound part
         // at d=40: raw v_exp_f32, scale folded into one FMA, masking only on the ragged last tile, and the
         // running-max rescale of O deferred until the max grows by > 2^8 (LSE stays exact: m + log2(l)).
-        if (k0 + AT_KT > p.Nk) {
+        if constexpr (decltype(ragged)::value) {
 #pragma unroll
             for (int kt = 0; kt < 4; kt++)
 #pragma unroll
@@ -201,16 +230,19 @@ __global__ __launch_bounds__(256) void attn_q_kernel(AttnParams p) {
 #pragma unroll
         for (int qt = 0; qt < QT; qt++) {
             if (MODE == 0) {
-                float mx = fmaxf(fmaxf(s[0][qt][0], s[0][qt][1]), fmaxf(s[0][qt][2], s[0][qt][3]));
-#pragma unroll
-                for (int kt = 1; kt < 4; kt++)
-#pragma unroll
-                    for (int r = 0; r < 4; r++) mx = fmaxf(mx, s[kt][qt][r]);
-                mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                float mx = fmax3(s[0][qt][0], s[0][qt][1], s[0][qt][2]);
+                mx = fmax3(mx, s[0][qt][3], s[1][qt][0]);
+                mx = fmax3(mx, s[1][qt][1], s[1][qt][2]);
+                mx = fmax3(mx, s[1][qt][3], s[2][qt][0]);
+                mx = fmax3(mx, s[2][qt][1], s[2][qt][2]);
+                mx = fmax3(mx, s[2][qt][3], s[3][qt][0]);
+                mx = fmax3(mx, s[3][qt][1], s[3][qt][2]);
+                mx = fmax2(mx, s[3][qt][3]);
+                mx = fmax2(mx, __shfl_xor(mx, 16, 64));
+                mx = fmax2(mx, __shfl_xor(mx, 32, 64));
                 mx *= p.scale2;                                    // scale2 > 0: max commutes with the scaling
                 if (__any(mx > m[qt] + 8.0f)) {                    // wave-uniform: rescale everything held at the old max
-                    const float mn = fmaxf(m[qt], mx);
+                    const float mn = fmax2(m[qt], mx);
                     const float alpha = __builtin_amdgcn_exp2f(m[qt] - mn);   // m = -inf on the first tile -> 0
                     l[qt] *= alpha;
                     m[qt] = mn;
@@ -225,9 +257,9 @@ __global__ __launch_bounds__(256) void attn_q_kernel(AttnParams p) {
                     for (int r = 0; r < 4; r++) {
                         const float e = __builtin_amdgcn_exp2f(fmaf(s[kt][qt][r], p.scale2, nm));
                         s[kt][qt][r] = e;
-                        sum += e;
+                        if (!ONES) sum += e;
                     }
-                l[qt] += sum;
+                if (!ONES) l[qt] += sum;
             } else {
                 const float nl = -lse[qt];
 #pragma unroll
@@ -241,7 +273,7 @@ __global__ __launch_bounds__(256) void attn_q_kernel(AttnParams p) {
 #pragma unroll
             for (int kt = 0; kt < 4; kt++) {
                 Frag<DP> fv;
-                frag_from_lds<DP>(fv, Vs + (kt * 16 + li) * LD, lg);
+                frag_from_lds<DP>(fv, Vt + (kt * 16 + li) * LD, lg);
 #pragma unroll
                 for (int qt = 0; qt < QT; qt++) {
                     const f32x4 dp = mma_d<DP>((f32x4){0, 0, 0, 0}, fv, fdo[qt]);
@@ -251,7 +283,7 @@ __global__ __launch_bounds__(256) void attn_q_kernel(AttnParams p) {
             }
         }
         // second contraction over keys: forward uses V, dQ uses K
-        const bf16* T2 = MODE == 0 ? Vs : Ks;
+        const bf16* T2 = MODE == 0 ? Vt : Kt;
 #pragma unroll
         for (int kb = 0; kb < 2; kb++) {
             bf16x8 pb[QT];
@@ -264,22 +296,30 @@ __global__ __launch_bounds__(256) void attn_q_kernel(AttnParams p) {
                 for (int qt = 0; qt < QT; qt++) o[dt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, pb[qt], o[dt][qt], 0, 0, 0);
             }
         }
-        __syncthreads();                 // everyone finished reading this tile
-        if (more) {
-            tk.store(Ks, LD);
-            tv.store(Vs, LD);
+        if (more) {                      // the other buffer was last read before the previous barrier
+            tk.store(Ks[buf ^ 1], LD);
+            tv.store(Vs[buf ^ 1], LD, ones_col);
             __syncthreads();
+            buf ^= 1;
         }
-    }
+    };
+    int k0 = 0;
+    for (; k0 + AT_KT <= p.Nk; k0 += AT_KT) tile(k0, std::false_type{});
+    if (k0 < p.Nk) tile(k0, std::true_type{});
     // epilogue: lane holds, for query li of tile qt, d = dt*16 + lg*4 + r
 #pragma unroll
     for (int qt = 0; qt < QT; qt++) {
         const int q = q0 + qt * 16 + li;
         float inv = MODE == 1 ? p.scale : 1.f;     // dQ = d^-1/2 * sum_k dS' K
         if (MODE == 0) {
-            float lt = l[qt];
-            lt += __shfl_xor(lt, 16, 64);
-            lt += __shfl_xor(lt, 32, 64);
+            float lt;
+            if (ONES) {
+                lt = __shfl(o[DT - 1][qt][0], li + 32, 64);        // row D = (DT-1)*16 + 8: lane group 2, r = 0
+            } else {
+                lt = l[qt];
+                lt += __shfl_xor(lt, 16, 64);
+                lt += __shfl_xor(lt, 32, 64);
+            }
             inv = lt > 0.f ? 1.f / lt : 0.f;
             if (q < p.Nq && lg == 0 && p.LSE) p.LSE[((long long)b * p.H + h) * p.Nq + q] = m[qt] + log2f(lt);
         }
@@ -302,9 +342,11 @@ template <int DP, int KT>
 __global__ __launch_bounds__(256) void attn_dkdv_kernel(AttnParams p) {
     constexpr int LD = DP + 8;
     constexpr int DT = DP / 16;
-    __shared__ __attribute__((aligned(16))) bf16 Qs[AK_QT * LD];
-    __shared__ __attribute__((aligned(16))) bf16 dOs[AK_QT * LD];
+    __shared__ __attribute__((aligned(16))) bf16 Qs[lds_tile_elems<DP, AK_QT>()];
+    __shared__ __attribute__((aligned(16))) bf16 dOs[lds_tile_elems<DP, AK_QT>()];
     __shared__ float lse_s[2][AK_QT], dl_s[2][AK_QT];
+    lds_tile_init<DP, AK_QT>(Qs);
+    lds_tile_init<DP, AK_QT>(dOs);
     const int b = blockIdx.z, h = blockIdx.y;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lg = lane >> 4;
     const int key0 = (blockIdx.x * 4 + wave) * (KT * 16);
@@ -429,8 +471,10 @@ __global__ void attn_delta_kernel(const bf16* __restrict__ dO, const bf16* __res
 template <int DP, int QT, int KT>
 static int launch_attn(const AttnParams& p, int mode, hipStream_t s) {
     const int qb = 4 * QT * 16, kb = 4 * KT * 16;
-    if (mode == 0) hipLaunchKernelGGL((attn_q_kernel<DP, QT, 0>), dim3((p.Nq + qb - 1) / qb, p.H, p.B), dim3(256), 0, s, p);
-    else if (mode == 1) hipLaunchKernelGGL((attn_q_kernel<DP, QT, 1>), dim3((p.Nq + qb - 1) / qb, p.H, p.B), dim3(256), 0, s, p);
+    if (mode == 0) {
+        if (p.D == DP - 8) hipLaunchKernelGGL((attn_q_kernel<DP, QT, 0, true>), dim3((p.Nq + qb - 1) / qb, p.H, p.B), dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((attn_q_kernel<DP, QT, 0, false>), dim3((p.Nq + qb - 1) / qb, p.H, p.B), dim3(256), 0, s, p);
+    } else if (mode == 1) hipLaunchKernelGGL((attn_q_kernel<DP, QT, 1, false>), dim3((p.Nq + qb - 1) / qb, p.H, p.B), dim3(256), 0, s, p);
     else hipLaunchKernelGGL((attn_dkdv_kernel<DP, KT>), dim3((p.Nk + kb - 1) / kb, p.H, p.B), dim3(256), 0, s, p);
     return sidlsg_last_error();
 }

@@ -9,6 +9,10 @@ PKG = os.path.dirname(HERE)
 SOURCES = ['gemm.hip', 'norm.hip', 'attention.hip', 'elementwise.hip', 'optim.hip']
 LIB = os.path.join(PKG, 'libsidlsg_hip.so')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-munsafe-fp-atomics', '-Wno-unused-result']
+# Per-file extras.  attention.hip: the softmax works on MFMA results with VALU ops; with the default heuristics the
+# accumulators live in AGPRs and every tile pays ~110 v_accvgpr_read/write moves in a VALU-bound loop.
+# -fno-honor-nans: no canonicalising v_max x,x in front of every fmaxf on an MFMA result (infinities stay honoured).
+EXTRA = {'attention.hip': ['-mllvm', '-amdgpu-mfma-vgpr-form', '-fno-honor-nans']}
 
 
 def digest():
@@ -16,7 +20,7 @@ def digest():
     for f in SOURCES + ['common.h']:
         with open(os.path.join(HERE, f), 'rb') as fh:
             h.update(fh.read())
-    h.update(' '.join(FLAGS).encode())
+    h.update((' '.join(FLAGS) + repr(sorted(EXTRA.items()))).encode())
     return h.hexdigest()
 
 
@@ -32,7 +36,7 @@ def build(force=False, verbose=True):
     for src in SOURCES:
         obj = os.path.join(HERE, 'build', src.replace('.hip', '.o'))
         objs.append(obj)
-        cmd = [hipcc] + FLAGS + ['-c', os.path.join(HERE, src), '-o', obj]
+        cmd = [hipcc] + FLAGS + EXTRA.get(src, []) + ['-c', os.path.join(HERE, src), '-o', obj]
         if verbose:
             print(' '.join(cmd), flush=True)
         procs.append((src, subprocess.Popen(cmd)))
