@@ -50,10 +50,13 @@ int sidlsg_conv3x3_bf16(const void* X, int ldx, const void* W, void* Y, int ldc,
 int sidlsg_set_workspace(void* ptr, long long bytes);
 
 /* weight gradients (autograd of the two ops above in the reference: loss.backward(),
- * sid_training_loop.py:450,533).  dW[N][K] += dY[M][N]^T A[M][K], fp32 atomics. */
-int sidlsg_wgrad_bf16(const void* dY, int ldy, const void* A, int lda, float* dW, int M, int N, int K, void* stream);
-int sidlsg_conv3x3_wgrad_bf16(const void* dY, int ldy, const void* X, int ldx, float* dW, int B, int H, int Wd, int Cin,
-                              int Cout, int stride, int ups, void* stream);
+ * sid_training_loop.py:450,533).  dW[N][K] += dY[M][N]^T A[M][K] in fp32 (pixel-split partial sums, reduced through the
+ * workspace).  dBias (may be NULL): dBias[N] += sum_m dY[m][N], the bias gradient of the same layer, produced by the
+ * same kernel (one extra MFMA against a vector of ones per dY fragment) instead of a separate column-sum pass. */
+int sidlsg_wgrad_bf16(const void* dY, int ldy, const void* A, int lda, float* dW, float* dBias, int M, int N, int K,
+                      void* stream);
+int sidlsg_conv3x3_wgrad_bf16(const void* dY, int ldy, const void* X, int ldx, float* dW, float* dBias, int B, int H, int Wd,
+                              int Cin, int Cout, int stride, int ups, void* stream);
 
 /* ---- normalisation (HBM bound) ------------------------------------------------------------
  * torch.nn.GroupNorm(32, C, eps)+SiLU of ResnetBlock2D.norm1/norm2, Transformer2DModel.norm,
@@ -127,6 +130,10 @@ int sidlsg_colsum(const void* g, int ldg, float* per_batch, float* total, float*
 int sidlsg_cast_f32_bf16(const float* x, void* y, long long n, void* stream);
 int sidlsg_cast_bf16_f32(const void* x, float* y, long long n, void* stream);
 int sidlsg_transpose_w(const float* src, void* dst, int N, int K, int T, void* stream); /* [N][T][K] -> [K][T rev][N] bf16 */
+/* All backward-data operands of a network in ONE launch.  jobs: DEVICE array of njobs records
+ *   struct sidlsg_tw_job { const float* src; void* dst; int N, K, T, blk0; };   (32 bytes, no padding)
+ * sorted by blk0 = index of the job's first 32x32 tile (job i covers T*ceil(N/32)*ceil(K/32) tiles); nblocks = total. */
+int sidlsg_transpose_w_batched(const void* jobs, int njobs, int nblocks, void* stream);
 
 /* ---- reference plugin op: torch_utils/ops/bias_act.cpp:32 `bias_act(x,b,xref,yref,dy,grad,dim,act,alpha,gain,clamp)`
  * act: 1 linear 2 relu 3 lrelu 4 tanh 5 sigmoid 6 elu 7 selu 8 softplus 9 swish (bias_act.py:23-33).

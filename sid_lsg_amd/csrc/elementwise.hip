@@ -271,6 +271,35 @@ __global__ void transpose_w_kernel(const float* __restrict__ src, bf16* __restri
     }
 }
 
+// Batched variant: one launch refreshes every backward-data operand of a network (~500 weights after each optimizer
+// step; launched one by one they were ~3 % of the step, launch- and tail-bound).  jobs[] is a device table sorted by
+// blk0 (first 32x32-tile index of the job); a block finds its job by binary search.  Layout = sidlsg_tw_job in the header.
+struct TwJob { const float* src; bf16* dst; int N, K, T, blk0; };
+__global__ void transpose_w_batched_kernel(const TwJob* __restrict__ jobs, int njobs) {
+    __shared__ float tile[32][33];
+    int lo = 0, hi = njobs - 1;
+    const int bid = blockIdx.x;
+    while (lo < hi) {                       // last job with blk0 <= bid
+        const int mid = (lo + hi + 1) >> 1;
+        if (jobs[mid].blk0 <= bid) lo = mid; else hi = mid - 1;
+    }
+    const TwJob j = jobs[lo];
+    const int tk = (j.K + 31) / 32, tn = (j.N + 31) / 32;
+    int t = bid - j.blk0;
+    const int tap = t / (tk * tn); t -= tap * tk * tn;
+    const int n0 = (t / tk) * 32, k0 = (t % tk) * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int r = ty; r < 32; r += 8) {
+        const int n = n0 + r, k = k0 + tx;
+        tile[r][tx] = (n < j.N && k < j.K) ? j.src[((size_t)n * j.T + tap) * j.K + k] : 0.f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int k = k0 + r, n = n0 + tx;
+        if (n < j.N && k < j.K) j.dst[((size_t)k * j.T + (j.T - 1 - tap)) * j.N + n] = f2bf(tile[tx][r]);
+    }
+}
+
 // ---- SiD losses: loss value + closed-form gradients -------------------
 // per-sample prepass: nan flag over the inputs, and sum |x - y_r|
 __global__ void sid_sample_stats_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ c,
@@ -504,6 +533,11 @@ int sidlsg_cast_bf16_f32(const void* x, float* y, long long n, void* stream) {
     return sidlsg_last_error();
 }
 // src fp32 [N][T][K] -> dst bf16 [K][T][N], taps reversed
+int sidlsg_transpose_w_batched(const void* jobs, int njobs, int nblocks, void* stream) {
+    if (!jobs || njobs <= 0 || nblocks <= 0) return SIDLSG_EINVAL;
+    hipLaunchKernelGGL(transpose_w_batched_kernel, dim3(nblocks), dim3(256), 0, (hipStream_t)stream, (const TwJob*)jobs, njobs);
+    return sidlsg_last_error();
+}
 int sidlsg_transpose_w(const float* src, void* dst, int N, int K, int T, void* stream) {
     hipLaunchKernelGGL(transpose_w_kernel, dim3((K + 31) / 32, (N + 31) / 32, T), dim3(256), 0, (hipStream_t)stream, src,
                        (bf16*)dst, N, K, T);

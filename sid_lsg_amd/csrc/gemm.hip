@@ -925,6 +925,7 @@ struct WgradParams {
     unsigned a_bytes, y_bytes;
     float* ws;        // [splits][N][K] slabs when splits > 1 and a workspace is available (else fp32 atomics)
     int nsplits;
+    float* dB;        // optional: dB[n] += sum_m dY[m][n] (bias gradient), produced by the k-tile-0 blocks
 };
 
 DEVFN int wg_swz(int row) { return (row & 3) | (((row >> 3) & 1) << 2); }
@@ -1017,6 +1018,12 @@ __global__ __launch_bounds__(NTHREADS) void wgrad_bf16_kernel(WgradParams p) {
     for (int i = 0; i < 4; i++)
 #pragma unroll
         for (int j = 0; j < 4; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // bias gradient = dY^T * ones: one extra MFMA per dY fragment in the waves that own k-columns 0..63 of k-tile 0
+    const bool do_bias = p.dB != nullptr && k0 == 0 && wk0 == 0;
+    f32x4 accb[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) accb[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const bf16x8 ones = {f2bf(1.f), f2bf(1.f), f2bf(1.f), f2bf(1.f), f2bf(1.f), f2bf(1.f), f2bf(1.f), f2bf(1.f)};
 
     typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
     auto tr_frag = [&](const bf16* tilebase, int mrow, int colbase) -> bf16x8 {
@@ -1053,9 +1060,22 @@ __global__ __launch_bounds__(NTHREADS) void wgrad_bf16_kernel(WgradParams p) {
 #pragma unroll
                 for (int j = 0; j < 4; j++)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fy[i], fx[j], acc[i][j], 0, 0, 0);
+            if (do_bias) {
+#pragma unroll
+                for (int i = 0; i < 4; i++) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fy[i], ones, accb[i], 0, 0, 0);
+            }
         }
         if (st + 1 < nsteps) store_tile(buf ^ 1);
         __syncthreads();
+    }
+    if (do_bias && li == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int n = n0 + wn0 + 16 * i + lg * 4 + r;
+                if (n < p.N) unsafeAtomicAdd(p.dB + n, accb[i][r]);
+            }
     }
     // acc[i][j][r]: n = n0+wn0+16i + lg*4 + r ; k = k0+wk0+16j + li
 #pragma unroll
@@ -1071,6 +1091,188 @@ __global__ __launch_bounds__(NTHREADS) void wgrad_bf16_kernel(WgradParams p) {
                 const size_t e = (size_t)n * p.K + k;
                 if (p.nsplits == 1) p.dW[e] += acc[i][j][r];                                  // sole owner of this element
                 else if (p.ws) p.ws[(size_t)blockIdx.y * p.N * p.K + e] = acc[i][j][r];      // slab, reduced by wgrad_reduce_kernel
+                else unsafeAtomicAdd(p.dW + e, acc[i][j][r]);
+            }
+        }
+}
+
+
+// "wgrad v2": same tile, LDS layout and fragment reads as wgrad_bf16_kernel, but the dY / X tiles are staged by
+// direct-to-LDS loads (global_load_lds_dwordx4): no staging registers, no ds_write commit phase.  The LDS swizzle is
+// applied on the SOURCE side: lane (row, q) fetches the 16-byte chunk whose swizzled position is q.  Padding (rows past
+// the split, columns past N/K, conv halo) reads a zero page.  Schedule per 64-pixel stage (2 LDS buffers, one barrier):
+//   A: issue the kk=1 fragment reads of the current buffer; kk=0 MFMAs   C: vmcnt(0)+lgkmcnt(0); s_barrier
+//   D: kk=0 fragment reads of the next buffer; DMA of stage st+2 into the buffer just vacated   E: kk=1 MFMAs
+// Blocks are numbered split-major and remapped so that one XCD works on consecutive (split, tile) pairs: the tiles of a
+// split share the same dY / X rows (the 9 taps re-read X shifted), which then stay in that XCD's L2.
+// Requires N % 8 == 0, K % 8 == 0 (conv: Cin % 8 == 0), ldy % 8 == 0, lda % 8 == 0, 16-byte aligned bases.
+constexpr int WG2_STAGE = 2 * WG_MB * WG_T;
+template <int MODE>
+__global__ __launch_bounds__(NTHREADS, 2) void wgrad_v2_kernel(WgradParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    bf16* ring = reinterpret_cast<bf16*>(smem);
+    const int tiles_k = (p.K + WG_T - 1) / WG_T;
+    const int tiles = ((p.N + WG_T - 1) / WG_T) * tiles_k;
+    int bid = blockIdx.x;
+    {
+        const int nblk = tiles * p.nsplits;
+        const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int split = bid / tiles, tile = bid - split * tiles;
+    const int n0 = (tile / tiles_k) * WG_T, k0 = (tile % tiles_k) * WG_T;
+    const int mbeg = split * p.m_per_split;
+    const int mend = min(p.M, mbeg + p.m_per_split);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, lg = lane >> 4;
+    const int wn0 = (wave >> 1) * 64, wk0 = (wave & 1) * 64;
+    const int q16 = tid & 15, r0 = tid >> 4;            // LDS chunk position and first row of this lane
+    const int c16 = (((q16 >> 1) ^ wg_swz(r0)) << 1) | (q16 & 1);   // source chunk (wg_swz(r0 + 16 i) == wg_swz(r0))
+    const char* zero = reinterpret_cast<const char*>(g_zero_page);
+
+    const int kA = k0 + c16 * 8;
+    const bool kok = kA < p.K;
+    int cA = kA, dh = 0, dw = 0;
+    if (MODE == 1) { const int tap = kA / p.Cin; cA = kA - tap * p.Cin; dh = tap / 3; dw = tap - dh * 3; }
+    const int nY = n0 + c16 * 8;
+    const bool nok = nY < p.N;
+    const int Hs = p.ups ? (p.H >> 1) : p.H, Ws = p.ups ? (p.Wd >> 1) : p.Wd;
+    const int hw = (MODE == 1) ? p.Ho * p.Wo : 1;
+    const char* ybase = reinterpret_cast<const char*>(p.dY) + (size_t)nY * 2;
+    const char* xbase = reinterpret_cast<const char*>(p.A) + (size_t)cA * 2;
+
+    int pb[4], pho[4], pwo[4];
+    const int d_b = WG_MB / hw, d_rem = WG_MB - d_b * hw;
+    const int d_ho = (MODE == 1) ? d_rem / p.Wo : 0, d_wo = (MODE == 1) ? d_rem - d_ho * p.Wo : 0;
+    if (MODE == 1) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int m = mbeg + r0 + 16 * i;
+            pb[i] = m / hw;
+            const int rem = m - pb[i] * hw;
+            pho[i] = rem / p.Wo;
+            pwo[i] = rem - pho[i] * p.Wo;
+        }
+    }
+    auto issue = [&](int mb, int buf) {      // called with mb = mbeg, mbeg + WG_MB, ... in order; 8 DMA instructions per wave
+        bf16* ys = ring + buf * WG2_STAGE;
+        bf16* xs = ys + WG_MB * WG_T;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int m = mb + r0 + 16 * i;
+            const bool mok = m < mend;
+            const char* ysrc = (mok && nok) ? ybase + (size_t)m * p.ldy * 2 : zero;
+            __builtin_amdgcn_global_load_lds((gptr_t)ysrc, (lptr_t)(ys + (4 * wave + 16 * i) * WG_T), 16, 0, 0);
+            const char* xsrc;
+            if (MODE == 0) {
+                xsrc = (mok && kok) ? xbase + (size_t)m * p.lda * 2 : zero;
+            } else {
+                bool ok = kok && mok;
+                const int b = pb[i], ho = pho[i], wo = pwo[i];
+                int hi = ho * p.stride - 1 + dh, wi = wo * p.stride - 1 + dw;
+                ok = ok && hi >= 0 && hi < p.H && wi >= 0 && wi < p.Wd;
+                if (p.ups) { hi >>= 1; wi >>= 1; }
+                xsrc = ok ? xbase + (size_t)(((unsigned)(b * Hs + hi) * (unsigned)Ws + (unsigned)wi) * (unsigned)p.lda) * 2 : zero;
+                int nwo = wo + d_wo, nho = ho + d_ho, nb = b + d_b;
+                if (nwo >= p.Wo) { nwo -= p.Wo; nho += 1; }
+                if (nho >= p.Ho) { nho -= p.Ho; nb += 1; }
+                pwo[i] = nwo; pho[i] = nho; pb[i] = nb;
+            }
+            __builtin_amdgcn_global_load_lds((gptr_t)xsrc, (lptr_t)(xs + (4 * wave + 16 * i) * WG_T), 16, 0, 0);
+        }
+    };
+
+    f32x4 acc[4][4];   // [n tile][k tile]
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const bool do_bias = p.dB != nullptr && k0 == 0 && wk0 == 0;
+    f32x4 accb[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) accb[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const bf16x8 ones = {f2bf(1.f), f2bf(1.f), f2bf(1.f), f2bf(1.f), f2bf(1.f), f2bf(1.f), f2bf(1.f), f2bf(1.f)};
+
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    // per-lane LDS offsets of the two transpose reads of a fragment (rows 8*lg + (li>>2) and +4), excluding the
+    // 16-column granule g of the fragment, which enters as (g ^ swz) << 4
+    const int rA = 8 * lg + (li >> 2), rB = rA + 4;
+    const int sA = wg_swz(rA), sB = wg_swz(rB);      // kk*32 does not change the swizzle bits
+    const int oA = rA * WG_T + (li & 3) * 4, oB = rB * WG_T + (li & 3) * 4;
+    auto tr_frag = [&](const bf16* tilebase, int kk, int colbase) -> bf16x8 {
+        const int g = colbase >> 4;
+        const bf16* base = tilebase + kk * 32 * WG_T;
+        s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base + oA + ((g ^ sA) << 4)));
+        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base + oB + ((g ^ sB) << 4)));
+        typedef short s16x8 __attribute__((ext_vector_type(8)));
+        s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        return __builtin_bit_cast(bf16x8, v);
+    };
+    auto read_frags = [&](int buf, int kk, bf16x8 (&fy)[4], bf16x8 (&fx)[4]) {
+        const bf16* ys = ring + buf * WG2_STAGE;
+        const bf16* xs = ys + WG_MB * WG_T;
+#pragma unroll
+        for (int i = 0; i < 4; i++) fy[i] = tr_frag(ys, kk, wn0 + i * 16);
+#pragma unroll
+        for (int j = 0; j < 4; j++) fx[j] = tr_frag(xs, kk, wk0 + j * 16);
+    };
+    auto mfma_block = [&](const bf16x8 (&fy)[4], const bf16x8 (&fx)[4]) {
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fy[i], fx[j], acc[i][j], 0, 0, 0);
+        if (do_bias) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fy[i], ones, accb[i], 0, 0, 0);
+        }
+    };
+
+    const int nsteps = (mend - mbeg + WG_MB - 1) / WG_MB;
+    if (nsteps <= 0) return;
+    bf16x8 fy0[4], fx0[4], fy1[4], fx1[4];
+    issue(mbeg, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    read_frags(0, 0, fy0, fx0);
+    if (nsteps > 1) issue(mbeg + WG_MB, 1);
+    for (int st = 0; st < nsteps; st++) {
+        const int buf = st & 1;
+        read_frags(buf, 1, fy1, fx1);                                     // A
+        mfma_block(fy0, fx0);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // C: my DMA share of stage st+1 landed; my reads of buf done
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (st + 1 < nsteps) {                                            // D
+            read_frags(buf ^ 1, 0, fy0, fx0);
+            if (st + 2 < nsteps) issue(mbeg + (st + 2) * WG_MB, buf);
+        }
+        mfma_block(fy1, fx1);                                             // E
+    }
+    if (do_bias && li == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int n = n0 + wn0 + 16 * i + lg * 4 + r;
+                if (n < p.N) unsafeAtomicAdd(p.dB + n, accb[i][r]);
+            }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int k = k0 + wk0 + 16 * j + li;
+            if (k >= p.K) continue;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int n = n0 + wn0 + 16 * i + lg * 4 + r;
+                if (n >= p.N) continue;
+                const size_t e = (size_t)n * p.K + k;
+                if (p.nsplits == 1) p.dW[e] += acc[i][j][r];
+                else if (p.ws) p.ws[(size_t)split * p.N * p.K + e] = acc[i][j][r];
                 else unsafeAtomicAdd(p.dW + e, acc[i][j][r]);
             }
         }
@@ -1120,6 +1322,18 @@ static int launch_wgrad(WgradParams p, hipStream_t s) {
     }
     p.m_per_split = mps;
     p.nsplits = splits;
+    static const bool v2_on = !(getenv("SIDLSG_WGRAD_V2") && atoi(getenv("SIDLSG_WGRAD_V2")) == 0);
+    const bool aligned = !(p.N & 7) && !(p.K & 7) && !(p.ldy & 7) && !(p.lda & 7) && !(MODE == 1 && (p.Cin & 7)) &&
+                         !(((uintptr_t)p.dY | (uintptr_t)p.A) & 15);
+    if (v2_on && aligned) {
+        const size_t lds = (size_t)2 * WG2_STAGE * sizeof(bf16);
+        static bool attr_done = false;
+        if (!attr_done) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_v2_kernel<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            attr_done = true;
+        }
+        hipLaunchKernelGGL((wgrad_v2_kernel<MODE>), dim3(tiles * splits), dim3(NTHREADS), lds, s, p);
+    } else
     hipLaunchKernelGGL((wgrad_bf16_kernel<MODE>), dim3(tiles, splits), dim3(NTHREADS), 0, s, p);
     if (splits > 1 && p.ws)
         hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((nk / 4 + 256) / 256)), dim3(256), 0, s, p.ws, p.dW, (size_t)nk, splits);
@@ -1178,10 +1392,10 @@ int sidlsg_conv3x3_bf16(const void* X, int ldx, const void* W, void* Y, int ldc,
 }
 
 // dW[N][K] += dY[M][N]^T A[M][K]   (dense: Linear / 1x1 conv weight gradient; fp32 accumulate)
-int sidlsg_wgrad_bf16(const void* dY, int ldy, const void* A, int lda, float* dW, int M, int N, int K, void* stream) {
+int sidlsg_wgrad_bf16(const void* dY, int ldy, const void* A, int lda, float* dW, float* dBias, int M, int N, int K, void* stream) {
     if (M <= 0 || N <= 0 || K <= 0 || (K & 7) || (lda & 7) || !dY || !A || !dW) return SIDLSG_EINVAL;
     WgradParams p{};
-    p.dY = (const bf16*)dY; p.A = (const bf16*)A; p.dW = dW; p.M = M; p.N = N; p.K = K; p.ldy = ldy; p.lda = lda;
+    p.dY = (const bf16*)dY; p.A = (const bf16*)A; p.dW = dW; p.dB = dBias; p.M = M; p.N = N; p.K = K; p.ldy = ldy; p.lda = lda;
     const unsigned long long ab = ((unsigned long long)(M - 1) * lda + K) * 2ull, yb = ((unsigned long long)(M - 1) * ldy + N) * 2ull;
     if (!fits31(ab) || !fits31(yb)) return SIDLSG_EINVAL;
     p.a_bytes = (unsigned)ab; p.y_bytes = (unsigned)yb;
@@ -1189,11 +1403,11 @@ int sidlsg_wgrad_bf16(const void* dY, int ldy, const void* A, int lda, float* dW
 }
 
 // dW[Cout][3][3][Cin] += conv3x3 weight gradient (same geometry arguments as sidlsg_conv3x3_bf16)
-int sidlsg_conv3x3_wgrad_bf16(const void* dY, int ldy, const void* X, int ldx, float* dW, int B, int H, int Wd, int Cin,
-                              int Cout, int stride, int ups, void* stream) {
+int sidlsg_conv3x3_wgrad_bf16(const void* dY, int ldy, const void* X, int ldx, float* dW, float* dBias, int B, int H, int Wd,
+                              int Cin, int Cout, int stride, int ups, void* stream) {
     if ((stride != 1 && stride != 2) || (Cin & 7) || (ldx & 7) || !dY || !X || !dW) return SIDLSG_EINVAL;
     WgradParams p{};
-    p.dY = (const bf16*)dY; p.A = (const bf16*)X; p.dW = dW; p.ldy = ldy; p.lda = ldx;
+    p.dY = (const bf16*)dY; p.A = (const bf16*)X; p.dW = dW; p.dB = dBias; p.ldy = ldy; p.lda = ldx;
     p.H = H; p.Wd = Wd; p.Cin = Cin; p.stride = stride; p.ups = ups;
     p.Ho = (H + 2 - 3) / stride + 1; p.Wo = (Wd + 2 - 3) / stride + 1;
     p.M = B * p.Ho * p.Wo; p.N = Cout; p.K = 9 * Cin;

@@ -112,14 +112,17 @@ class _Linear(torch.autograd.Function):
         if dy.dtype != BF16:
             dy = dy.to(BF16)
         dx = gemm(dy, w16t) if ctx.needs_input_grad[0] else None
+        need_b = _wants_grad(bias)
+        need_rv = ctx.has_rv and ctx.needs_input_grad[6]
+        fused_b = need_b and not need_rv and _wants_grad(weight)    # bias gradient comes out of the wgrad kernel
         if _wants_grad(weight):
             M, K = x.shape
-            lib.sidlsg_wgrad_bf16(_p(dy), dy.stride(0), _p(x), x.stride(0), _p(weight.grad), M, weight.shape[0], K, _s())
+            lib.sidlsg_wgrad_bf16(_p(dy), dy.stride(0), _p(x), x.stride(0), _p(weight.grad), _p(bias.grad) if fused_b else None,
+                                  M, weight.shape[0], K, _s())
         drv = None
-        need_b = _wants_grad(bias)
-        if ctx.has_rv and ctx.needs_input_grad[6]:
+        if need_rv:
             drv = colsum(dy, ctx.rpb, per_batch=True, total=bias.grad if need_b else None)
-        elif need_b:
+        elif need_b and not fused_b:
             colsum(dy, dy.shape[0], total=bias.grad)
         dres = dy if (ctx.has_res and ctx.needs_input_grad[5]) else None
         return dx, None, None, None, None, dres, drv, None, None
@@ -163,25 +166,28 @@ class _Conv3x3(torch.autograd.Function):
                 lib.sidlsg_sumpool2x2(_p(full), _p(dx), B, x.shape[1], x.shape[2], Cin, _s())
         co_w, ci_w = weight.shape[0], weight.shape[1]     # logical (unpadded) sizes of the master
         padded = (co_w != Cout) or (ci_w != Cin)           # conv_in (Cin 4->8) / conv_out (Cout 4->8)
+        need_b = _wants_grad(bias)
+        need_rv = has_rv and ctx.needs_input_grad[6]
+        fused_b = need_b and not need_rv and not padded and _wants_grad(weight)   # bias gradient from the wgrad kernel
         if _wants_grad(weight):
             H, W = (2 * x.shape[1], 2 * x.shape[2]) if ups else (x.shape[1], x.shape[2])
             if not padded:
-                lib.sidlsg_conv3x3_wgrad_bf16(_p(dy), Cout, _p(x), Cin, _p(weight.grad), B, H, W, Cin, Cout, stride, ups, _s())
+                lib.sidlsg_conv3x3_wgrad_bf16(_p(dy), Cout, _p(x), Cin, _p(weight.grad), _p(bias.grad) if fused_b else None,
+                                              B, H, W, Cin, Cout, stride, ups, _s())
             else:
                 tmp = torch.zeros((Cout, 9, Cin), device=dy.device, dtype=F32)
-                lib.sidlsg_conv3x3_wgrad_bf16(_p(dy), Cout, _p(x), Cin, _p(tmp), B, H, W, Cin, Cout, stride, ups, _s())
+                lib.sidlsg_conv3x3_wgrad_bf16(_p(dy), Cout, _p(x), Cin, _p(tmp), None, B, H, W, Cin, Cout, stride, ups, _s())
                 weight.grad.permute(0, 2, 3, 1).reshape(co_w, 9, ci_w).add_(tmp[:co_w, :, :ci_w])
         dy2 = dy.view(B * Ho * Wo, Cout)
         drv = None
-        need_b = _wants_grad(bias)
         btot = None
-        if need_b:
+        if need_b and not fused_b:
             btot = bias.grad if co_w == Cout else torch.zeros(Cout, device=dy.device, dtype=F32)
-        if has_rv and ctx.needs_input_grad[6]:
+        if need_rv:
             drv = colsum(dy2, Ho * Wo, per_batch=True, total=btot)
-        elif need_b:
+        elif need_b and not fused_b:
             colsum(dy2, dy2.shape[0], total=btot)
-        if need_b and co_w != Cout:
+        if need_b and not fused_b and co_w != Cout:
             bias.grad.add_(btot[:co_w])
         dres = dy if (has_res and ctx.needs_input_grad[5]) else None
         return dx, None, None, None, None, dres, drv, None, None, None, None
@@ -514,6 +520,11 @@ def transpose_w(src_f32, n, k, taps=1):
     dst = torch.empty((k, taps * n), device=src_f32.device, dtype=BF16)
     lib.sidlsg_transpose_w(_p(src_f32), _p(dst), n, k, taps, _s())
     return dst
+
+
+def transpose_w_batched(jobs, njobs, nblocks):
+    """jobs: device uint8 tensor holding njobs sidlsg_tw_job records (see include/sidlsg_hip.h)."""
+    lib.sidlsg_transpose_w_batched(_p(jobs), njobs, nblocks, _s())
 
 
 def cast_bf16(src_f32, out=None):

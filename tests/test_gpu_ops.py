@@ -93,9 +93,14 @@ def test_wgrad_dense(dev, M, N, K):
     dy, a = rnd(M, N, seed=1), rnd(M, K, seed=2)
     ref = dy.float().t() @ a.float()
     dw = torch.full((N, K), 0.5, device=dev, dtype=F32)          # accumulates into existing content
+    db = torch.full((N,), 0.25, device=dev, dtype=F32)           # fused bias gradient, also accumulating
     dyd, ad = dy.to(dev), a.to(dev)
-    lib.sidlsg_wgrad_bf16(_p(dyd), N, _p(ad), K, _p(dw), M, N, K, _s())
+    lib.sidlsg_wgrad_bf16(_p(dyd), N, _p(ad), K, _p(dw), _p(db), M, N, K, _s())
     close(dw - 0.5, ref, 2e-3, 'wgrad')
+    close(db - 0.25, dy.float().sum(0), 2e-3, 'fused bias grad')
+    dw2 = torch.zeros((N, K), device=dev, dtype=F32)
+    lib.sidlsg_wgrad_bf16(_p(dyd), N, _p(ad), K, _p(dw2), None, M, N, K, _s())      # NULL dBias
+    close(dw2, ref, 2e-3, 'wgrad (no bias)')
 
 
 @pytest.mark.parametrize('B,H,W,Cin,Cout,stride,ups', CONV_CASES)

@@ -76,12 +76,14 @@ def bench_wgrad(B):
     for M, N, K in ((B * 4096, 320, 320), (B * 4096, 2560, 320), (B * 1024, 640, 2560), (B * 256, 1280, 1280)):
         dy, a = r(M, N), r(M, K)
         dw = torch.zeros(N, K, device=dev)
-        t = timeit(lambda: lib.sidlsg_wgrad_bf16(dy.data_ptr(), N, a.data_ptr(), K, dw.data_ptr(), M, N, K, ops._s()))
+        db = torch.zeros(N, device=dev)
+        t = timeit(lambda: lib.sidlsg_wgrad_bf16(dy.data_ptr(), N, a.data_ptr(), K, dw.data_ptr(), db.data_ptr(), M, N, K, ops._s()))
         print(f'  dense {M}x{N}x{K}: {t * 1e6:8.1f} us  {2.0 * M * N * K / t / 1e12:7.1f} TF/s')
     for H, cin, cout in ((64, 320, 320), (32, 640, 640), (16, 1280, 1280), (32, 1920, 640)):
         x, dy = r(B, H, H, cin), r(B, H, H, cout)
         dw = torch.zeros(cout, 9 * cin, device=dev)
-        t = timeit(lambda: lib.sidlsg_conv3x3_wgrad_bf16(dy.data_ptr(), cout, x.data_ptr(), cin, dw.data_ptr(), B, H, H, cin, cout, 1, 0, ops._s()))
+        db = torch.zeros(cout, device=dev)
+        t = timeit(lambda: lib.sidlsg_conv3x3_wgrad_bf16(dy.data_ptr(), cout, x.data_ptr(), cin, dw.data_ptr(), db.data_ptr(), B, H, H, cin, cout, 1, 0, ops._s()))
         print(f'  conv {H}x{H} {cin}->{cout}: {t * 1e6:8.1f} us  {2.0 * B * H * H * cout * 9 * cin / t / 1e12:7.1f} TF/s')
 
 
