@@ -616,6 +616,18 @@ static int launch_gemm_v2(const GemmParams& p, hipStream_t s) {
 //   C: s_waitcnt vmcnt(0) (this wave's DMA of tile kt+1 has landed) ; s_barrier
 //   D: issue the kk=0 fragment reads of tile kt+1 and the DMA of tile kt+2 into the buffer just vacated
 //   E: kk=1 MFMAs (cover D's latencies)
+// W-tile LDS swizzle (16-byte chunk index ^= wsw(row)).  A ds_read_b128 is serviced in the lane groups
+// {0-3,12-15,20-27}, {4-11,16-19,28-31}, ... (MI355X guide, LDS table), and the W fragment rows of a paired (ni, ni+1)
+// column block are li -> 8*(li>>2) + (li&3): with the plain (row>>1)&7 swizzle the lg=0 and lg=1 lanes of one group
+// collide 2-way (measured: SQ_LDS_BANK_CONFLICT = 31 % of SQ_LDS_IDX_ACTIVE).  For those rows use
+// (q&1) | ((q>>2)&3)<<1 with q = row>>1, which makes the 16 lanes of every group hit 16 distinct 16-byte slots; the
+// trailing unpaired 16-row block (rows 64..79 of each wave's 80) keeps the plain swizzle.
+DEVFN int wsw(int r) {
+    const int rr = r >= 80 ? r - 80 : r;
+    const int q = r >> 1;
+    return rr < 64 ? ((q & 1) | (((q >> 2) & 3) << 1)) : (q & 7);
+}
+
 template <int MODE>   // 0 dense, 1 conv3x3 with Cin % 64 == 0
 __global__ __launch_bounds__(NTHREADS, 2) void gemm_v3_kernel(GemmParams p) {
     constexpr int BM = 128, BN = 160, MT = 4, NT = 5;
@@ -638,13 +650,16 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_v3_kernel(GemmParams p) {
     const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 80;
     const int li = lane & 15, lg = lane >> 4;
     const int lrow = lane >> 3, lslot = lane & 7;
-    const char* zero = reinterpret_cast<const char*>(g_zero_page);
 
+    // Loader: buffer_load_dwordx4 ... lds.  Per row ONE 32-bit byte offset (VGPR) that already contains the lane's
+    // swizzled chunk; the K position of the tile is the wave-uniform soffset.  Invalid rows (m >= M, n >= N, conv halo)
+    // carry an out-of-range offset and the buffer unit writes zeros: no pointer arithmetic, selects or zero page in the
+    // steady state (the 64-bit global_load_lds version issued ~150 VALU+SALU per 40 MFMAs).
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(p.A), 0, (int)p.a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(p.W), 0, (int)p.w_bytes, 0x00020000);
     const int Hs = p.ups ? (p.H >> 1) : p.H, Ws = p.ups ? (p.Wd >> 1) : p.Wd;
-    const char* abase[4];
+    unsigned abase[4], aoff[4];
     int ahi[4], awi[4];
-    const char* arow[4];
-    bool aval[4];
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         const int r = wave * 32 + j * 8 + lrow;
@@ -652,72 +667,76 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_v3_kernel(GemmParams p) {
         const int m = m0 + r;
         const bool ok = m < p.M;
         if (MODE == 0) {
-            abase[j] = reinterpret_cast<const char*>(p.A) + ((size_t)(ok ? m : 0) * p.lda + kcs * 8) * 2;
-            aval[j] = ok; arow[j] = abase[j]; ahi[j] = awi[j] = 0;
+            aoff[j] = ok ? ((unsigned)m * (unsigned)p.lda + kcs * 8) * 2u : OOB;
+            abase[j] = 0; ahi[j] = awi[j] = 0;
         } else {
             const int mm = ok ? m : 0;
             const int hw = p.Ho * p.Wo;
             const int b = mm / hw, rem = mm - b * hw;
             const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
-            abase[j] = reinterpret_cast<const char*>(p.A) + ((size_t)b * Hs * Ws * p.lda + kcs * 8) * 2;
+            abase[j] = ((unsigned)(b * Hs * Ws) * (unsigned)p.lda + kcs * 8) * 2u;
             ahi[j] = ok ? ho * p.stride - 1 : -100000;
             awi[j] = wo * p.stride - 1;
-            aval[j] = false; arow[j] = zero;
+            aoff[j] = OOB;
         }
     }
-    const char* bbase[5];
-    bool bval[5];
+    unsigned boff[5];
 #pragma unroll
     for (int j = 0; j < 5; j++) {
         const int g = wave + 4 * j;                 // 20 groups of 8 weight rows, 5 per wave
         const int r = g * 8 + lrow;
-        const int kcs = lslot ^ ((r >> 1) & 7);
+        const int kcs = lslot ^ wsw(r);
         const int n = n0 + r;
-        bval[j] = n < p.N;
-        bbase[j] = reinterpret_cast<const char*>(p.W) + ((size_t)(bval[j] ? n : 0) * p.K + kcs * 8) * 2;
+        boff[j] = n < p.N ? ((unsigned)n * (unsigned)p.K + kcs * 8) * 2u : OOB;
     }
     const int nk_all = (p.K + BK - 1) / BK;
     const int kt_begin = p.kt_per_split ? blockIdx.y * p.kt_per_split : 0;
     const int nk = p.kt_per_split ? min(nk_all, kt_begin + p.kt_per_split) : nk_all;
     int cur_tap = -1;
 
-    auto issue = [&](int t, int buf) {          // 9 global_load_lds per wave
+    auto issue = [&](int t, int buf) {          // 9 buffer_load ... lds per wave
         bf16* sa = ring + buf * STAGE;
         bf16* sb = sa + BM * BK;
         const int k0 = t * BK;
-        int c0 = 0;
+        int asoff = k0 * 2;
         if (MODE == 1) {
             const int tap = k0 / p.Cin;
-            c0 = k0 - tap * p.Cin;
-            if (tap != cur_tap) {
+            asoff = (k0 - tap * p.Cin) * 2;
+            if (tap != cur_tap) {               // every Cin/64 tiles: new tap -> new row offsets / halo mask
                 cur_tap = tap;
                 const int dh = tap / 3, dw = tap - dh * 3;
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
                     int hi = ahi[j] + dh, wi = awi[j] + dw;
-                    aval[j] = hi >= 0 && hi < p.H && wi >= 0 && wi < p.Wd;
+                    const bool v = hi >= 0 && hi < p.H && wi >= 0 && wi < p.Wd;
                     if (p.ups) { hi >>= 1; wi >>= 1; }
-                    arow[j] = abase[j] + (size_t)(hi * Ws + wi) * p.lda * 2;
+                    aoff[j] = v ? abase[j] + (unsigned)(hi * Ws + wi) * (unsigned)p.lda * 2u : OOB;
                 }
             }
         }
+        if (MODE == 0 && k0 + BK > p.K) {       // ragged K tail (dense only): chunks past K must read zeros
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const int r = wave * 32 + j * 8 + lrow;
-            const int kcs = lslot ^ ((r >> 1) & 7);
-            const bool kok = k0 + kcs * 8 < p.K;
-            const char* src = (aval[j] && kok) ? arow[j] + (size_t)(MODE == 0 ? k0 : c0) * 2 : zero;
-            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sa + (wave * 32 + j * 8) * BK), 16, 0, 0);
+            for (int j = 0; j < 4; j++) {
+                const int r = wave * 32 + j * 8 + lrow;
+                const int kcs = lslot ^ ((r >> 1) & 7);
+                const unsigned o = (k0 + kcs * 8 < p.K) ? aoff[j] : OOB;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lptr_t)(sa + (wave * 32 + j * 8) * BK), 16, o, asoff, 0, 0);
+            }
+#pragma unroll
+            for (int j = 0; j < 5; j++) {
+                const int g = wave + 4 * j;
+                const int kcs = lslot ^ wsw(g * 8 + lrow);
+                const unsigned o = (k0 + kcs * 8 < p.K) ? boff[j] : OOB;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lptr_t)(sb + g * 8 * BK), 16, o, k0 * 2, 0, 0);
+            }
+            return;
         }
 #pragma unroll
-        for (int j = 0; j < 5; j++) {
-            const int g = wave + 4 * j;
-            const int r = g * 8 + lrow;
-            const int kcs = lslot ^ ((r >> 1) & 7);
-            const bool kok = k0 + kcs * 8 < p.K;
-            const char* src = (bval[j] && kok) ? bbase[j] + (size_t)k0 * 2 : zero;
-            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sb + g * 8 * BK), 16, 0, 0);
-        }
+        for (int j = 0; j < 4; j++)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lptr_t)(sa + (wave * 32 + j * 8) * BK), 16, aoff[j], asoff, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 5; j++)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lptr_t)(sb + (wave + 4 * j) * 8 * BK), 16, boff[j], k0 * 2, 0, 0);
     };
 
     f32x4 acc[NT][MT];
@@ -743,7 +762,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_v3_kernel(GemmParams p) {
 #pragma unroll
         for (int ni = 0; ni < NT; ni++) {
             const int r = wrow[ni];
-            fw[ni] = *reinterpret_cast<const bf16x8*>(b + r * BK + ((ch ^ ((r >> 1) & 7)) << 3));
+            fw[ni] = *reinterpret_cast<const bf16x8*>(b + r * BK + ((ch ^ wsw(r)) << 3));
         }
     };
     auto mfma_block = [&](const bf16x8 (&fa)[MT], const bf16x8 (&fw)[NT]) {
@@ -1129,8 +1148,6 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad_v2_kernel(WgradParams p) {
     const int wn0 = (wave >> 1) * 64, wk0 = (wave & 1) * 64;
     const int q16 = tid & 15, r0 = tid >> 4;            // LDS chunk position and first row of this lane
     const int c16 = (((q16 >> 1) ^ wg_swz(r0)) << 1) | (q16 & 1);   // source chunk (wg_swz(r0 + 16 i) == wg_swz(r0))
-    const char* zero = reinterpret_cast<const char*>(g_zero_page);
-
     const int kA = k0 + c16 * 8;
     const bool kok = kA < p.K;
     int cA = kA, dh = 0, dw = 0;
@@ -1139,8 +1156,17 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad_v2_kernel(WgradParams p) {
     const bool nok = nY < p.N;
     const int Hs = p.ups ? (p.H >> 1) : p.H, Ws = p.ups ? (p.Wd >> 1) : p.Wd;
     const int hw = (MODE == 1) ? p.Ho * p.Wo : 1;
-    const char* ybase = reinterpret_cast<const char*>(p.dY) + (size_t)nY * 2;
-    const char* xbase = reinterpret_cast<const char*>(p.A) + (size_t)cA * 2;
+    // buffer_load ... lds with one 32-bit byte offset per row; rows past the split / columns past N,K / the conv halo
+    // carry an out-of-range offset (the buffer unit writes zeros).  dY and dense X advance by a wave-uniform soffset.
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(p.dY), 0, (int)p.y_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(p.A), 0, (int)p.a_bytes, 0x00020000);
+    unsigned yoff[4], xoff[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const unsigned m = (unsigned)(mbeg + r0 + 16 * i);
+        yoff[i] = nok ? (m * (unsigned)p.ldy + (unsigned)nY) * 2u : OOB;
+        xoff[i] = (MODE == 0 && kok) ? (m * (unsigned)p.lda + (unsigned)kA) * 2u : OOB;
+    }
 
     int pb[4], pho[4], pwo[4];
     const int d_b = WG_MB / hw, d_rem = WG_MB - d_b * hw;
@@ -1158,28 +1184,27 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad_v2_kernel(WgradParams p) {
     auto issue = [&](int mb, int buf) {      // called with mb = mbeg, mbeg + WG_MB, ... in order; 8 DMA instructions per wave
         bf16* ys = ring + buf * WG2_STAGE;
         bf16* xs = ys + WG_MB * WG_T;
+        const int ysoff = (mb - mbeg) * p.ldy * 2, xsoff = (mb - mbeg) * p.lda * 2;
+        const bool tail = mb + WG_MB > mend;          // only the last stage of a split has rows past mend
 #pragma unroll
         for (int i = 0; i < 4; i++) {
-            const int m = mb + r0 + 16 * i;
-            const bool mok = m < mend;
-            const char* ysrc = (mok && nok) ? ybase + (size_t)m * p.ldy * 2 : zero;
-            __builtin_amdgcn_global_load_lds((gptr_t)ysrc, (lptr_t)(ys + (4 * wave + 16 * i) * WG_T), 16, 0, 0);
-            const char* xsrc;
+            const bool mok = !tail || (mb + r0 + 16 * i < mend);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ry, (lptr_t)(ys + (4 * wave + 16 * i) * WG_T), 16, mok ? yoff[i] : OOB, ysoff, 0, 0);
             if (MODE == 0) {
-                xsrc = (mok && kok) ? xbase + (size_t)m * p.lda * 2 : zero;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lptr_t)(xs + (4 * wave + 16 * i) * WG_T), 16, mok ? xoff[i] : OOB, xsoff, 0, 0);
             } else {
                 bool ok = kok && mok;
                 const int b = pb[i], ho = pho[i], wo = pwo[i];
                 int hi = ho * p.stride - 1 + dh, wi = wo * p.stride - 1 + dw;
                 ok = ok && hi >= 0 && hi < p.H && wi >= 0 && wi < p.Wd;
                 if (p.ups) { hi >>= 1; wi >>= 1; }
-                xsrc = ok ? xbase + (size_t)(((unsigned)(b * Hs + hi) * (unsigned)Ws + (unsigned)wi) * (unsigned)p.lda) * 2 : zero;
+                const unsigned o = ok ? (((unsigned)(b * Hs + hi) * (unsigned)Ws + (unsigned)wi) * (unsigned)p.lda + (unsigned)cA) * 2u : OOB;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lptr_t)(xs + (4 * wave + 16 * i) * WG_T), 16, o, 0, 0, 0);
                 int nwo = wo + d_wo, nho = ho + d_ho, nb = b + d_b;
                 if (nwo >= p.Wo) { nwo -= p.Wo; nho += 1; }
                 if (nho >= p.Ho) { nho -= p.Ho; nb += 1; }
                 pwo[i] = nwo; pho[i] = nho; pb[i] = nb;
             }
-            __builtin_amdgcn_global_load_lds((gptr_t)xsrc, (lptr_t)(xs + (4 * wave + 16 * i) * WG_T), 16, 0, 0);
         }
     };
 
