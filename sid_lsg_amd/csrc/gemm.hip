@@ -22,6 +22,7 @@
 // pixel: the epilogue stores 16 bytes per lane.
 #include "common.h"
 #include <stdlib.h>
+#include <algorithm>
 
 struct GemmParams {
     const bf16* A;        // dense: [M][lda]; conv: NHWC image [B][Hs][Ws][ldx]
@@ -1323,8 +1324,21 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restr
 template <int MODE>
 static int launch_wgrad(WgradParams p, hipStream_t s) {
     const int tiles = ((p.N + WG_T - 1) / WG_T) * ((p.K + WG_T - 1) / WG_T);
-    // split the pixel contraction so the grid fills the chip (256 CUs, 2 blocks each)
-    int splits = (768 + tiles - 1) / tiles;
+    // Split the pixel contraction so the grid fills the chip in whole rounds of 512 resident blocks (256 CUs x 2).
+    // Small cost model (us): rounds * (rows per block * 24 ns + 3 us block overhead) + slab reduction at ~4 TB/s;
+    // e.g. 69 tiles: ceil(768/69) = 12 splits ran 1.6 rounds, the model picks a whole number of rounds.
+    int splits = 1;
+    {
+        const int cap = std::min(64, (p.M + 4 * WG_MB - 1) / (4 * WG_MB));
+        double best = 1e30;
+        const double slab_us = (double)p.N * p.K * 4.0 / 4e6;
+        for (int sp = 1; sp <= cap; sp++) {
+            const int rounds = (sp * tiles + 511) / 512;
+            const double rows = (double)((p.M + sp - 1) / sp);
+            const double est = rounds * (rows * 0.024 + 3.0) + (sp > 1 ? sp * slab_us : 0.0);
+            if (est < best) { best = est; splits = sp; }
+        }
+    }
     const int max_splits = (p.M + 4 * WG_MB - 1) / (4 * WG_MB);
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
