@@ -127,11 +127,16 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X: the product path has no CPU fallback')
+    # test hook (1-GPU boxes): SIDLSG_BENCH_SHARE_GPU=1 puts every rank on cuda:0 and uses gloo for the exchange, so the
+    # whole multi-rank control flow (reducer, barriers, max-over-ranks timing) can be exercised without a second GPU
+    share = os.environ.get('SIDLSG_BENCH_SHARE_GPU', '0') == '1'
+    if share:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     if world > 1:
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        torch.distributed.init_process_group('nccl', init_method='env://')
+        torch.distributed.init_process_group('gloo' if share else 'nccl', init_method='env://')
     assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
 
     from sid_lsg_amd._lib import lib
