@@ -836,6 +836,301 @@ static int launch_gemm_v3(const GemmParams& p, hipStream_t s) {
     return sidlsg_last_error();
 }
 
+// ---------------------------------------------------------------------------------------------
+// "v5": 256 x 160 x 64 tile, 4 waves, ONE wave per SIMD (512 registers), 32x32x16 MFMA.  Wave w owns rows
+// [64w, 64w+64) x all 160 columns = 2 x 5 MFMA blocks (160 accumulator registers): per K=16 step it reads 2 A + 5 W
+// fragments for 10 MFMAs of 32 cycles -- 22 % less LDS traffic per MFMA cycle than the 64x80 wave tile of v3, a W tile
+// shared by 256 rows (28 % less L2->LDS traffic), and every phase overlapped INSIDE the wave: fragment reads and the
+// DMA are spread between the MFMAs with sched_group_barrier (v3 relies on the second block of the CU for overlap, and
+// its ablations show the LDS, DMA and MFMA phases adding up instead).  Same loader as v3 (buffer_load ... lds, one
+// 32-bit offset per row), 2 LDS stages of 52 KiB, one barrier per K-tile in the middle of the tile:
+//   steps 0,1 (MFMA) | reads of steps 1,2,3          -> s_waitcnt vmcnt(0) ; s_barrier  (tile kt+1 landed, tile kt read)
+//   steps 2,3 (MFMA) | reads of step 0 of tile kt+1, DMA of tile kt+2 into the buffer just vacated
+// Epilogue: the 32x32 accumulator holds 4-channel runs interleaved between lanes l and l+32; v_permlane32_swap turns
+// them into 8-channel runs so that every lane stores 16 bytes.
+constexpr int V5_BM = 256, V5_BN = 160;
+constexpr int V5_STAGE = (V5_BM + V5_BN) * BK;
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// one 8-channel run of the output row m (N % 8 == 0 guaranteed by the dispatcher): same semantics as gemm_epilogue
+DEVFN void epilogue_run8(const GemmParams& p, int m, int n, float (&v)[8]) {
+    float bb[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (p.bias) {
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.bias + n), b1 = *reinterpret_cast<const f32x4*>(p.bias + n + 4);
+#pragma unroll
+        for (int e = 0; e < 4; e++) { bb[e] = b0[e]; bb[4 + e] = b1[e]; }
+    }
+    if (p.rowvec) {
+        const float* rv = p.rowvec + (size_t)(m / p.rows_per_batch) * p.N + n;
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(rv), b1 = *reinterpret_cast<const f32x4*>(rv + 4);
+#pragma unroll
+        for (int e = 0; e < 4; e++) { bb[e] += b0[e]; bb[4 + e] += b1[e]; }
+    }
+    if (p.res) {
+        const bf16x8 t = ld8(p.res + (size_t)m * p.ldres + n);
+#pragma unroll
+        for (int e = 0; e < 8; e++) bb[e] += bf2f(t[e]);
+    }
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+        float x = v[e] * p.alpha + bb[e];
+        if (p.flags & F_SILU) x = silu_f(x);
+        v[e] = x;
+    }
+    if (p.flags & F_OUT_F32) {
+        float* c = reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n;
+        if (p.flags & F_ACCUM) {
+#pragma unroll
+            for (int e = 0; e < 8; e++) c[e] += v[e];
+        } else {
+            *reinterpret_cast<f32x4*>(c) = (f32x4){v[0], v[1], v[2], v[3]};
+            *reinterpret_cast<f32x4*>(c + 4) = (f32x4){v[4], v[5], v[6], v[7]};
+        }
+    } else {
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; e++) o[e] = f2bf(v[e]);
+        st8(reinterpret_cast<bf16*>(p.C) + (size_t)m * p.ldc + n, o);
+    }
+}
+
+template <int MODE>   // 0 dense, 1 conv3x3 with Cin % 64 == 0
+__global__ __launch_bounds__(256, 1) void gemm_v5_kernel(GemmParams p) {
+    constexpr int MB = 2, NB = 5;          // 32x32 blocks per wave
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    bf16* ring = reinterpret_cast<bf16*>(smem);
+
+    const int tiles_n = (p.N + V5_BN - 1) / V5_BN;
+    const int tiles_m = (p.M + V5_BM - 1) / V5_BM;
+    const int nblk = tiles_n * tiles_m;
+    int bid = blockIdx.x;
+    {
+        const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int m0 = (bid / tiles_n) * V5_BM;
+    const int n0 = (bid % tiles_n) * V5_BN;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm0 = wave * 64;
+    const int l32 = lane & 31, lh = lane >> 5;
+    const int lrow = lane >> 3, lslot = lane & 7;
+
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(p.A), 0, (int)p.a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(p.W), 0, (int)p.w_bytes, 0x00020000);
+    const int Hs = p.ups ? (p.H >> 1) : p.H, Ws = p.ups ? (p.Wd >> 1) : p.Wd;
+    // A: wave w stages its own 64 rows (8 loads of 8 rows); W: 20 groups of 8 rows, 5 per wave
+    unsigned abase[8], aoff[8], boff[5];
+    int ahi[8], awi[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const int r = wm0 + j * 8 + lrow;
+        const int kcs = lslot ^ ((r >> 1) & 7);
+        const int m = m0 + r;
+        const bool ok = m < p.M;
+        if (MODE == 0) {
+            aoff[j] = ok ? ((unsigned)m * (unsigned)p.lda + kcs * 8) * 2u : OOB;
+            abase[j] = 0; ahi[j] = awi[j] = 0;
+        } else {
+            const int mm = ok ? m : 0;
+            const int hw = p.Ho * p.Wo;
+            const int b = mm / hw, rem = mm - b * hw;
+            const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+            abase[j] = ((unsigned)(b * Hs * Ws) * (unsigned)p.lda + kcs * 8) * 2u;
+            ahi[j] = ok ? ho * p.stride - 1 : -100000;
+            awi[j] = wo * p.stride - 1;
+            aoff[j] = OOB;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 5; j++) {
+        const int r = (wave + 4 * j) * 8 + lrow;
+        const int kcs = lslot ^ ((r >> 1) & 7);
+        const int n = n0 + r;
+        boff[j] = n < p.N ? ((unsigned)n * (unsigned)p.K + kcs * 8) * 2u : OOB;
+    }
+    const int nk = (p.K + BK - 1) / BK;
+    int cur_tap = -1;
+    unsigned ao[8], bo[5];
+    int asoff = 0, bsoff = 0;
+    auto prepare = [&](int t) {      // offsets of K-tile t (branchy but rare); past the end: all out of range (zeros)
+        const int k0 = t * BK;
+        if (t >= nk) {
+#pragma unroll
+            for (int j = 0; j < 8; j++) ao[j] = OOB;
+#pragma unroll
+            for (int j = 0; j < 5; j++) bo[j] = OOB;
+            asoff = bsoff = 0;
+            return;
+        }
+        asoff = k0 * 2; bsoff = k0 * 2;
+        if (MODE == 1) {
+            const int tap = k0 / p.Cin;
+            asoff = (k0 - tap * p.Cin) * 2;
+            if (tap != cur_tap) {
+                cur_tap = tap;
+                const int dh = tap / 3, dw = tap - dh * 3;
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    int hi = ahi[j] + dh, wi = awi[j] + dw;
+                    const bool v = hi >= 0 && hi < p.H && wi >= 0 && wi < p.Wd;
+                    if (p.ups) { hi >>= 1; wi >>= 1; }
+                    aoff[j] = v ? abase[j] + (unsigned)(hi * Ws + wi) * (unsigned)p.lda * 2u : OOB;
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; j++) ao[j] = aoff[j];
+#pragma unroll
+        for (int j = 0; j < 5; j++) bo[j] = boff[j];
+        if (MODE == 0 && k0 + BK > p.K) {       // ragged K tail (dense only)
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const int r = wm0 + j * 8 + lrow;
+                if (k0 + (lslot ^ ((r >> 1) & 7)) * 8 >= p.K) ao[j] = OOB;
+            }
+#pragma unroll
+            for (int j = 0; j < 5; j++) {
+                const int r = (wave + 4 * j) * 8 + lrow;
+                if (k0 + (lslot ^ ((r >> 1) & 7)) * 8 >= p.K) bo[j] = OOB;
+            }
+        }
+    };
+    auto fire = [&](int buf) {       // 13 buffer_load ... lds, branch-free
+        bf16* sa = ring + buf * V5_STAGE;
+        bf16* sb = sa + V5_BM * BK;
+#pragma unroll
+        for (int j = 0; j < 8; j++)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lptr_t)(sa + (wm0 + j * 8) * BK), 16, ao[j], asoff, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 5; j++)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lptr_t)(sb + (wave + 4 * j) * 8 * BK), 16, bo[j], bsoff, 0, 0);
+    };
+
+    f32x16 acc[NB][MB];
+#pragma unroll
+    for (int i = 0; i < NB; i++)
+#pragma unroll
+        for (int j = 0; j < MB; j++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) acc[i][j][e] = 0.f;
+
+    // fragment of K=16 step s: lane (l32, lh) reads row l32 (+32 per block), 16-byte chunk 2s + lh, swizzled with (row>>1)&7
+    // (rows of all blocks of a lane differ by multiples of 32, so one swizzle value per lane)
+    const int xs = lh ^ ((l32 >> 1) & 7);
+    struct Frags { bf16x8 a[MB], w[NB]; };
+    auto read_step = [&](int buf, int st, Frags& f) {
+        const bf16* a = ring + buf * V5_STAGE + (wm0 + l32) * BK + ((xs ^ (2 * st)) << 3);
+        const bf16* b = ring + buf * V5_STAGE + V5_BM * BK + l32 * BK + ((xs ^ (2 * st)) << 3);
+#pragma unroll
+        for (int mi = 0; mi < MB; mi++) f.a[mi] = *reinterpret_cast<const bf16x8*>(a + mi * 32 * BK);
+#pragma unroll
+        for (int nb = 0; nb < NB; nb++) f.w[nb] = *reinterpret_cast<const bf16x8*>(b + nb * 32 * BK);
+    };
+    auto mfma_step = [&](const Frags& f) {
+#pragma unroll
+        for (int nb = 0; nb < NB; nb++)
+#pragma unroll
+            for (int mi = 0; mi < MB; mi++)
+                acc[nb][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.w[nb], f.a[mi], acc[nb][mi], 0, 0, 0);
+    };
+
+    Frags f0, f1, f2, f3;
+    prepare(0);
+    fire(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    read_step(0, 0, f0);
+    prepare(1);
+    fire(1);
+    for (int kt = 0; kt < nk; kt++) {
+        const int buf = kt & 1;
+        prepare(kt + 2);
+        __builtin_amdgcn_sched_barrier(0);
+        // steps 0,1 | reads of steps 1,2,3 (21 ds_read_b128 spread over 20 MFMAs)
+        mfma_step(f0);
+        read_step(buf, 1, f1);
+        mfma_step(f1);
+        read_step(buf, 2, f2);
+        read_step(buf, 3, f3);
+#pragma unroll
+        for (int i = 0; i < 7; i++) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+#pragma unroll
+        for (int i = 0; i < 7; i++) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");    // tile kt+1 landed; my reads of tile kt are done
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        // steps 2,3 | reads of step 0 of tile kt+1 (stale data past the last tile, never used), DMA of tile kt+2
+        mfma_step(f2);
+        read_step(buf ^ 1, 0, f0);
+        mfma_step(f3);
+        fire(buf);
+#pragma unroll
+        for (int i = 0; i < 7; i++) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 1);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 3, 1);
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
+            __builtin_amdgcn_sched_group_barrier(0x020, 2, 1);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 1);
+        __builtin_amdgcn_sched_group_barrier(0x008, 3, 1);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the trailing dummy loads before the LDS is released
+
+    // ---- epilogue.  acc[nb][mi][4j+e] = C[m = .. + 32 mi + l32][n = .. + 32 nb + 8 j + 4 lh + e]
+#pragma unroll
+    for (int mi = 0; mi < MB; mi++) {
+        const int m = m0 + wm0 + 32 * mi + l32;
+#pragma unroll
+        for (int nb = 0; nb < NB; nb++) {
+            float va[8], vb[8];
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                // (j=0, j=2) -> lanes < 32: channels e, 4+e ; lanes >= 32: 16+e, 20+e
+                const auto s02 = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[nb][mi][e]), __float_as_uint(acc[nb][mi][8 + e]), false, false);
+                va[e] = __uint_as_float(s02[0]); va[4 + e] = __uint_as_float(s02[1]);
+                // (j=1, j=3) -> lanes < 32: 8+e, 12+e ; lanes >= 32: 24+e, 28+e
+                const auto s13 = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[nb][mi][4 + e]), __float_as_uint(acc[nb][mi][12 + e]), false, false);
+                vb[e] = __uint_as_float(s13[0]); vb[4 + e] = __uint_as_float(s13[1]);
+            }
+            if (m < p.M) {
+                const int n = n0 + 32 * nb + 16 * lh;
+                epilogue_run8(p, m, n, va);
+                epilogue_run8(p, m, n + 8, vb);
+            }
+        }
+    }
+}
+
+template <int MODE>
+static int launch_gemm_v5(const GemmParams& p, hipStream_t s) {
+    const int tiles = ((p.M + V5_BM - 1) / V5_BM) * ((p.N + V5_BN - 1) / V5_BN);
+    const size_t lds = (size_t)2 * V5_STAGE * sizeof(bf16);
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_v5_kernel<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((gemm_v5_kernel<MODE>), dim3(tiles), dim3(256), lds, s, p);
+    return sidlsg_last_error();
+}
+
 template <int BM, int BN, int MODE, int VAR = 0>
 static int launch_gemm(const GemmParams& p, hipStream_t s) {
     const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
@@ -897,6 +1192,8 @@ static int dispatch_gemm(const GemmParams& p, hipStream_t s) {
             }
         }
     }
+    static const int v5_min = getenv("SIDLSG_GEMM_V5_MIN_TILES") ? atoi(getenv("SIDLSG_GEMM_V5_MIN_TILES")) : 0;   // 0 = off
+    if (v5_min > 0 && n160 && MODE != 2 && !(p.N & 7) && tiles(V5_BM, V5_BN) >= v5_min) return launch_gemm_v5<MODE == 2 ? 0 : MODE>(p, s);
     if (tiles(128, n160 ? 160 : 128) >= 384) {
         if (n160 && v3_on && MODE != 2) return launch_gemm_v3<MODE == 2 ? 0 : MODE>(p, s);
         static const int var = getenv("SIDLSG_GEMM_VAR") ? atoi(getenv("SIDLSG_GEMM_VAR")) : 0;   // scheduling experiments (A/B)
