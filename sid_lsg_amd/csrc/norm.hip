@@ -15,6 +15,7 @@
 //   gn_bwd_apply : dx = rstd*(dy'*gamma - s1/n - xhat*s2/n)
 //   colsum_reduce: dgamma/dbeta (+=) from the per-channel partials
 #include "common.h"
+#include <stdlib.h>
 
 constexpr int GN_MAX_C = 2560;
 
@@ -263,55 +264,86 @@ static dim3 reduce_grid(int n, int P) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// LayerNorm over the last dim C (C % 8 == 0, C <= 8*64*LN_MAXCH): one wave per token row.
-constexpr int LN_MAXCH = 4;  // chunks of 8 per lane -> C <= 2048
+// LayerNorm over the last dim C (C % 8 == 0, C <= 2048): one wave per token row, lane owns NCH chunks of 8 channels.
+// HBM/latency bound: what matters is bytes in flight per CU.  The kernels are specialised on NCH (1 for C = 320) so
+// that they stay under ~64 VGPRs (8 waves per SIMD), and every wave keeps R rows in flight (all loads issued before
+// the first reduction).  (The generic 4-chunk version held 160 VGPRs and one row per wave in flight: 2.8 TB/s.)
+constexpr int LN_MAXCH = 4;   // chunks of 8 per lane -> C <= 2048
 
+template <int NCH, int R>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16* __restrict__ x, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, bf16* __restrict__ y,
-                                                     float* __restrict__ stats, int rows, int C, float eps) {
+                                                     float* __restrict__ stats, int rows, int C, float eps, int rpw) {
     const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= rows) return;
     const int C8 = C >> 3;
-    bf16x8 v[LN_MAXCH];
-    float s = 0.f;
+    const int rbeg = (blockIdx.x * 4 + (threadIdx.x >> 6)) * rpw;      // rpw rows per wave
+    const int rend = min(rows, rbeg + rpw);
+    if (rbeg >= rows) return;
+    float ga[NCH][8], be[NCH][8];
 #pragma unroll
-    for (int i = 0; i < LN_MAXCH; i++) {
+    for (int i = 0; i < NCH; i++) {
         const int cc = lane + 64 * i;
-        if (cc < C8) {
-            v[i] = ld8(x + (size_t)row * C + cc * 8);
 #pragma unroll
-            for (int e = 0; e < 8; e++) s += bf2f(v[i][e]);
-        }
+        for (int e = 0; e < 8; e++) { ga[i][e] = cc < C8 ? gamma[cc * 8 + e] : 0.f; be[i][e] = cc < C8 ? beta[cc * 8 + e] : 0.f; }
     }
-    const float mean = wave_sum(s) / (float)C;
-    float q = 0.f;
+    const float invC = 1.0f / (float)C;
+    for (int r0 = rbeg; r0 < rend; r0 += R) {
+        bf16x8 v[R][NCH];
 #pragma unroll
-    for (int i = 0; i < LN_MAXCH; i++) {
-        const int cc = lane + 64 * i;
-        if (cc < C8) {
+        for (int r = 0; r < R; r++)
 #pragma unroll
-            for (int e = 0; e < 8; e++) { const float d = bf2f(v[i][e]) - mean; q += d * d; }
-        }
-    }
-    const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
-    if (lane == 0 && stats) { stats[(size_t)row * 2] = mean; stats[(size_t)row * 2 + 1] = rstd; }
-#pragma unroll
-    for (int i = 0; i < LN_MAXCH; i++) {
-        const int cc = lane + 64 * i;
-        if (cc < C8) {
-            bf16x8 o;
-#pragma unroll
-            for (int e = 0; e < 8; e++) {
-                const int ch = cc * 8 + e;
-                o[e] = f2bf((bf2f(v[i][e]) - mean) * rstd * gamma[ch] + beta[ch]);
+            for (int i = 0; i < NCH; i++) {
+                const int cc = lane + 64 * i;
+                v[r][i] = (r0 + r < rend && cc < C8) ? ld8(x + (size_t)(r0 + r) * C + cc * 8) : zero8();
             }
-            st8(y + (size_t)row * C + cc * 8, o);
+        float mean[R], rstd[R];
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            float t = 0.f;
+#pragma unroll
+            for (int i = 0; i < NCH; i++)
+#pragma unroll
+                for (int e = 0; e < 8; e++) t += bf2f(v[r][i][e]);
+            mean[r] = t;
+        }
+#pragma unroll
+        for (int r = 0; r < R; r++) mean[r] = wave_sum(mean[r]) * invC;
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            float q = 0.f;
+#pragma unroll
+            for (int i = 0; i < NCH; i++) {
+                const int cc = lane + 64 * i;
+                if (cc < C8) {
+#pragma unroll
+                    for (int e = 0; e < 8; e++) { const float d = bf2f(v[r][i][e]) - mean[r]; q += d * d; }
+                }
+            }
+            rstd[r] = q;
+        }
+#pragma unroll
+        for (int r = 0; r < R; r++) rstd[r] = rsqrtf(wave_sum(rstd[r]) * invC + eps);
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const int row = r0 + r;
+            if (row >= rend) break;
+            if (lane == 0 && stats) { stats[(size_t)row * 2] = mean[r]; stats[(size_t)row * 2 + 1] = rstd[r]; }
+#pragma unroll
+            for (int i = 0; i < NCH; i++) {
+                const int cc = lane + 64 * i;
+                if (cc < C8) {
+                    bf16x8 o;
+#pragma unroll
+                    for (int e = 0; e < 8; e++) o[e] = f2bf((bf2f(v[r][i][e]) - mean[r]) * rstd[r] * ga[i][e] + be[i][e]);
+                    st8(y + (size_t)row * C + cc * 8, o);
+                }
+            }
         }
     }
 }
 
 // dx = rstd*(dy*gamma - mean(dy*gamma) - xhat*mean(dy*gamma*xhat)); per-block partial dgamma/dbeta.
+template <int NCH, int R>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* __restrict__ x, const bf16* __restrict__ dy,
                                                      const float* __restrict__ stats, const float* __restrict__ gamma,
                                                      bf16* __restrict__ dx, float* __restrict__ part, int rows, int C,
@@ -319,50 +351,73 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* __restrict__ x,
     extern __shared__ float dyn[];  // [4 waves][C][2] for the param-grad partials
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int C8 = C >> 3;
-    float ga[LN_MAXCH][8], pg[LN_MAXCH][8], pb[LN_MAXCH][8];
+    float ga[NCH][8], pg[NCH][8], pb[NCH][8];
 #pragma unroll
-    for (int i = 0; i < LN_MAXCH; i++)
+    for (int i = 0; i < NCH; i++)
 #pragma unroll
         for (int e = 0; e < 8; e++) {
             const int cc = lane + 64 * i;
             ga[i][e] = cc < C8 ? gamma[cc * 8 + e] : 0.f;
             pg[i][e] = pb[i][e] = 0.f;
         }
+    const float invC = 1.0f / (float)C;
     const int rbeg = blockIdx.x * rows_per_block, rend = min(rows, rbeg + rows_per_block);
-    for (int row = rbeg + wave; row < rend; row += 4) {
-        const float mean = stats[(size_t)row * 2], rstd = stats[(size_t)row * 2 + 1];
-        float xh[LN_MAXCH][8], dg[LN_MAXCH][8];
-        float s1 = 0.f, s2 = 0.f;
+    for (int r0 = rbeg + wave * R; r0 < rend; r0 += 4 * R) {
+        bf16x8 xv[R][NCH], dv[R][NCH];
+        float mean[R], rstd[R];
 #pragma unroll
-        for (int i = 0; i < LN_MAXCH; i++) {
-            const int cc = lane + 64 * i;
-            if (cc < C8) {
-                const bf16x8 xv = ld8(x + (size_t)row * C + cc * 8), dv = ld8(dy + (size_t)row * C + cc * 8);
+        for (int r = 0; r < R; r++) {
+            const bool ok = r0 + r < rend;
+            mean[r] = ok ? stats[(size_t)(r0 + r) * 2] : 0.f;
+            rstd[r] = ok ? stats[(size_t)(r0 + r) * 2 + 1] : 0.f;
 #pragma unroll
-                for (int e = 0; e < 8; e++) {
-                    xh[i][e] = (bf2f(xv[e]) - mean) * rstd;
-                    const float d = bf2f(dv[e]);
-                    pg[i][e] += d * xh[i][e]; pb[i][e] += d;
-                    dg[i][e] = d * ga[i][e];
-                    s1 += dg[i][e]; s2 += dg[i][e] * xh[i][e];
-                }
+            for (int i = 0; i < NCH; i++) {
+                const int cc = lane + 64 * i;
+                const bool okc = ok && cc < C8;
+                xv[r][i] = okc ? ld8(x + (size_t)(r0 + r) * C + cc * 8) : zero8();
+                dv[r][i] = okc ? ld8(dy + (size_t)(r0 + r) * C + cc * 8) : zero8();
             }
         }
-        s1 = wave_sum(s1) / (float)C; s2 = wave_sum(s2) / (float)C;
+        float s1[R], s2[R];
 #pragma unroll
-        for (int i = 0; i < LN_MAXCH; i++) {
-            const int cc = lane + 64 * i;
-            if (cc < C8) {
-                bf16x8 o;
+        for (int r = 0; r < R; r++) {
+            float a = 0.f, c = 0.f;
 #pragma unroll
-                for (int e = 0; e < 8; e++) o[e] = f2bf(rstd * (dg[i][e] - s1 - xh[i][e] * s2));
-                st8(dx + (size_t)row * C + cc * 8, o);
+            for (int i = 0; i < NCH; i++)
+#pragma unroll
+                for (int e = 0; e < 8; e++) {
+                    const float xh = (bf2f(xv[r][i][e]) - mean[r]) * rstd[r];     // zero rows: mean = rstd = 0 -> xh = 0
+                    const float d = bf2f(dv[r][i][e]);
+                    pg[i][e] += d * xh; pb[i][e] += d;
+                    const float dg = d * ga[i][e];
+                    a += dg; c += dg * xh;
+                }
+            s1[r] = a; s2[r] = c;
+        }
+#pragma unroll
+        for (int r = 0; r < R; r++) { s1[r] = wave_sum(s1[r]) * invC; s2[r] = wave_sum(s2[r]) * invC; }
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const int row = r0 + r;
+            if (row >= rend) break;
+#pragma unroll
+            for (int i = 0; i < NCH; i++) {
+                const int cc = lane + 64 * i;
+                if (cc < C8) {
+                    bf16x8 o;
+#pragma unroll
+                    for (int e = 0; e < 8; e++) {
+                        const float xh = (bf2f(xv[r][i][e]) - mean[r]) * rstd[r];
+                        o[e] = f2bf(rstd[r] * (bf2f(dv[r][i][e]) * ga[i][e] - s1[r] - xh * s2[r]));
+                    }
+                    st8(dx + (size_t)row * C + cc * 8, o);
+                }
             }
         }
     }
     if (part) {
 #pragma unroll
-        for (int i = 0; i < LN_MAXCH; i++) {
+        for (int i = 0; i < NCH; i++) {
             const int cc = lane + 64 * i;
             if (cc < C8) {
 #pragma unroll
@@ -381,13 +436,16 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* __restrict__ x,
 static int gn_geom(GnGeom& g, int B, int HW, int C, int G) {
     if (C % 8 || C % G || C > GN_MAX_C || B <= 0 || HW <= 0) return SIDLSG_EINVAL;
     g.C = C; g.HW = HW; g.G = G; g.cpg = C / G; g.C8 = C / 8;
-    g.rows = 256 / g.C8; if (g.rows < 1) g.rows = 1;
+    static const int gn_threads = getenv("SIDLSG_GN_THREADS") ? atoi(getenv("SIDLSG_GN_THREADS")) : 256;
+    g.rows = gn_threads / g.C8; if (g.rows < 1) g.rows = 1;
     if (g.rows > HW) g.rows = HW;
-    // enough (sample, chunk) blocks to fill 256 CUs x2, each chunk >= rows*4 pixels
-    int want = (512 + B - 1) / B;
+    // enough (sample, chunk) blocks for ~6 blocks per CU (latency bound: bytes in flight per CU are what count; with
+    // 2 blocks per CU the kernels ran at 2-3 TB/s), each chunk >= rows*4 pixels
+    static const int target = getenv("SIDLSG_GN_BLOCKS") ? atoi(getenv("SIDLSG_GN_BLOCKS")) : 512;
+    int want = (target + B - 1) / B;
     int maxch = HW / (g.rows * 4); if (maxch < 1) maxch = 1;
     g.nch = want < maxch ? want : maxch;
-    if (g.nch > 64) g.nch = 64;
+    if (g.nch > 128) g.nch = 128;
     g.ppb = (HW + g.nch - 1) / g.nch;
     g.nch = (HW + g.ppb - 1) / g.ppb;
     return SIDLSG_OK;
@@ -441,13 +499,19 @@ int sidlsg_groupnorm_bwd(const void* x, const void* dy, const float* stats, cons
 int sidlsg_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* stats, int rows, int C,
                          float eps, void* stream) {
     if (C % 8 || C > 8 * 64 * LN_MAXCH || rows <= 0) return SIDLSG_EINVAL;
-    hipLaunchKernelGGL(ln_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, gamma, beta,
-                       (bf16*)y, stats, rows, C, eps);
+    const int nch = (C / 8 + 63) / 64;
+    const int R = nch <= 1 ? 4 : 2;
+    // rows per wave: enough waves to fill the chip (>= ~4096), at most 16 rows (amortises the gamma/beta loads)
+    int rpw = rows / 4096; rpw = rpw < R ? R : (rpw > 16 ? 16 : rpw); rpw = (rpw + R - 1) / R * R;
+    const dim3 grid((rows + 4 * rpw - 1) / (4 * rpw));
+#define LN_FWD(NCH, RR) hipLaunchKernelGGL((ln_fwd_kernel<NCH, RR>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)x, gamma, \
+                                           beta, (bf16*)y, stats, rows, C, eps, rpw)
+    if (nch == 1) LN_FWD(1, 4); else if (nch == 2) LN_FWD(2, 2); else if (nch == 3) LN_FWD(3, 2); else LN_FWD(4, 2);
+#undef LN_FWD
     return sidlsg_last_error();
 }
-
 int sidlsg_layernorm_bwd_nblocks(int rows) {
-    int nb = (rows + 63) / 64; if (nb > 1024) nb = 1024; if (nb < 1) nb = 1; return nb;
+    int nb = (rows + 15) / 16; if (nb > 1024) nb = 1024; if (nb < 1) nb = 1; return nb;
 }
 
 // dx, and dgamma/dbeta (+=) when non-null; ws: [nblocks][C][2] floats
@@ -458,8 +522,12 @@ int sidlsg_layernorm_bwd(const void* x, const void* dy, const float* stats, cons
     const int nb = sidlsg_layernorm_bwd_nblocks(rows);
     const int rpb = (rows + nb - 1) / nb;
     const bool pg = dgamma && dbeta;
-    hipLaunchKernelGGL(ln_bwd_kernel, dim3(nb), dim3(256), pg ? (size_t)4 * C * 2 * sizeof(float) : 0, s, (const bf16*)x,
-                       (const bf16*)dy, stats, gamma, (bf16*)dx, pg ? ws : nullptr, rows, C, rpb);
+    const int nch = (C / 8 + 63) / 64;
+    const size_t lds = pg ? (size_t)4 * C * 2 * sizeof(float) : 0;
+#define LN_BWD(NCH, R) hipLaunchKernelGGL((ln_bwd_kernel<NCH, R>), dim3(nb), dim3(256), lds, s, (const bf16*)x, (const bf16*)dy, \
+                                          stats, gamma, (bf16*)dx, pg ? ws : nullptr, rows, C, rpb)
+    if (nch == 1) LN_BWD(1, 2); else if (nch == 2) LN_BWD(2, 2); else if (nch == 3) LN_BWD(3, 1); else LN_BWD(4, 1);
+#undef LN_BWD
     if (pg) {
         hipLaunchKernelGGL(colsum_reduce_kernel, reduce_grid(C, nb), dim3(256), 0, s, ws, dgamma, nb, (size_t)C * 2, 2, 0, C, 1);
         hipLaunchKernelGGL(colsum_reduce_kernel, reduce_grid(C, nb), dim3(256), 0, s, ws, dbeta, nb, (size_t)C * 2, 2, 1, C, 1);

@@ -109,21 +109,34 @@ def bench_attn(B):
 
 
 def bench_norm(B):
-    print('--- GroupNorm+SiLU / LayerNorm: GB/s (algorithmic bytes = read x + write y, bf16)')
+    """Raw C-ABI calls on preallocated buffers (kernel time, not Python/autograd overhead)."""
+    print('--- GroupNorm+SiLU / LayerNorm: us and GB/s of algorithmic bytes (fwd: x,y; bwd: x,dy,dx; bf16)')
+    F32 = torch.float32
     for HW, C in ((4096, 320), (4096, 640), (1024, 640), (1024, 1920), (256, 1280), (64, 2560)):
-        x = r(B, HW, C).requires_grad_()
+        x, dy = r(B, HW, C), r(B, HW, C)
+        y, dx = torch.empty_like(x), torch.empty_like(x)
         g, b = torch.ones(C, device=dev), torch.zeros(C, device=dev)
-        tf = timeit(lambda: ops.group_norm(x.detach(), g, b, 32, 1e-5, True))
-        y = ops.group_norm(x, g, b, 32, 1e-5, True)
-        dy = r(B, HW, C)
-        tb = timeit(lambda: y.backward(dy, retain_graph=True), iters=5)
-        by = 2.0 * B * HW * C * 2
-        print(f'  GN B{B} HW{HW} C{C}: fwd {tf * 1e6:7.1f} us {by / tf / 1e9:7.0f} GB/s | bwd {tb * 1e6:7.1f} us {1.5 * by / tb / 1e9:7.0f} GB/s')
+        gg, gb = torch.zeros(C, device=dev), torch.zeros(C, device=dev)
+        ws = torch.empty(lib.sidlsg_groupnorm_ws_floats.raw(B, HW, C, 32), device=dev, dtype=F32)
+        st = torch.empty(B, 32, 2, device=dev, dtype=F32)
+        tf = timeit(lambda: lib.sidlsg_groupnorm_fwd(x.data_ptr(), g.data_ptr(), b.data_ptr(), y.data_ptr(), st.data_ptr(), ws.data_ptr(),
+                                                     B, HW, C, 32, 1e-5, 1, ops._s()))
+        tb = timeit(lambda: lib.sidlsg_groupnorm_bwd(x.data_ptr(), dy.data_ptr(), st.data_ptr(), g.data_ptr(), b.data_ptr(), dx.data_ptr(),
+                                                     gg.data_ptr(), gb.data_ptr(), ws.data_ptr(), B, HW, C, 32, 1, ops._s()))
+        by = 1.0 * B * HW * C * 2
+        print(f'  GN B{B} HW{HW} C{C}: fwd {tf * 1e6:7.1f} us {2 * by / tf / 1e9:6.0f} GB/s | bwd {tb * 1e6:7.1f} us {3 * by / tb / 1e9:6.0f} GB/s')
     for rows, C in ((B * 4096, 320), (B * 1024, 640), (B * 256, 1280)):
-        x = r(rows, C)
+        x, dy = r(rows, C), r(rows, C)
+        y, dx = torch.empty_like(x), torch.empty_like(x)
         g, b = torch.ones(C, device=dev), torch.zeros(C, device=dev)
-        tf = timeit(lambda: ops.layer_norm(x, g, b))
-        print(f'  LN {rows}x{C}: fwd {tf * 1e6:7.1f} us {2.0 * rows * C * 2 / tf / 1e9:7.0f} GB/s')
+        gg, gb = torch.zeros(C, device=dev), torch.zeros(C, device=dev)
+        st = torch.empty(rows, 2, device=dev, dtype=F32)
+        ws = torch.empty(lib.sidlsg_layernorm_bwd_nblocks.raw(rows) * C * 2, device=dev, dtype=F32)
+        tf = timeit(lambda: lib.sidlsg_layernorm_fwd(x.data_ptr(), g.data_ptr(), b.data_ptr(), y.data_ptr(), st.data_ptr(), rows, C, 1e-5, ops._s()))
+        tb = timeit(lambda: lib.sidlsg_layernorm_bwd(x.data_ptr(), dy.data_ptr(), st.data_ptr(), g.data_ptr(), dx.data_ptr(), gg.data_ptr(),
+                                                     gb.data_ptr(), ws.data_ptr(), rows, C, ops._s()))
+        by = 1.0 * rows * C * 2
+        print(f'  LN {rows}x{C}: fwd {tf * 1e6:7.1f} us {2 * by / tf / 1e9:6.0f} GB/s | bwd {tb * 1e6:7.1f} us {3 * by / tb / 1e9:6.0f} GB/s')
 
 
 if __name__ == '__main__':
