@@ -61,17 +61,20 @@ int sidlsg_conv3x3_wgrad_bf16(const void* dY, int ldy, const void* X, int ldx, f
 /* ---- normalisation (HBM bound) ------------------------------------------------------------
  * torch.nn.GroupNorm(32, C, eps)+SiLU of ResnetBlock2D.norm1/norm2, Transformer2DModel.norm,
  * conv_norm_out; torch.nn.LayerNorm of BasicTransformerBlock.norm1-3. */
+/* backward: dres (may be NULL, same shape as x) is the gradient reaching x through its other consumer (the residual /
+ * shortcut branch of the block that owns the norm); dx = norm-backward + dres in the same pass. */
 int sidlsg_groupnorm_ws_floats(int B, int HW, int C, int G); /* host: workspace size in floats, <0 on bad shape */
 int sidlsg_groupnorm_nchunks(int B, int HW, int C, int G);   /* host */
 int sidlsg_groupnorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* stats, float* ws, int B,
                          int HW, int C, int G, float eps, int silu, void* stream);
-int sidlsg_groupnorm_bwd(const void* x, const void* dy, const float* stats, const float* gamma, const float* beta, void* dx,
-                         float* dgamma, float* dbeta, float* ws, int B, int HW, int C, int G, int silu, void* stream);
+int sidlsg_groupnorm_bwd(const void* x, const void* dy, const float* stats, const float* gamma, const float* beta,
+                         const void* dres, void* dx, float* dgamma, float* dbeta, float* ws, int B, int HW, int C, int G,
+                         int silu, void* stream);
 int sidlsg_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* stats, int rows, int C,
                          float eps, void* stream);
 int sidlsg_layernorm_bwd_nblocks(int rows); /* host: ws = nblocks*C*2 floats */
-int sidlsg_layernorm_bwd(const void* x, const void* dy, const float* stats, const float* gamma, void* dx, float* dgamma,
-                         float* dbeta, float* ws, int rows, int C, void* stream);
+int sidlsg_layernorm_bwd(const void* x, const void* dy, const float* stats, const float* gamma, const void* dres, void* dx,
+                         float* dgamma, float* dbeta, float* ws, int rows, int C, void* stream);
 
 /* ---- attention (diffusers Attention + AttnProcessor2_0 / xformers; sid_sd_util.py:102-113) --
  * O = softmax(Q K^T D^-1/2) V per head; Q/K/V/O are strided views ([b][token][h*D + d], token

@@ -188,7 +188,9 @@ __global__ void gn_bwd_stats_kernel(const bf16* __restrict__ x, const bf16* __re
 __global__ void gn_bwd_apply_kernel(const bf16* __restrict__ x, const bf16* __restrict__ dy,
                                     const float* __restrict__ stats, const float* __restrict__ gamma,
                                     const float* __restrict__ beta, const float* __restrict__ part,
-                                    bf16* __restrict__ dx, GnGeom g, int act) {
+                                    const bf16* __restrict__ add, bf16* __restrict__ dx, GnGeom g, int act) {
+    // add (may be null): gradient arriving at x through its OTHER consumer (residual / shortcut branch); summed here
+    // instead of in a separate elementwise kernel
     extern __shared__ float sm[];  // s1[G], s2[G]
     const int b = blockIdx.y, chunk = blockIdx.x;
     for (int grp = threadIdx.x; grp < g.G; grp += blockDim.x) {
@@ -219,26 +221,28 @@ __global__ void gn_bwd_apply_kernel(const bf16* __restrict__ x, const bf16* __re
         for (int u = 0; u < 2; u++) { xv[u] = ld8(x + base + (size_t)(p + u * g.rows) * g.C); dv[u] = ld8(dy + base + (size_t)(p + u * g.rows) * g.C); }
 #pragma unroll
         for (int u = 0; u < 2; u++) {
-            bf16x8 o;
+            bf16x8 o, av = zero8();
+            if (add) av = ld8(add + base + (size_t)(p + u * g.rows) * g.C);
 #pragma unroll
             for (int e = 0; e < 8; e++) {
                 const float xh = (bf2f(xv[u][e]) - mu[e]) * rs[e];
                 float d = bf2f(dv[u][e]);
                 if (act) d *= silu_grad_f(xh * ga[e] + be[e]);
-                o[e] = f2bf(rs[e] * (d * ga[e] - m1[e] - xh * m2[e]));
+                o[e] = f2bf(rs[e] * (d * ga[e] - m1[e] - xh * m2[e]) + bf2f(av[e]));
             }
             st8(dx + base + (size_t)(p + u * g.rows) * g.C, o);
         }
     }
     for (; p < p1; p += g.rows) {
         const bf16x8 xv = ld8(x + base + (size_t)p * g.C), dv = ld8(dy + base + (size_t)p * g.C);
-        bf16x8 o;
+        bf16x8 o, av = zero8();
+        if (add) av = ld8(add + base + (size_t)p * g.C);
 #pragma unroll
         for (int e = 0; e < 8; e++) {
             const float xh = (bf2f(xv[e]) - mu[e]) * rs[e];
             float d = bf2f(dv[e]);
             if (act) d *= silu_grad_f(xh * ga[e] + be[e]);
-            o[e] = f2bf(rs[e] * (d * ga[e] - m1[e] - xh * m2[e]));
+            o[e] = f2bf(rs[e] * (d * ga[e] - m1[e] - xh * m2[e]) + bf2f(av[e]));
         }
         st8(dx + base + (size_t)p * g.C, o);
     }
@@ -346,8 +350,8 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16* __restrict__ x,
 template <int NCH, int R>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* __restrict__ x, const bf16* __restrict__ dy,
                                                      const float* __restrict__ stats, const float* __restrict__ gamma,
-                                                     bf16* __restrict__ dx, float* __restrict__ part, int rows, int C,
-                                                     int rows_per_block) {
+                                                     const bf16* __restrict__ add, bf16* __restrict__ dx,
+                                                     float* __restrict__ part, int rows, int C, int rows_per_block) {
     extern __shared__ float dyn[];  // [4 waves][C][2] for the param-grad partials
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int C8 = C >> 3;
@@ -404,11 +408,12 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* __restrict__ x,
             for (int i = 0; i < NCH; i++) {
                 const int cc = lane + 64 * i;
                 if (cc < C8) {
-                    bf16x8 o;
+                    bf16x8 o, av = zero8();
+                    if (add) av = ld8(add + (size_t)row * C + cc * 8);       // residual-branch gradient, summed here
 #pragma unroll
                     for (int e = 0; e < 8; e++) {
                         const float xh = (bf2f(xv[r][i][e]) - mean[r]) * rstd[r];
-                        o[e] = f2bf(rstd[r] * (bf2f(dv[r][i][e]) * ga[i][e] - s1[r] - xh * s2[r]));
+                        o[e] = f2bf(rstd[r] * (bf2f(dv[r][i][e]) * ga[i][e] - s1[r] - xh * s2[r]) + bf2f(av[e]));
                     }
                     st8(dx + (size_t)row * C + cc * 8, o);
                 }
@@ -478,15 +483,15 @@ int sidlsg_groupnorm_fwd(const void* x, const float* gamma, const float* beta, v
 
 // dx (and optionally dgamma/dbeta +=) of y = act(GroupNorm(x))
 int sidlsg_groupnorm_bwd(const void* x, const void* dy, const float* stats, const float* gamma, const float* beta,
-                         void* dx, float* dgamma, float* dbeta, float* ws, int B, int HW, int C, int G, int silu,
-                         void* stream) {
+                         const void* dres, void* dx, float* dgamma, float* dbeta, float* ws, int B, int HW, int C, int G,
+                         int silu, void* stream) {
     GnGeom g; if (int e = gn_geom(g, B, HW, C, G)) return e;
     hipStream_t s = (hipStream_t)stream;
     const int threads = g.C8 * g.rows;
     hipLaunchKernelGGL(gn_bwd_stats_kernel, dim3(g.nch, B), dim3(threads), (size_t)g.rows * C * 2 * sizeof(float), s,
                        (const bf16*)x, (const bf16*)dy, stats, gamma, beta, ws, g, silu);
     hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(g.nch, B), dim3(threads), (size_t)2 * G * sizeof(float), s,
-                       (const bf16*)x, (const bf16*)dy, stats, gamma, beta, ws, (bf16*)dx, g, silu);
+                       (const bf16*)x, (const bf16*)dy, stats, gamma, beta, ws, (const bf16*)dres, (bf16*)dx, g, silu);
     if (dgamma && dbeta) {
         const int P = B * g.nch;
         hipLaunchKernelGGL(colsum_reduce_kernel, reduce_grid(C, P), dim3(256), 0, s, ws, dgamma, P, (size_t)C * 2, 2, 0, C, 1);
@@ -515,8 +520,8 @@ int sidlsg_layernorm_bwd_nblocks(int rows) {
 }
 
 // dx, and dgamma/dbeta (+=) when non-null; ws: [nblocks][C][2] floats
-int sidlsg_layernorm_bwd(const void* x, const void* dy, const float* stats, const float* gamma, void* dx, float* dgamma,
-                         float* dbeta, float* ws, int rows, int C, void* stream) {
+int sidlsg_layernorm_bwd(const void* x, const void* dy, const float* stats, const float* gamma, const void* dres, void* dx,
+                         float* dgamma, float* dbeta, float* ws, int rows, int C, void* stream) {
     if (C % 8 || C > 8 * 64 * LN_MAXCH || rows <= 0) return SIDLSG_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     const int nb = sidlsg_layernorm_bwd_nblocks(rows);
@@ -525,7 +530,7 @@ int sidlsg_layernorm_bwd(const void* x, const void* dy, const float* stats, cons
     const int nch = (C / 8 + 63) / 64;
     const size_t lds = pg ? (size_t)4 * C * 2 * sizeof(float) : 0;
 #define LN_BWD(NCH, R) hipLaunchKernelGGL((ln_bwd_kernel<NCH, R>), dim3(nb), dim3(256), lds, s, (const bf16*)x, (const bf16*)dy, \
-                                          stats, gamma, (bf16*)dx, pg ? ws : nullptr, rows, C, rpb)
+                                          stats, gamma, (const bf16*)dres, (bf16*)dx, pg ? ws : nullptr, rows, C, rpb)
     if (nch == 1) LN_BWD(1, 2); else if (nch == 2) LN_BWD(2, 2); else if (nch == 3) LN_BWD(3, 1); else LN_BWD(4, 1);
 #undef LN_BWD
     if (pg) {

@@ -199,6 +199,38 @@ def test_layernorm(dev, rows, C):
     close(bm.grad, br.grad, 3e-3, 'dbeta')
 
 
+@pytest.mark.parametrize('kind', ['gn', 'ln'])
+def test_norm_fork_fuses_residual_gradient(dev, kind):
+    """fork=True: (y, x_keep); the gradient arriving through x_keep is summed inside the norm-backward kernel.
+    Reference: y = norm(x) * a + x * b  ->  dx = norm_bwd(a*dy) + b*dy, plain torch fp32."""
+    from sid_lsg_amd import ops
+    B, HW, C = 2, 100, 320
+    x = (rnd(B, HW, C, seed=1).float() * 1.5 + 0.3).to(BF16)
+    gam = torch.randn(C, generator=torch.Generator().manual_seed(2)) * 0.5 + 1
+    bet = torch.randn(C, generator=torch.Generator().manual_seed(3)) * 0.3
+    dy = rnd(B, HW, C, seed=4)
+    xr = x.float().requires_grad_()
+    if kind == 'gn':
+        nr = F.silu(F.group_norm(xr.permute(0, 2, 1), 32, gam, bet, 1e-5).permute(0, 2, 1))
+    else:
+        nr = F.layer_norm(xr, (C,), gam, bet, 1e-5)
+    (nr * 0.5 + xr * 2.0).backward(dy.float())
+    gm, bm = torch.nn.Parameter(gam.to(dev)), torch.nn.Parameter(bet.to(dev))
+    xd = x.to(dev).requires_grad_()
+    if kind == 'gn':
+        y, xk = ops.group_norm(xd, gm, bm, 32, 1e-5, True, fork=True)
+    else:
+        y, xk = ops.layer_norm(xd, gm, bm, 1e-5, fork=True)
+    assert xk.data_ptr() == xd.data_ptr()
+    (y.float() * 0.5 + xk.float() * 2.0).backward(dy.to(dev).float())
+    close(xd.grad, xr.grad, 1.5e-2, 'dx with fused residual gradient')
+    # pass-through only (normalised output unused)
+    xd2 = x.to(dev).requires_grad_()
+    _, xk2 = ops.layer_norm(xd2, gm, bm, 1e-5, fork=True) if kind == 'ln' else ops.group_norm(xd2, gm, bm, 32, 1e-5, True, fork=True)
+    (xk2.float() * 3.0).sum().backward()
+    close(xd2.grad, torch.full_like(xr, 3.0), 1e-6, 'pass-through only')
+
+
 def attn_ref(q, k, v, heads):
     B, Nq, C = q.shape
     d = C // heads

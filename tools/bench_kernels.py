@@ -121,7 +121,7 @@ def bench_norm(B):
         st = torch.empty(B, 32, 2, device=dev, dtype=F32)
         tf = timeit(lambda: lib.sidlsg_groupnorm_fwd(x.data_ptr(), g.data_ptr(), b.data_ptr(), y.data_ptr(), st.data_ptr(), ws.data_ptr(),
                                                      B, HW, C, 32, 1e-5, 1, ops._s()))
-        tb = timeit(lambda: lib.sidlsg_groupnorm_bwd(x.data_ptr(), dy.data_ptr(), st.data_ptr(), g.data_ptr(), b.data_ptr(), dx.data_ptr(),
+        tb = timeit(lambda: lib.sidlsg_groupnorm_bwd(x.data_ptr(), dy.data_ptr(), st.data_ptr(), g.data_ptr(), b.data_ptr(), None, dx.data_ptr(),
                                                      gg.data_ptr(), gb.data_ptr(), ws.data_ptr(), B, HW, C, 32, 1, ops._s()))
         by = 1.0 * B * HW * C * 2
         print(f'  GN B{B} HW{HW} C{C}: fwd {tf * 1e6:7.1f} us {2 * by / tf / 1e9:6.0f} GB/s | bwd {tb * 1e6:7.1f} us {3 * by / tb / 1e9:6.0f} GB/s')
@@ -133,7 +133,7 @@ def bench_norm(B):
         st = torch.empty(rows, 2, device=dev, dtype=F32)
         ws = torch.empty(lib.sidlsg_layernorm_bwd_nblocks.raw(rows) * C * 2, device=dev, dtype=F32)
         tf = timeit(lambda: lib.sidlsg_layernorm_fwd(x.data_ptr(), g.data_ptr(), b.data_ptr(), y.data_ptr(), st.data_ptr(), rows, C, 1e-5, ops._s()))
-        tb = timeit(lambda: lib.sidlsg_layernorm_bwd(x.data_ptr(), dy.data_ptr(), st.data_ptr(), g.data_ptr(), dx.data_ptr(), gg.data_ptr(),
+        tb = timeit(lambda: lib.sidlsg_layernorm_bwd(x.data_ptr(), dy.data_ptr(), st.data_ptr(), g.data_ptr(), None, dx.data_ptr(), gg.data_ptr(),
                                                      gb.data_ptr(), ws.data_ptr(), rows, C, ops._s()))
         by = 1.0 * rows * C * 2
         print(f'  LN {rows}x{C}: fwd {tf * 1e6:7.1f} us {2 * by / tf / 1e9:6.0f} GB/s | bwd {tb * 1e6:7.1f} us {3 * by / tb / 1e9:6.0f} GB/s')
