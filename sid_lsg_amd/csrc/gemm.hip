@@ -39,7 +39,8 @@ struct GemmParams {
     float alpha;
     int flags;
     unsigned a_bytes, w_bytes;   // sizes of the A / W allocations seen by the kernel (< 2 GiB)
-    int kt_per_split;            // split-K: K-tiles per blockIdx.y slice (0 = no split)
+    int kt_per_split;            // split-K: K-tiles per split (0 = no split)
+    int group_m;                 // v3: m-tiles per group of the logical tile order (see gemm_v3_kernel)
     float* ws;                   // split-K: fp32 [splits][M][N] partial-sum slabs
 };
 
@@ -636,16 +637,36 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_v3_kernel(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16* ring = reinterpret_cast<bf16*>(smem);
 
+    // Work item = (output tile, K split), 1-D grid.  Hardware block b runs on XCD b % 8; the remap gives every XCD a
+    // contiguous range of logical items.  Logical order: split-major, and inside a split the tiles in groups of 8
+    // m-tiles (m fastest, then n): the ~64 blocks resident on an XCD then form an ~8 x 8 patch of output tiles and
+    // fetch 8 A panels + 8 W panels into that XCD's L2.  (Row-major strips fetched 1 A panel + 64 W panels for FF-in
+    // at 16x16 -- every XCD streamed the whole weight matrix; measured 154 -> 130 us on 4096x10240x1280 and 90 -> 72
+    // us on the 8x8 2560->1280 conv.)
     const int tiles_n = (p.N + BN - 1) / BN;
     const int tiles_m = (p.M + BM - 1) / BM;
-    const int nblk = tiles_n * tiles_m;
+    const int nk_all = (p.K + BK - 1) / BK;
+    const int nsplit = p.kt_per_split ? (nk_all + p.kt_per_split - 1) / p.kt_per_split : 1;
+    const int ntile = tiles_n * tiles_m;
     int bid = blockIdx.x;
     {
+        const int nblk = ntile * nsplit;
         const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
-    const int m0 = (bid / tiles_n) * BM;
-    const int n0 = (bid % tiles_n) * BN;
+    const int split = bid / ntile;
+    int mt, nt;
+    {
+        const int t = bid - split * ntile;
+        const int per_group = p.group_m * tiles_n;
+        const int g = t / per_group, first_m = g * p.group_m;
+        const int gm = min(p.group_m, tiles_m - first_m);       // last group may be short
+        const int in_g = t - g * per_group;
+        mt = first_m + in_g % gm;
+        nt = in_g / gm;
+    }
+    const int m0 = mt * BM;
+    const int n0 = nt * BN;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 80;
@@ -690,8 +711,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_v3_kernel(GemmParams p) {
         const int n = n0 + r;
         boff[j] = n < p.N ? ((unsigned)n * (unsigned)p.K + kcs * 8) * 2u : OOB;
     }
-    const int nk_all = (p.K + BK - 1) / BK;
-    const int kt_begin = p.kt_per_split ? blockIdx.y * p.kt_per_split : 0;
+    const int kt_begin = p.kt_per_split ? split * p.kt_per_split : 0;
     const int nk = p.kt_per_split ? min(nk_all, kt_begin + p.kt_per_split) : nk_all;
     int cur_tap = -1;
 
@@ -805,7 +825,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_v3_kernel(GemmParams p) {
             for (int ni = 0; ni < NT; ni++) {
                 const bool paired = (ni | 1) < NT;
                 const int nb = n0 + wn0 + (paired ? 32 * (ni >> 1) + lg * 8 + (ni & 1) * 4 : 16 * ni + lg * 4);
-                float* dst = p.ws + ((size_t)blockIdx.y * p.M + m) * p.N + nb;
+                float* dst = p.ws + ((size_t)split * p.M + m) * p.N + nb;
                 if (nb + 4 <= p.N) *reinterpret_cast<f32x4*>(dst) = acc[ni][mi];
                 else
                     for (int r = 0; r < 4; r++)
@@ -828,7 +848,10 @@ static int launch_gemm_v3(const GemmParams& p, hipStream_t s) {
     }
     const int nk = (p.K + BK - 1) / BK;
     const int splits = p.kt_per_split ? (nk + p.kt_per_split - 1) / p.kt_per_split : 1;
-    hipLaunchKernelGGL((gemm_v3_kernel<MODE>), dim3(tiles, splits), dim3(NTHREADS), lds, s, p);
+    GemmParams q = p;
+    static const int group_env = getenv("SIDLSG_GEMM_GROUP_M") ? atoi(getenv("SIDLSG_GEMM_GROUP_M")) : 4;   // A/B switch (measured: 4 and 8 equivalent, 1 = row-major strips)
+    q.group_m = group_env < 1 ? 1 : group_env;
+    hipLaunchKernelGGL((gemm_v3_kernel<MODE>), dim3(tiles * splits), dim3(NTHREADS), lds, s, q);
     if (p.kt_per_split) {
         const size_t n4 = ((size_t)p.M * p.N + 3) / 4;
         hipLaunchKernelGGL(gemm_finish_kernel, dim3((unsigned)((n4 + 255) / 256), splits), dim3(256), 0, s, p);
