@@ -28,24 +28,6 @@ def _is_hip(net):
     return isinstance(_unwrap(net), HipUNet2DCondition)
 
 
-class LatentPreviewVAE(torch.nn.Module):
-    """Placeholder for AutoencoderKL when no VAE weights are available offline: previews the first three
-    latent channels.  Has the members the reference touches (sid_training_loop.py:254;
-    sid_sd_util.py:198-209).  The real VAE decode is a cold-path "next" row."""
-
-    def __init__(self):
-        super().__init__()
-        self.config = SimpleNamespace(block_out_channels=[128, 256, 512, 512], scaling_factor=0.18215, force_upcast=True)
-        self.post_quant_conv = torch.nn.Conv2d(4, 4, 1)
-
-    @property
-    def dtype(self):
-        return self.post_quant_conv.weight.dtype
-
-    def decode(self, z, return_dict=False):
-        return (F.interpolate(z[:, :3].float(), scale_factor=8.0, mode='nearest').clamp(-1, 1),)
-
-
 def _arch_of(name):
     n = name.lower()
     if n.startswith('random:'):
@@ -95,7 +77,17 @@ def load_sd15(pretrained_model_name_or_path, pretrained_vae_model_name_or_path, 
         if os.path.isfile(vj) and os.path.isfile(mt):
             tokenizer = CLIPBPETokenizer.from_files(vj, mt, model_max_length=cfg.text_len, pad_token_id=tokenizer.pad_token_id)
     text_encoder.requires_grad_(False).eval().to(device)
-    vae = LatentPreviewVAE().requires_grad_(False).to(device)
+    # VAE (decode only; cold path): real weights when the directory has them, seeded random ones otherwise
+    vae_dir = pretrained_vae_model_name_or_path if (pretrained_vae_model_name_or_path and os.path.isdir(str(pretrained_vae_model_name_or_path))) else name
+    vae_file = os.path.join(str(vae_dir), 'vae', 'diffusion_pytorch_model.safetensors')
+    from .vae import HipAutoencoderKLDecoder
+    vae = HipAutoencoderKLDecoder('sd' if arch in ('sd15', 'sd21-base') else 'tiny')
+    if local and os.path.isfile(vae_file):
+        from safetensors.torch import load_file
+        vae.load_state_dict(load_file(vae_file))
+    else:
+        vae.init_parameters(seed + 2)
+    vae = vae.to(device)
     return unet, vae, DDPMScheduler().to(device), text_encoder, tokenizer
 
 

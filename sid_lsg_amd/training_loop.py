@@ -98,6 +98,14 @@ def training_loop(
     opt_f = construct_class_by_name(params=fake_score.parameters(), **_hip_opt(fake_score_optimizer_kwargs))
     opt_g = construct_class_by_name(params=G.parameters(), **_hip_opt(g_optimizer_kwargs))
     G_ema = copy.deepcopy(G).eval().requires_grad_(False) if ema_halflife_kimg > 0 else G
+    if resume_pkl is not None:          # --transfer: start G / G_ema from a network snapshot (sid_training_loop.py:296-303)
+        dist.print0(f'Loading network weights from "{resume_pkl}"...')
+        with open(resume_pkl, 'rb') as f:
+            src = pickle.load(f)['ema']
+        for net in (G, G_ema):
+            net.load_state_dict(_snapshot_state(src))
+            net.refresh_compute_weights()
+        del src
     if resume_training is not None:
         data = torch.load(resume_training, map_location='cpu', weights_only=False)
         fake_score.load_state_dict(_sd(data['fake_score'])); G.load_state_dict(_sd(data['G']))
@@ -208,3 +216,9 @@ def _hip_opt(kw):
 
 def _sd(obj):
     return obj.state_dict() if isinstance(obj, torch.nn.Module) else obj
+
+
+def _snapshot_state(net):
+    """fp32 state of a network unpickled from network-snapshot-*.pkl (not yet materialised on a GPU) or of a live one."""
+    pending = getattr(net, '_pending_state', None)
+    return pending if pending is not None else net.state_dict()

@@ -1,0 +1,42 @@
+"""End to end through the two command lines: sid_train.py (distillation, snapshot) -> generate_onestep.py (PNG files)."""
+import glob
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_train_then_generate(tmp_path):
+    if not torch.cuda.is_available():
+        pytest.skip('needs an MI355X')
+    from click.testing import CliRunner
+    import generate_onestep
+    import sid_train
+    (tmp_path / 'aesthetics_6_plus.txt').write_text('\n'.join(f'prompt number {i}' for i in range(40)) + '\n')
+    runs = tmp_path / 'runs'
+    res = CliRunner().invoke(sid_train.main, [
+        '--outdir', str(runs), '--data_prompt_text', str(tmp_path), '--sd_model', 'random:tiny', '--seed', '1', '--batch', '4',
+        '--batch-gpu', '2', '--duration', '0.00004', '--ema', '0.00001', '--tick', '1', '--snap', '1', '--dump', '1',
+        '--cfg_train_fake', '1.5', '--cfg_eval_fake', '1.5', '--cfg_eval_real', '1.5', '--resolution', '128'],
+        catch_exceptions=False)
+    assert res.exit_code == 0, res.output
+    run_dir = glob.glob(str(runs / '00000-*'))[0]
+    snaps = sorted(glob.glob(os.path.join(run_dir, 'network-snapshot-*.pkl')))
+    assert snaps and glob.glob(os.path.join(run_dir, 'training-state-*.pt'))
+    assert os.path.isfile(os.path.join(run_dir, 'training_options.json'))
+
+    outs = []
+    for batch in (2, 4):
+        out = tmp_path / f'img_b{batch}'
+        res = CliRunner().invoke(generate_onestep.main, [
+            '--network', snaps[-1], '--outdir', str(out), '--seeds', '0-3', '--batch', str(batch),
+            '--text_prompts', str(tmp_path / 'aesthetics_6_plus.txt'), '--repo_id', 'random:tiny'], catch_exceptions=False)
+        assert res.exit_code == 0, res.output
+        files = sorted(glob.glob(str(out / '*.png')))
+        assert [os.path.basename(f) for f in files] == [f'{i:06d}.png' for i in range(4)]
+        outs.append([open(f, 'rb').read() for f in files])
+    assert outs[0] == outs[1]              # per-sample seeding: an image does not depend on the batch it was generated in
+    with open(glob.glob(str(tmp_path / 'img_b2' / '*.png'))[0], 'rb') as f:
+        assert f.read(8) == b'\x89PNG\r\n\x1a\n'

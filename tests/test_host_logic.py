@@ -198,3 +198,40 @@ dist.print0("REDUCER_OK", world)
                           '127.0.0.1', '--master-port', '29631', str(script)], capture_output=True, text=True, env=env, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
     assert 'REDUCER_OK 2' in out.stdout
+
+
+def test_cli_dry_run_builds_reference_config(tmp_path):
+    """sid_train.py (boundary B5): option surface + derived config of the reference CLI, no GPU needed for --dry-run."""
+    from click.testing import CliRunner
+    import sid_train
+    prompts = tmp_path / 'aesthetics_6_plus.txt'
+    prompts.write_text('a red cube\na blue sphere\n')
+    res = CliRunner().invoke(sid_train.main, [
+        '--outdir', str(tmp_path / 'runs'), '--data_prompt_text', str(tmp_path), '--sd_model', 'random:tiny', '--seed', '3',
+        '--batch', '8', '--batch-gpu', '2', '--duration', '0.01', '--ema', '0.05', '--cfg_train_fake', '1.5',
+        '--cfg_eval_fake', '1.5', '--cfg_eval_real', '1.5', '--optimizer', 'adamw', '--fp16', '1', '--dry-run'])
+    assert res.exit_code == 0, res.output
+    assert 'Dry run; exiting.' in res.output
+    o = sid_train.EasyDict(dict(
+        outdir='x', data=None, data_stat=None, data_prompt_text=str(tmp_path), duration=0.01, batch=8, batch_gpu=2, ema=0.05,
+        xflip=0.0, bench=True, cache=True, workers=1, desc=None, nosubdir=False, tick=2, snap=50, dump=100, seed=3, transfer=None,
+        resume=None, dry_run=True, metrics=None, sd_model='random:tiny', resolution=512, init_timestep=625, fp16=True, ls=1, lsg=1,
+        alpha=1, tmax=980, tmin=20, lr=1e-6, glr=2e-6, train_mode=True, network_pkl=None, cfg_train_fake=1.5, cfg_eval_fake=1.5,
+        cfg_eval_real=1.5, metric_pt_path=None, metric_clip_path=None, metric_open_clip_path=None, enable_xformers=True,
+        gradient_checkpointing=False, optimizer='adamw', num_steps=1, fake_score_use_lora=False))
+    c = sid_train.build_config(o)
+    assert c.total_kimg == 10 and c.ema_halflife_kimg == 50 and c.batch_size == 8 and c.batch_gpu == 2
+    assert c.g_optimizer_kwargs == dict(class_name='torch.optim.AdamW', lr=2e-6, betas=[0.0, 0.999], eps=1e-6, weight_decay=0.01)
+    assert c.fake_score_optimizer_kwargs['lr'] == 1e-6
+    assert c.dataset_prompt_text_kwargs['class_name'] == 'sid_lsg_amd.data.PromptDataset'
+    # errors the reference raises as ClickException
+    bad = CliRunner().invoke(sid_train.main, ['--outdir', 'x', '--data_prompt_text', str(tmp_path), '--resume', 'nope.pt', '--seed', '0', '-n'])
+    assert bad.exit_code != 0 and 'training-state' in bad.output
+
+
+def test_generate_cli_helpers():
+    import generate_onestep as g
+    assert g.parse_int_list('1,2,5-8') == [1, 2, 5, 6, 7, 8]
+    a = g.StackedRandomGenerator('cpu', [7, 8]).randn([2, 4, 3, 3])
+    b = g.StackedRandomGenerator('cpu', [8]).randn([1, 4, 3, 3])
+    assert torch.equal(a[1], b[0])          # a sample depends on its own seed only, not on the batch
