@@ -119,6 +119,19 @@ def test_glue_matches_reference_golden(dev, golden_dir):
 @pytest.mark.parametrize('kappa,alpha', [(1.5, 1.0), (1.0, 1.2)])
 def test_sid_iteration_matches_oracle(dev, kappa, alpha):
     """Two full iterations (fake-score step + generator step, 2 accumulation rounds, Adam, EMA) vs oracle/sid_ref.py."""
+    _iteration_parity(dev, 'tiny', lat=8, b=2, rounds=2, lr=2e-5, kappa=kappa, alpha=alpha, iters=2,
+                      ema_names=('conv_in.weight', 'conv_out.bias', 'mid_block.attentions.0.proj_in.weight'))
+
+
+@pytest.mark.skipif(os.environ.get('SIDLSG_FULLSIZE', '0') != '1', reason='minutes of CPU oracle time: set SIDLSG_FULLSIZE=1')
+def test_sid_iteration_full_size_config1(dev):
+    """BASELINE.json configs[0]: the reference's own CPU-runnable case -- full SD1.5 UNet (859.5 M parameters), kappa = 1.5,
+    batch 1, 64x64x4 latents; one complete iteration of the bf16 HIP path against the fp32 CPU oracle."""
+    _iteration_parity(dev, 'sd15', lat=64, b=1, rounds=1, lr=1e-6, kappa=1.5, alpha=1.0, iters=1,
+                      ema_names=('conv_in.weight', 'conv_out.bias'))
+
+
+def _iteration_parity(dev, cfg_name, lat, b, rounds, lr, kappa, alpha, iters, ema_names):
     from oracle import fixtures, sid_ref
     from oracle.scheduler_ref import DDPMSchedulerRef
     from oracle.unet_ref import CONFIGS as RC
@@ -126,7 +139,6 @@ def test_sid_iteration_matches_oracle(dev, kappa, alpha):
     from sid_lsg_amd.scheduler import DDPMScheduler
     from sid_lsg_amd.sid_step import SiDStep
     from sid_lsg_amd.unet import CONFIGS, HipUNet2DCondition
-    cfg_name, lat, b, rounds, lr = 'tiny', 8, 2, 2, 2e-5
     cfg = RC[cfg_name]
     phi_r = fixtures.make_unet(cfg_name).eval().requires_grad_(False)
     psi_r = fixtures.make_unet(cfg_name, seed=77).requires_grad_(False)   # psi != phi so the G loss is non-trivial at step 0
@@ -147,7 +159,7 @@ def test_sid_iteration_matches_oracle(dev, kappa, alpha):
               betas=(0.0, 0.999), eps=1e-8, init_t=625, batch_size=b * rounds, ema_halflife_kimg=50, ema_rampup_ratio=0.05)
     gen = torch.Generator().manual_seed(5)
     cur_nimg = 0
-    for it in range(2):
+    for it in range(iters):
         inputs = dict(A=[], B=[])
         for ph in ('A', 'B'):
             for _ in range(rounds):
@@ -181,7 +193,7 @@ def test_sid_iteration_matches_oracle(dev, kappa, alpha):
         assert frac > 0.93
     ema_r = dict(Gema_r.named_parameters())
     for n, p in G_ema.named_parameters():
-        if n in ('conv_in.weight', 'conv_out.bias', 'mid_block.attentions.0.proj_in.weight'):
+        if n in ema_names:
             e, _ = rel_err(p, ema_r[n])
             # max-norm relative error; the only source of difference is the ~0.1 % of weights whose +-lr Adam step
             # (beta1 = 0) has the opposite sign because their gradient is ~0
