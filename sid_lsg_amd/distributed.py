@@ -64,6 +64,20 @@ class FlatGradReducer:
         self.stream = torch.cuda.Stream() if torch.cuda.is_available() else None
         self.handles = []
 
+    def start_range(self, flat_grad, lo, hi, max_elems=1 << 28):
+        """all-reduce flat_grad[lo:hi] (in messages of <= max_elems elements = 1 GiB fp32) on the communication stream,
+        ordered after everything already enqueued on the current stream.  Several ranges may be in flight; wait() joins all."""
+        if get_world_size() == 1 or hi <= lo:
+            return
+        if self.stream is not None:
+            self.stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self.stream):
+                for o in range(lo, hi, max_elems):
+                    self.handles.append(torch.distributed.all_reduce(flat_grad[o:min(hi, o + max_elems)], group=self.group, async_op=True))
+        else:
+            for o in range(lo, hi, max_elems):
+                self.handles.append(torch.distributed.all_reduce(flat_grad[o:min(hi, o + max_elems)], group=self.group, async_op=True))
+
     def start(self, flat_grad):
         if get_world_size() == 1:
             return

@@ -544,6 +544,26 @@ def transpose_w(src_f32, n, k, taps=1):
     return dst
 
 
+class _GradReady(torch.autograd.Function):
+    """Identity whose backward calls `cb()` before passing the gradient on: placed at a block boundary in the forward, it
+    fires when the backward has finished everything AFTER that boundary (autograd runs ready nodes with the highest
+    sequence number first, and the marker is older than every node of the blocks behind it)."""
+
+    @staticmethod
+    def forward(ctx, x, cb):
+        ctx.cb = cb
+        return x.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, g):
+        ctx.cb()
+        return g, None
+
+
+def grad_ready_marker(x, cb):
+    return _GradReady.apply(x, cb) if (cb is not None and x.requires_grad) else x
+
+
 def transpose_w_batched(jobs, njobs, nblocks):
     """jobs: device uint8 tensor holding njobs sidlsg_tw_job records (see include/sidlsg_hip.h)."""
     lib.sidlsg_transpose_w_batched(_p(jobs), njobs, nblocks, _s())

@@ -14,6 +14,8 @@ Differences from the reference that do NOT change the math (DESIGN.md "Step"):
     mean is folded into the optimizer kernel;
   * EMA, bf16 weight refresh and zero_grad are fused into the optimizer kernel.
 """
+import os
+
 import torch
 
 from . import ops
@@ -30,6 +32,7 @@ class SiDStep:
         self.ls, self.lsg, self.bgt = float(loss_scaling), float(loss_scaling_G), int(batch_gpu_total)
         self.init_timestep = int(init_timestep)
         self.reducer, self.world = reducer, world_size
+        self.overlap_g = os.environ.get('SIDLSG_OVERLAP_G', '1') != '0'    # A/B switch; results are identical either way
         opt_fake.grad_scale = opt_G.grad_scale = 1.0 / world_size     # DDP mean, folded into the optimizer kernel
         opt_fake.attach(ema=None, w16=fake_score.flat_w16)
         opt_G.attach(ema=(G_ema.flat_params if (G_ema is not None and G_ema is not G) else None), w16=G.flat_w16)
@@ -85,10 +88,19 @@ class SiDStep:
         self.G.requires_grad_(True)                                                 # :468
         self.psi.requires_grad_(False)
         loss = None
+        overlap = self.reducer is not None and self.world > 1 and self.overlap_g
+        segs = self.G.grad_segments() if overlap else None
         for i, r in enumerate(rounds):
+            if overlap and i == len(rounds) - 1:
+                # last accumulation round (what DDP does outside no_sync): a segment of the flat gradient is exchanged as
+                # soon as the backward has passed it, while the earlier layers' backward is still running
+                self.G.set_grad_ready_callback(lambda k: self.reducer.start_range(self.G.flat_grads, *segs[k]))
             loss = self.generator_round(r, before_fake_eval if i == 0 else None)
         self.G.requires_grad_(False)                                                # :538
-        self._optimizer_step(self.G, self.opt_G, ema_beta=ema_beta)                 # :541-565
+        if overlap:
+            self.G.set_grad_ready_callback(None)
+            self.reducer.start_range(self.G.flat_grads, *segs[2])
+        self._optimizer_step(self.G, self.opt_G, ema_beta=ema_beta, started=overlap)   # :541-565
         return loss
 
     # ---- optimizer + data-parallel exchange ------------------------------------------------------

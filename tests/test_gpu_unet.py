@@ -232,3 +232,35 @@ def test_training_loop_end_to_end(dev, tmp_path):
     # resume from the dumped state runs
     kw.update(resume_training=str(state), total_kimg=0.004)
     training_loop(**kw)
+
+
+def test_grad_segments_complete_when_marker_fires(dev):
+    """The overlapped data-parallel exchange starts a segment's all-reduce from an autograd marker: at that moment the
+    segment's gradients must already be final.  Snapshot each segment when its marker fires and compare with the
+    gradient buffer after the whole backward (bit exact: nothing may accumulate into a segment afterwards)."""
+    from oracle.unet_ref import CONFIGS as RC
+    from sid_lsg_amd.unet import CONFIGS, HipUNet2DCondition
+    for cfg_name, lat in (('tiny', 16), ('tiny40', 8)):
+        cfg = RC[cfg_name]
+        net = HipUNet2DCondition(CONFIGS[cfg_name]).materialize(dev, seed=3)
+        net.requires_grad_(True)
+        segs = net.grad_segments()
+        assert segs[0][1] == net.flat_grads.numel() and segs[2][0] == 0 and segs[0][0] == segs[1][1] and segs[1][0] == segs[2][1]
+        snaps, order = {}, []
+
+        def cb(k):
+            order.append(k)
+            lo, hi = segs[k]
+            snaps[k] = net.flat_grads[lo:hi].clone()
+        net.set_grad_ready_callback(cb)
+        g = torch.Generator().manual_seed(1)
+        x = torch.randn(2, 4, lat, lat, generator=g).to(dev).requires_grad_()
+        ctx = torch.randn(2, cfg.text_len, cfg.cross_attention_dim, generator=g).to(dev).to(BF16)
+        y = net(x, torch.tensor([625, 37], device=dev), encoder_hidden_states=ctx).sample
+        y.backward(torch.randn(y.shape, generator=g).to(dev))
+        net.set_grad_ready_callback(None)
+        assert order == [0, 1], order
+        for k in (0, 1):
+            lo, hi = segs[k]
+            assert snaps[k].abs().sum() > 0
+            assert torch.equal(snaps[k], net.flat_grads[lo:hi]), f'{cfg_name}: segment {k} changed after its marker fired'

@@ -191,6 +191,20 @@ red.start(g); red.wait()
 expect = torch.arange(10007, dtype=torch.float32) * 3
 assert torch.equal(g, expect), (g[:4], expect[:4])
 assert torch.allclose(g / world, torch.arange(10007, dtype=torch.float32) * 1.5)
+# segment-wise exchange (overlap of the generator's exchange with its own backward): ranges in completion order,
+# several in flight, one wait; plus the autograd marker that triggers them
+g2 = torch.arange(10007, dtype=torch.float32) * (rank + 1)
+fired = []
+x = torch.ones(4, requires_grad=True)
+from sid_lsg_amd import ops
+def cb(k, segs=[(7000, 10007), (4000, 7000)]):
+    fired.append(k); red.start_range(g2, *segs[k], max_elems=1024)
+h = ops.grad_ready_marker(x * 2.0, lambda: cb(1))
+h = ops.grad_ready_marker(h * 3.0, lambda: cb(0))
+(h * 5.0).sum().backward()
+assert fired == [0, 1] and torch.equal(x.grad, torch.full((4,), 30.0))
+red.start_range(g2, 0, 4000); red.wait()
+assert torch.equal(g2, expect)
 dist.print0("REDUCER_OK", world)
 ''')
     env = dict(os.environ, MASTER_ADDR='127.0.0.1')
