@@ -151,7 +151,7 @@ DEVFN void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[NT][MT], int mbase, i
 }
 
 
-template <int BM, int BN, int MODE, int VAR = 0>
+template <int BM, int BN, int MODE>
 __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_kernel(GemmParams p) {   // 2 blocks/CU: <= 256 registers
     constexpr int WMT = BM / 2, WNT = BN / 2;   // wave tile
     constexpr int MT = WMT / 16, NT = WNT / 16;
@@ -247,10 +247,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_kernel(GemmParams p) { 
                 areg[i] = buf_ld8(ra, ok ? abase[i] - kc * 16u + ((unsigned)(hi * Ws + wi) * (unsigned)p.lda + (unsigned)c) * 2u : OOB);
             }
         }
-        if (!(VAR & 128)) {
 #pragma unroll
-            for (int i = 0; i < BR; i++) breg[i] = buf_ld8(rw, kok ? bbase[i] + (unsigned)k0 * 2u : OOB);
-        }
+        for (int i = 0; i < BR; i++) breg[i] = buf_ld8(rw, kok ? bbase[i] + (unsigned)k0 * 2u : OOB);
     };
     auto store_tile = [&](int buf) {
         bf16* a = As + buf * BM * BK;
@@ -260,12 +258,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_kernel(GemmParams p) { 
             const int r = r0 + 32 * i;
             st8(a + r * BK + ((kc ^ ((r >> 1) & 7)) << 3), areg[i]);
         }
-        if (!(VAR & 128)) {
 #pragma unroll
-            for (int i = 0; i < BR; i++) {
-                const int r = r0 + 32 * i;
-                st8(b + r * BK + ((kc ^ ((r >> 1) & 7)) << 3), breg[i]);
-            }
+        for (int i = 0; i < BR; i++) {
+            const int r = r0 + 32 * i;
+            st8(b + r * BK + ((kc ^ ((r >> 1) & 7)) << 3), breg[i]);
         }
     };
 
@@ -288,34 +284,19 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_kernel(GemmParams p) { 
     const int kt_begin = p.kt_per_split ? blockIdx.y * p.kt_per_split : 0;
     const int nk = p.kt_per_split ? min(nk_all, kt_begin + p.kt_per_split) : nk_all;
 
-    // VAR & 128: weight fragments bypass LDS (buffer loads in MFMA fragment layout, served by L2): LDS carries only the A tile
-    unsigned woff[NT];
-#pragma unroll
-    for (int ni = 0; ni < NT; ni++) {
-        const int n = n0 + wrow[ni];
-        woff[ni] = n < p.N ? (unsigned)n * (unsigned)p.K * 2u : OOB;
-    }
-    auto read_frags = [&](int kt, int buf, int kk, bf16x8 (&fa)[MT], bf16x8 (&fw)[NT]) {
+    auto read_frags = [&](int buf, int kk, bf16x8 (&fa)[MT], bf16x8 (&fw)[NT]) {
         const bf16* a = As + buf * BM * BK;
         const bf16* b = Bs + buf * BN * BK;
         const int ch = kk * 4 + lg;
-        if (VAR & 128) {
-            const int k = kt * BK + ch * 8;
-            const unsigned ko = k < p.K ? (unsigned)k * 2u : OOB;
-#pragma unroll
-            for (int ni = 0; ni < NT; ni++) fw[ni] = buf_ld8(rw, woff[ni] + ko);
-        }
 #pragma unroll
         for (int mi = 0; mi < MT; mi++) {
             const int r = wm0 + mi * 16 + li;
             fa[mi] = *reinterpret_cast<const bf16x8*>(a + r * BK + ((ch ^ ((r >> 1) & 7)) << 3));
         }
-        if (!(VAR & 128)) {
 #pragma unroll
-            for (int ni = 0; ni < NT; ni++) {
-                const int r = wrow[ni];
-                fw[ni] = *reinterpret_cast<const bf16x8*>(b + r * BK + ((ch ^ ((r >> 1) & 7)) << 3));
-            }
+        for (int ni = 0; ni < NT; ni++) {
+            const int r = wrow[ni];
+            fw[ni] = *reinterpret_cast<const bf16x8*>(b + r * BK + ((ch ^ ((r >> 1) & 7)) << 3));
         }
     };
     auto mfma_block = [&](const bf16x8 (&fa)[MT], const bf16x8 (&fw)[NT]) {
@@ -336,26 +317,20 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_kernel(GemmParams p) { 
     load_tile(kt_begin);
     store_tile(0);
     __syncthreads();
-    read_frags(kt_begin, 0, 0, fa0, fw0);
+    read_frags(0, 0, fa0, fw0);
     if (kt_begin + 1 < nk) load_tile(kt_begin + 1);
     for (int kt = kt_begin; kt < nk; kt++) {
         const int buf = (kt - kt_begin) & 1;
         const bool more = kt + 1 < nk;
-        read_frags(kt, buf, 1, fa1, fw1);          // A
-        if (!(VAR & 32)) mfma_block(fa0, fw0);
-        if (more && !(VAR & 16)) store_tile(buf ^ 1);         // B
+        read_frags(buf, 1, fa1, fw1);          // A
+        mfma_block(fa0, fw0);
+        if (more) store_tile(buf ^ 1);         // B
         __syncthreads();                       // C
         if (more) {                            // D
-            read_frags(kt + 1, buf ^ 1, 0, fa0, fw0);
-            if (kt + 2 < nk && !(VAR & 64)) load_tile(kt + 2);
+            read_frags(buf ^ 1, 0, fa0, fw0);
+            if (kt + 2 < nk) load_tile(kt + 2);
         }
-        if (!(VAR & 32)) mfma_block(fa1, fw1);                  // E
-        if (VAR & 32) {   // ablation: keep the fragment reads alive without MFMAs
-#pragma unroll
-            for (int mi = 0; mi < MT; mi++) { asm volatile("" :: "v"(fa0[mi]), "v"(fa1[mi])); }
-#pragma unroll
-            for (int ni = 0; ni < NT; ni++) { asm volatile("" :: "v"(fw0[ni]), "v"(fw1[ni])); }
-        }
+        mfma_block(fa1, fw1);                  // E
     }
 
     if (p.kt_per_split) {
@@ -413,201 +388,11 @@ static float* g_ws = nullptr;          // set by sidlsg_set_workspace (host-allo
 static long long g_ws_bytes = 0;
 
 // ---------------------------------------------------------------------------------------------
-// "v2" main loop for large grids: 256 x 160 x 64 tile, 8 waves (4 x 2, same 64 x 80 wave tile), a 3-stage LDS ring
-// (3 x 52 KiB = 156 KiB, one block per CU) filled by direct-to-LDS loads (global_load_lds_dwordx4: no staging
-// registers, no ds_write pass).  Tile kt+2 is in flight while tile kt is multiplied: a load has two K-tiles of
-// MFMA work to hide behind, with ONE raw s_barrier per K-tile and a counted s_waitcnt vmcnt(N) that leaves the
-// younger tile's loads outstanding across the barrier (MI355X guide: "Pipelining across barriers").
-// The LDS image is lane-linear per wave instruction (8 rows x 128 B), so the bank swizzle is applied to the
-// SOURCE address (lane fetches chunk (lane&7) ^ swz(row)) and again on the fragment read.  Out-of-image taps /
-// rows >= M read a 16-byte zero page instead of being branched around.
-__device__ __attribute__((aligned(16))) unsigned g_zero_page[64];
-
-constexpr int V2_BM = 256, V2_BN = 160, V2_THREADS = 512, V2_STAGES = 3;
-constexpr int V2_STAGE_ELEMS = (V2_BM + V2_BN) * BK;
-
+// Direct-to-LDS (buffer_load ... lds) kernels.  (A 256 x 160 / 8-wave / 3-stage-ring variant "v2" and a
+// 256 x 160 / one-wave-per-SIMD / 32x32x16-MFMA variant "v5" were built and measured -- both correct, both slower
+// than v3 on every SD shape; they live in the git history, not in the build.)
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
-
-template <int MODE, int VAR = 0>   // 0 dense, 1 conv3x3 with Cin % 64 == 0
-__global__ __launch_bounds__(V2_THREADS, 2) void gemm_v2_kernel(GemmParams p) {
-    constexpr int MT = 4, NT = 5;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    bf16* ring = reinterpret_cast<bf16*>(smem);
-
-    const int tiles_n = (p.N + V2_BN - 1) / V2_BN;
-    const int tiles_m = (p.M + V2_BM - 1) / V2_BM;
-    const int nblk = tiles_n * tiles_m;
-    int bid = blockIdx.x;
-    {
-        const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
-    const int m0 = (bid / tiles_n) * V2_BM;
-    const int n0 = (bid % tiles_n) * V2_BN;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 80;
-    const int li = lane & 15, lg = lane >> 4;
-    const int lrow = lane >> 3, lslot = lane & 7;
-    const char* zero = reinterpret_cast<const char*>(g_zero_page);
-
-    // ---- loader state.  A: wave w fills rows [32w, 32w+32) with 4 instructions of 8 rows; B: 8-row groups w, w+8, w+16 (< 20)
-    const int Hs = p.ups ? (p.H >> 1) : p.H, Ws = p.ups ? (p.Wd >> 1) : p.Wd;
-    const char* abase[4];
-    int ahi[4], awi[4];
-    const char* arow[4];
-    bool aval[4];
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-        const int r = wave * 32 + j * 8 + lrow;
-        const int kcs = lslot ^ ((r >> 1) & 7);          // the 16-byte chunk this lane must fetch for its LDS slot
-        const int m = m0 + r;
-        const bool ok = m < p.M;
-        if (MODE == 0) {
-            abase[j] = reinterpret_cast<const char*>(p.A) + ((size_t)(ok ? m : 0) * p.lda + kcs * 8) * 2;
-            aval[j] = ok; arow[j] = abase[j]; ahi[j] = awi[j] = 0;
-        } else {
-            const int mm = ok ? m : 0;
-            const int hw = p.Ho * p.Wo;
-            const int b = mm / hw, rem = mm - b * hw;
-            const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
-            abase[j] = reinterpret_cast<const char*>(p.A) + ((size_t)b * Hs * Ws * p.lda + kcs * 8) * 2;
-            ahi[j] = ok ? ho * p.stride - 1 : -100000;
-            awi[j] = wo * p.stride - 1;
-            aval[j] = false; arow[j] = zero;
-        }
-    }
-    const char* bbase[3];
-    bool bval[3], bact[3];
-#pragma unroll
-    for (int j = 0; j < 3; j++) {
-        const int g = wave + 8 * j;
-        bact[j] = g < V2_BN / 8;                               // wave-uniform
-        const int r = g * 8 + lrow;
-        const int kcs = lslot ^ ((r >> 1) & 7);
-        const int n = n0 + r;
-        bval[j] = bact[j] && n < p.N;
-        bbase[j] = reinterpret_cast<const char*>(p.W) + ((size_t)(bval[j] ? n : 0) * p.K + kcs * 8) * 2;
-    }
-    // the k offset of this lane's chunk inside a K-tile depends on the (swizzled) chunk index of each row; for the K-tail test
-    // (dense only, K % 64 != 0) use the largest chunk index conservatively per row below.
-    const int nk = (p.K + BK - 1) / BK;
-    int cur_tap = -1;
-
-    auto issue = [&](int t, int stage) {
-        bf16* sa = ring + stage * V2_STAGE_ELEMS;
-        bf16* sb = sa + V2_BM * BK;
-        const bool live = t < nk;
-        const int k0 = t * BK;
-        int c0 = 0;
-        if (MODE == 1 && live) {
-            const int tap = k0 / p.Cin;
-            c0 = k0 - tap * p.Cin;
-            if (tap != cur_tap) {
-                cur_tap = tap;
-                const int dh = tap / 3, dw = tap - dh * 3;
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    int hi = ahi[j] + dh, wi = awi[j] + dw;
-                    aval[j] = hi >= 0 && hi < p.H && wi >= 0 && wi < p.Wd;
-                    if (p.ups) { hi >>= 1; wi >>= 1; }
-                    arow[j] = abase[j] + (size_t)(hi * Ws + wi) * p.lda * 2;
-                }
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const int r = wave * 32 + j * 8 + lrow;
-            const int kcs = lslot ^ ((r >> 1) & 7);
-            const bool kok = k0 + kcs * 8 < p.K;
-            const char* src = (live && aval[j] && kok) ? arow[j] + (size_t)(MODE == 0 ? k0 : c0) * 2 : zero;
-            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sa + (wave * 32 + j * 8) * BK), 16, 0, 0);
-        }
-#pragma unroll
-        for (int j = 0; j < 3; j++) {
-            if (bact[j]) {
-                const int g = wave + 8 * j;
-                const int r = g * 8 + lrow;
-                const int kcs = lslot ^ ((r >> 1) & 7);
-                const bool kok = k0 + kcs * 8 < p.K;
-                const char* src = (live && bval[j] && kok) ? bbase[j] + (size_t)k0 * 2 : zero;
-                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sb + g * 8 * BK), 16, 0, 0);
-            }
-        }
-    };
-
-    f32x4 acc[NT][MT];
-#pragma unroll
-    for (int i = 0; i < NT; i++)
-#pragma unroll
-        for (int j = 0; j < MT; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    int wrow[NT];
-#pragma unroll
-    for (int ni = 0; ni < NT; ni++) {
-        const bool paired = (ni | 1) < NT;
-        wrow[ni] = wn0 + (paired ? 32 * (ni >> 1) + (li >> 2) * 8 + (ni & 1) * 4 + (li & 3) : 16 * ni + li);
-    }
-
-    issue(0, 0);
-    issue(1, 1);
-    int st_cur = 0, st_nxt = 2;
-    for (int kt = 0; kt < nk; kt++) {
-        // tile kt landed for THIS wave once at most the younger tile's loads are outstanding (7 per tile for waves 0-3, 6 for 4-7)
-        if (VAR & 64) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else if (wave < 4) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        __builtin_amdgcn_s_barrier();            // everyone's part of tile kt is in LDS; everyone is done reading tile kt-1
-        asm volatile("" ::: "memory");
-        if (!(VAR & 64) || kt == 0) issue(kt + 2, st_nxt);   // refill the stage tile kt-1 lived in (dummy zero loads past the end keep the count fixed)
-        const bf16* a = ring + st_cur * V2_STAGE_ELEMS;
-        const bf16* b = a + V2_BM * BK;
-#pragma unroll
-        for (int kk = 0; kk < 2; kk++) {
-            bf16x8 fa[MT], fw[NT];
-            const int ch = kk * 4 + lg;
-#pragma unroll
-            for (int mi = 0; mi < MT; mi++) {
-                const int r = wm0 + mi * 16 + li;
-                fa[mi] = *reinterpret_cast<const bf16x8*>(a + r * BK + ((ch ^ ((r >> 1) & 7)) << 3));
-            }
-#pragma unroll
-            for (int ni = 0; ni < NT; ni++) {
-                const int r = wrow[ni];
-                fw[ni] = *reinterpret_cast<const bf16x8*>(b + r * BK + ((ch ^ ((r >> 1) & 7)) << 3));
-            }
-            if (!(VAR & 32)) {
-#pragma unroll
-                for (int ni = 0; ni < NT; ni++)
-#pragma unroll
-                    for (int mi = 0; mi < MT; mi++)
-                        acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[ni], fa[mi], acc[ni][mi], 0, 0, 0);
-            } else {
-#pragma unroll
-                for (int mi = 0; mi < MT; mi++) asm volatile("" :: "v"(fa[mi]));
-#pragma unroll
-                for (int ni = 0; ni < NT; ni++) asm volatile("" :: "v"(fw[ni]));
-            }
-        }
-        st_cur = st_cur == V2_STAGES - 1 ? 0 : st_cur + 1;
-        st_nxt = st_nxt == V2_STAGES - 1 ? 0 : st_nxt + 1;
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the trailing dummy loads before the LDS is released
-    gemm_epilogue<MT, NT>(p, acc, m0 + wm0, n0 + wn0, li, lg);
-}
-
-template <int MODE, int VAR = 0>
-static int launch_gemm_v2(const GemmParams& p, hipStream_t s) {
-    const int tiles = ((p.M + V2_BM - 1) / V2_BM) * ((p.N + V2_BN - 1) / V2_BN);
-    const size_t lds = (size_t)V2_STAGES * V2_STAGE_ELEMS * sizeof(bf16);
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_v2_kernel<MODE, VAR>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_done = true;
-    }
-    hipLaunchKernelGGL((gemm_v2_kernel<MODE, VAR>), dim3(tiles), dim3(V2_THREADS), lds, s, p);
-    return sidlsg_last_error();
-}
 
 // ---------------------------------------------------------------------------------------------
 // "v3": the 128 x 160 x 64 tile / 4 waves / 2 blocks per CU structure of gemm_bf16_kernel, but tiles are staged by
@@ -859,314 +644,19 @@ static int launch_gemm_v3(const GemmParams& p, hipStream_t s) {
     return sidlsg_last_error();
 }
 
-// ---------------------------------------------------------------------------------------------
-// "v5": 256 x 160 x 64 tile, 4 waves, ONE wave per SIMD (512 registers), 32x32x16 MFMA.  Wave w owns rows
-// [64w, 64w+64) x all 160 columns = 2 x 5 MFMA blocks (160 accumulator registers): per K=16 step it reads 2 A + 5 W
-// fragments for 10 MFMAs of 32 cycles -- 22 % less LDS traffic per MFMA cycle than the 64x80 wave tile of v3, a W tile
-// shared by 256 rows (28 % less L2->LDS traffic), and every phase overlapped INSIDE the wave: fragment reads and the
-// DMA are spread between the MFMAs with sched_group_barrier (v3 relies on the second block of the CU for overlap, and
-// its ablations show the LDS, DMA and MFMA phases adding up instead).  Same loader as v3 (buffer_load ... lds, one
-// 32-bit offset per row), 2 LDS stages of 52 KiB, one barrier per K-tile in the middle of the tile:
-//   steps 0,1 (MFMA) | reads of steps 1,2,3          -> s_waitcnt vmcnt(0) ; s_barrier  (tile kt+1 landed, tile kt read)
-//   steps 2,3 (MFMA) | reads of step 0 of tile kt+1, DMA of tile kt+2 into the buffer just vacated
-// Epilogue: the 32x32 accumulator holds 4-channel runs interleaved between lanes l and l+32; v_permlane32_swap turns
-// them into 8-channel runs so that every lane stores 16 bytes.
-constexpr int V5_BM = 256, V5_BN = 160;
-constexpr int V5_STAGE = (V5_BM + V5_BN) * BK;
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-// one 8-channel run of the output row m (N % 8 == 0 guaranteed by the dispatcher): same semantics as gemm_epilogue
-DEVFN void epilogue_run8(const GemmParams& p, int m, int n, float (&v)[8]) {
-    float bb[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (p.bias) {
-        const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.bias + n), b1 = *reinterpret_cast<const f32x4*>(p.bias + n + 4);
-#pragma unroll
-        for (int e = 0; e < 4; e++) { bb[e] = b0[e]; bb[4 + e] = b1[e]; }
-    }
-    if (p.rowvec) {
-        const float* rv = p.rowvec + (size_t)(m / p.rows_per_batch) * p.N + n;
-        const f32x4 b0 = *reinterpret_cast<const f32x4*>(rv), b1 = *reinterpret_cast<const f32x4*>(rv + 4);
-#pragma unroll
-        for (int e = 0; e < 4; e++) { bb[e] += b0[e]; bb[4 + e] += b1[e]; }
-    }
-    if (p.res) {
-        const bf16x8 t = ld8(p.res + (size_t)m * p.ldres + n);
-#pragma unroll
-        for (int e = 0; e < 8; e++) bb[e] += bf2f(t[e]);
-    }
-#pragma unroll
-    for (int e = 0; e < 8; e++) {
-        float x = v[e] * p.alpha + bb[e];
-        if (p.flags & F_SILU) x = silu_f(x);
-        v[e] = x;
-    }
-    if (p.flags & F_OUT_F32) {
-        float* c = reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n;
-        if (p.flags & F_ACCUM) {
-#pragma unroll
-            for (int e = 0; e < 8; e++) c[e] += v[e];
-        } else {
-            *reinterpret_cast<f32x4*>(c) = (f32x4){v[0], v[1], v[2], v[3]};
-            *reinterpret_cast<f32x4*>(c + 4) = (f32x4){v[4], v[5], v[6], v[7]};
-        }
-    } else {
-        bf16x8 o;
-#pragma unroll
-        for (int e = 0; e < 8; e++) o[e] = f2bf(v[e]);
-        st8(reinterpret_cast<bf16*>(p.C) + (size_t)m * p.ldc + n, o);
-    }
-}
-
-template <int MODE>   // 0 dense, 1 conv3x3 with Cin % 64 == 0
-__global__ __launch_bounds__(256, 1) void gemm_v5_kernel(GemmParams p) {
-    constexpr int MB = 2, NB = 5;          // 32x32 blocks per wave
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    bf16* ring = reinterpret_cast<bf16*>(smem);
-
-    const int tiles_n = (p.N + V5_BN - 1) / V5_BN;
-    const int tiles_m = (p.M + V5_BM - 1) / V5_BM;
-    const int nblk = tiles_n * tiles_m;
-    int bid = blockIdx.x;
-    {
-        const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
-    const int m0 = (bid / tiles_n) * V5_BM;
-    const int n0 = (bid % tiles_n) * V5_BN;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm0 = wave * 64;
-    const int l32 = lane & 31, lh = lane >> 5;
-    const int lrow = lane >> 3, lslot = lane & 7;
-
-    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(p.A), 0, (int)p.a_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(p.W), 0, (int)p.w_bytes, 0x00020000);
-    const int Hs = p.ups ? (p.H >> 1) : p.H, Ws = p.ups ? (p.Wd >> 1) : p.Wd;
-    // A: wave w stages its own 64 rows (8 loads of 8 rows); W: 20 groups of 8 rows, 5 per wave
-    unsigned abase[8], aoff[8], boff[5];
-    int ahi[8], awi[8];
-#pragma unroll
-    for (int j = 0; j < 8; j++) {
-        const int r = wm0 + j * 8 + lrow;
-        const int kcs = lslot ^ ((r >> 1) & 7);
-        const int m = m0 + r;
-        const bool ok = m < p.M;
-        if (MODE == 0) {
-            aoff[j] = ok ? ((unsigned)m * (unsigned)p.lda + kcs * 8) * 2u : OOB;
-            abase[j] = 0; ahi[j] = awi[j] = 0;
-        } else {
-            const int mm = ok ? m : 0;
-            const int hw = p.Ho * p.Wo;
-            const int b = mm / hw, rem = mm - b * hw;
-            const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
-            abase[j] = ((unsigned)(b * Hs * Ws) * (unsigned)p.lda + kcs * 8) * 2u;
-            ahi[j] = ok ? ho * p.stride - 1 : -100000;
-            awi[j] = wo * p.stride - 1;
-            aoff[j] = OOB;
-        }
-    }
-#pragma unroll
-    for (int j = 0; j < 5; j++) {
-        const int r = (wave + 4 * j) * 8 + lrow;
-        const int kcs = lslot ^ ((r >> 1) & 7);
-        const int n = n0 + r;
-        boff[j] = n < p.N ? ((unsigned)n * (unsigned)p.K + kcs * 8) * 2u : OOB;
-    }
-    const int nk = (p.K + BK - 1) / BK;
-    int cur_tap = -1;
-    unsigned ao[8], bo[5];
-    int asoff = 0, bsoff = 0;
-    auto prepare = [&](int t) {      // offsets of K-tile t (branchy but rare); past the end: all out of range (zeros)
-        const int k0 = t * BK;
-        if (t >= nk) {
-#pragma unroll
-            for (int j = 0; j < 8; j++) ao[j] = OOB;
-#pragma unroll
-            for (int j = 0; j < 5; j++) bo[j] = OOB;
-            asoff = bsoff = 0;
-            return;
-        }
-        asoff = k0 * 2; bsoff = k0 * 2;
-        if (MODE == 1) {
-            const int tap = k0 / p.Cin;
-            asoff = (k0 - tap * p.Cin) * 2;
-            if (tap != cur_tap) {
-                cur_tap = tap;
-                const int dh = tap / 3, dw = tap - dh * 3;
-#pragma unroll
-                for (int j = 0; j < 8; j++) {
-                    int hi = ahi[j] + dh, wi = awi[j] + dw;
-                    const bool v = hi >= 0 && hi < p.H && wi >= 0 && wi < p.Wd;
-                    if (p.ups) { hi >>= 1; wi >>= 1; }
-                    aoff[j] = v ? abase[j] + (unsigned)(hi * Ws + wi) * (unsigned)p.lda * 2u : OOB;
-                }
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < 8; j++) ao[j] = aoff[j];
-#pragma unroll
-        for (int j = 0; j < 5; j++) bo[j] = boff[j];
-        if (MODE == 0 && k0 + BK > p.K) {       // ragged K tail (dense only)
-#pragma unroll
-            for (int j = 0; j < 8; j++) {
-                const int r = wm0 + j * 8 + lrow;
-                if (k0 + (lslot ^ ((r >> 1) & 7)) * 8 >= p.K) ao[j] = OOB;
-            }
-#pragma unroll
-            for (int j = 0; j < 5; j++) {
-                const int r = (wave + 4 * j) * 8 + lrow;
-                if (k0 + (lslot ^ ((r >> 1) & 7)) * 8 >= p.K) bo[j] = OOB;
-            }
-        }
-    };
-    auto fire = [&](int buf) {       // 13 buffer_load ... lds, branch-free
-        bf16* sa = ring + buf * V5_STAGE;
-        bf16* sb = sa + V5_BM * BK;
-#pragma unroll
-        for (int j = 0; j < 8; j++)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lptr_t)(sa + (wm0 + j * 8) * BK), 16, ao[j], asoff, 0, 0);
-#pragma unroll
-        for (int j = 0; j < 5; j++)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lptr_t)(sb + (wave + 4 * j) * 8 * BK), 16, bo[j], bsoff, 0, 0);
-    };
-
-    f32x16 acc[NB][MB];
-#pragma unroll
-    for (int i = 0; i < NB; i++)
-#pragma unroll
-        for (int j = 0; j < MB; j++)
-#pragma unroll
-            for (int e = 0; e < 16; e++) acc[i][j][e] = 0.f;
-
-    // fragment of K=16 step s: lane (l32, lh) reads row l32 (+32 per block), 16-byte chunk 2s + lh, swizzled with (row>>1)&7
-    // (rows of all blocks of a lane differ by multiples of 32, so one swizzle value per lane)
-    const int xs = lh ^ ((l32 >> 1) & 7);
-    struct Frags { bf16x8 a[MB], w[NB]; };
-    auto read_step = [&](int buf, int st, Frags& f) {
-        const bf16* a = ring + buf * V5_STAGE + (wm0 + l32) * BK + ((xs ^ (2 * st)) << 3);
-        const bf16* b = ring + buf * V5_STAGE + V5_BM * BK + l32 * BK + ((xs ^ (2 * st)) << 3);
-#pragma unroll
-        for (int mi = 0; mi < MB; mi++) f.a[mi] = *reinterpret_cast<const bf16x8*>(a + mi * 32 * BK);
-#pragma unroll
-        for (int nb = 0; nb < NB; nb++) f.w[nb] = *reinterpret_cast<const bf16x8*>(b + nb * 32 * BK);
-    };
-    auto mfma_step = [&](const Frags& f) {
-#pragma unroll
-        for (int nb = 0; nb < NB; nb++)
-#pragma unroll
-            for (int mi = 0; mi < MB; mi++)
-                acc[nb][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.w[nb], f.a[mi], acc[nb][mi], 0, 0, 0);
-    };
-
-    Frags f0, f1, f2, f3;
-    prepare(0);
-    fire(0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    read_step(0, 0, f0);
-    prepare(1);
-    fire(1);
-    for (int kt = 0; kt < nk; kt++) {
-        const int buf = kt & 1;
-        prepare(kt + 2);
-        __builtin_amdgcn_sched_barrier(0);
-        // steps 0,1 | reads of steps 1,2,3 (21 ds_read_b128 spread over 20 MFMAs)
-        mfma_step(f0);
-        read_step(buf, 1, f1);
-        mfma_step(f1);
-        read_step(buf, 2, f2);
-        read_step(buf, 3, f3);
-#pragma unroll
-        for (int i = 0; i < 7; i++) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-        }
-        __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
-#pragma unroll
-        for (int i = 0; i < 7; i++) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-        }
-        __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");    // tile kt+1 landed; my reads of tile kt are done
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        // steps 2,3 | reads of step 0 of tile kt+1 (stale data past the last tile, never used), DMA of tile kt+2
-        mfma_step(f2);
-        read_step(buf ^ 1, 0, f0);
-        mfma_step(f3);
-        fire(buf);
-#pragma unroll
-        for (int i = 0; i < 7; i++) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 1);
-        }
-        __builtin_amdgcn_sched_group_barrier(0x008, 3, 1);
-#pragma unroll
-        for (int i = 0; i < 6; i++) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
-            __builtin_amdgcn_sched_group_barrier(0x020, 2, 1);
-        }
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
-        __builtin_amdgcn_sched_group_barrier(0x020, 1, 1);
-        __builtin_amdgcn_sched_group_barrier(0x008, 3, 1);
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the trailing dummy loads before the LDS is released
-
-    // ---- epilogue.  acc[nb][mi][4j+e] = C[m = .. + 32 mi + l32][n = .. + 32 nb + 8 j + 4 lh + e]
-#pragma unroll
-    for (int mi = 0; mi < MB; mi++) {
-        const int m = m0 + wm0 + 32 * mi + l32;
-#pragma unroll
-        for (int nb = 0; nb < NB; nb++) {
-            float va[8], vb[8];
-#pragma unroll
-            for (int e = 0; e < 4; e++) {
-                // (j=0, j=2) -> lanes < 32: channels e, 4+e ; lanes >= 32: 16+e, 20+e
-                const auto s02 = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[nb][mi][e]), __float_as_uint(acc[nb][mi][8 + e]), false, false);
-                va[e] = __uint_as_float(s02[0]); va[4 + e] = __uint_as_float(s02[1]);
-                // (j=1, j=3) -> lanes < 32: 8+e, 12+e ; lanes >= 32: 24+e, 28+e
-                const auto s13 = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[nb][mi][4 + e]), __float_as_uint(acc[nb][mi][12 + e]), false, false);
-                vb[e] = __uint_as_float(s13[0]); vb[4 + e] = __uint_as_float(s13[1]);
-            }
-            if (m < p.M) {
-                const int n = n0 + 32 * nb + 16 * lh;
-                epilogue_run8(p, m, n, va);
-                epilogue_run8(p, m, n + 8, vb);
-            }
-        }
-    }
-}
-
-template <int MODE>
-static int launch_gemm_v5(const GemmParams& p, hipStream_t s) {
-    const int tiles = ((p.M + V5_BM - 1) / V5_BM) * ((p.N + V5_BN - 1) / V5_BN);
-    const size_t lds = (size_t)2 * V5_STAGE * sizeof(bf16);
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_v5_kernel<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_done = true;
-    }
-    hipLaunchKernelGGL((gemm_v5_kernel<MODE>), dim3(tiles), dim3(256), lds, s, p);
-    return sidlsg_last_error();
-}
-
-template <int BM, int BN, int MODE, int VAR = 0>
+template <int BM, int BN, int MODE>
 static int launch_gemm(const GemmParams& p, hipStream_t s) {
     const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
     const size_t lds = (size_t)2 * (BM + BN) * BK * sizeof(bf16);
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<BM, BN, MODE, VAR>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<BM, BN, MODE>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done = true;
     }
     const int nk = (p.K + BK - 1) / BK;
     const int splits = p.kt_per_split ? (nk + p.kt_per_split - 1) / p.kt_per_split : 1;
-    hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, MODE, VAR>), dim3(tiles, splits), dim3(NTHREADS), lds, s, p);
+    hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, MODE>), dim3(tiles, splits), dim3(NTHREADS), lds, s, p);
     if (p.kt_per_split) {
         const size_t n4 = ((size_t)p.M * p.N + 3) / 4;
         hipLaunchKernelGGL(gemm_finish_kernel, dim3((unsigned)((n4 + 255) / 256), splits), dim3(256), 0, s, p);   // grid.y only carries the split count
@@ -1176,28 +666,16 @@ static int launch_gemm(const GemmParams& p, hipStream_t s) {
 
 template <int MODE>
 static int dispatch_gemm(const GemmParams& p, hipStream_t s) {
-    // N multiple of 160 (every SD channel count is a multiple of 320) -> exact 160-wide tiles;
-    // otherwise 128-wide; narrow outputs (conv_out, dgrad of conv_in) -> 64-wide.
-    // Small pixel counts (8x8 / 16x16 stages, small batches) would give < 256 tiles = idle CUs:
-    // fall back to 64-row and then 64x64 tiles until the grid covers the chip.
+    // N multiple of 160 (every SD channel count is a multiple of 320) -> exact 160-wide tiles and, for dense rows /
+    // Cin % 64 == 0 convs, the direct-to-LDS kernel (v3); otherwise 128-wide; narrow outputs (conv_out, dgrad of conv_in)
+    // -> 64-wide.  Small pixel counts (8x8 / 16x16 stages, small batches) would give < 256 tiles = idle CUs: split K when
+    // the contraction is long, else fall back to 64-row and then 64x64 tiles until the grid covers the chip.
     if (p.N <= 64) return launch_gemm<128, 64, MODE>(p, s);
-    {   // large grids with 160-multiple N: the deeper-pipelined 256x160 direct-to-LDS kernel (SIDLSG_GEMM_V2=0 disables it)
-        static const bool v2_on = getenv("SIDLSG_GEMM_V2") && atoi(getenv("SIDLSG_GEMM_V2")) != 0;   // off by default: v3 is faster on every measured shape
-        const long long t2 = (long long)((p.M + V2_BM - 1) / V2_BM) * ((p.N + V2_BN - 1) / V2_BN);
-        static const long long v2_min = getenv("SIDLSG_GEMM_V2_MIN_TILES") ? atoll(getenv("SIDLSG_GEMM_V2_MIN_TILES")) : 512;  // tests force 1
-        // measured: v2 wins 3-8% on long-K shapes with >= 2 full waves of tiles, loses on short K / partial waves
-        if (v2_on && MODE != 2 && p.N % 160 == 0 && t2 >= v2_min && (p.K >= 640 || v2_min == 1)) {
-            static const int v2var = getenv("SIDLSG_GEMM_V2VAR") ? atoi(getenv("SIDLSG_GEMM_V2VAR")) : 0;
-            if (v2var == 32) return launch_gemm_v2<MODE == 2 ? 0 : MODE, 32>(p, s);
-            if (v2var == 64) return launch_gemm_v2<MODE == 2 ? 0 : MODE, 64>(p, s);
-            if (v2var == 96) return launch_gemm_v2<MODE == 2 ? 0 : MODE, 96>(p, s);
-            return launch_gemm_v2<MODE == 2 ? 0 : MODE>(p, s);
-        }
-    }
     auto tiles = [&](int bm, int bn) { return (long long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn); };
     const bool n160 = p.N % 160 == 0;
-    static const int v3_on = getenv("SIDLSG_GEMM_V3") ? atoi(getenv("SIDLSG_GEMM_V3")) : 1;
-    {   // few output tiles but a long contraction (8x8 / 16x16 stages, small batches): split K over blockIdx.y with the big tile
+    static const bool v3_on = !(getenv("SIDLSG_GEMM_V3") && atoi(getenv("SIDLSG_GEMM_V3")) == 0);   // A/B switch
+    const bool v3 = n160 && v3_on && MODE != 2;
+    {
         const long long t = tiles(128, n160 ? 160 : 128);
         const int nk = (p.K + BK - 1) / BK;
         if (t < 384 && nk >= 32 && (p.N & 3) == 0 && g_ws && (long long)p.M * p.N * 8 <= g_ws_bytes) {
@@ -1210,23 +688,13 @@ static int dispatch_gemm(const GemmParams& p, hipStream_t s) {
                 GemmParams q = p;
                 q.kt_per_split = (nk + splits - 1) / splits;
                 q.ws = g_ws;
-                if (n160 && v3_on && MODE != 2) return launch_gemm_v3<MODE == 2 ? 0 : MODE>(q, s);
+                if (v3) return launch_gemm_v3<MODE == 2 ? 0 : MODE>(q, s);
                 return n160 ? launch_gemm<128, 160, MODE>(q, s) : launch_gemm<128, 128, MODE>(q, s);
             }
         }
     }
-    static const int v5_min = getenv("SIDLSG_GEMM_V5_MIN_TILES") ? atoi(getenv("SIDLSG_GEMM_V5_MIN_TILES")) : 0;   // 0 = off
-    if (v5_min > 0 && n160 && MODE != 2 && !(p.N & 7) && tiles(V5_BM, V5_BN) >= v5_min) return launch_gemm_v5<MODE == 2 ? 0 : MODE>(p, s);
     if (tiles(128, n160 ? 160 : 128) >= 384) {
-        if (n160 && v3_on && MODE != 2) return launch_gemm_v3<MODE == 2 ? 0 : MODE>(p, s);
-        static const int var = getenv("SIDLSG_GEMM_VAR") ? atoi(getenv("SIDLSG_GEMM_VAR")) : 0;   // scheduling experiments (A/B)
-        if (n160 && var == 2) return launch_gemm<128, 160, MODE, 2>(p, s);
-        if (n160 && var == 128) return launch_gemm<128, 160, MODE, 128>(p, s);
-        if (n160 && var == 16) return launch_gemm<128, 160, MODE, 16>(p, s);   // ablations: 16 no LDS commit, 32 no MFMA, 64 no global loads
-        if (n160 && var == 32) return launch_gemm<128, 160, MODE, 32>(p, s);
-        if (n160 && var == 64) return launch_gemm<128, 160, MODE, 64>(p, s);
-        if (n160 && var == 80) return launch_gemm<128, 160, MODE, 80>(p, s);
-        if (n160 && var == 96) return launch_gemm<128, 160, MODE, 96>(p, s);
+        if (v3) return launch_gemm_v3<MODE == 2 ? 0 : MODE>(p, s);
         return n160 ? launch_gemm<128, 160, MODE>(p, s) : launch_gemm<128, 128, MODE>(p, s);
     }
     if (tiles(64, n160 ? 160 : 128) >= 384) return n160 ? launch_gemm<64, 160, MODE>(p, s) : launch_gemm<64, 128, MODE>(p, s);
