@@ -41,6 +41,10 @@ class _Lib:
             if not os.path.isfile(LIB_PATH):
                 raise RuntimeError(f'{LIB_PATH} not built: run `python -m sid_lsg_amd.csrc.build` '
                                    '(or __graft_entry__.build()).  There is no non-HIP fallback.')
+            # torch first: it brings its own libamdhip64; loading our library before it would pull a second HIP runtime
+            # (/opt/rocm) into the process, and kernels registered with one runtime cannot touch the other's memory
+            # (seen as hipErrorNoDevice from the first launch when build() and smoke() ran in one process)
+            import torch  # noqa: F401
             dll = ctypes.CDLL(LIB_PATH)
             for name, args in self.protos.items():
                 fn = getattr(dll, name)

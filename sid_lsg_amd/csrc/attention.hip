@@ -481,20 +481,17 @@ static int launch_attn(const AttnParams& p, int mode, hipStream_t s) {
 static int dispatch_attn(const AttnParams& p, int mode, hipStream_t s) {
     if (p.D % 8 || p.D <= 0 || p.D > 160) return SIDLSG_EINVAL;
     const int dp = (p.D + 15) / 16 * 16;
-    // long sequences + small heads: 64 queries (32 keys) per wave; otherwise 32 (16) to bound registers / keep the grid full
-    // Measured on MI355X (N=4096, d=40, B=16): 64 queries/wave at 1 wave/SIMD is ~3x SLOWER than 32 queries/wave at
-    // 2 waves/SIMD -- the softmax VALU work only overlaps MFMA across waves.  Kept behind an env switch for A/B runs.
-    static const bool allow_big = getenv("SIDLSG_ATTN_BIG") && atoi(getenv("SIDLSG_ATTN_BIG")) != 0;
-    const bool big = allow_big && (mode == 2 ? p.Nk : p.Nq) >= 1024;
-    // dK/dV with 32 keys per wave: halves the LDS fragment traffic per MFMA.  Measured (N=4096, B=16): d=40
-    // 3075 -> 2661 us for the whole backward; d=64 is neutral/slightly slower, so only DP=48 uses it by default.
+    // 32 queries per wave (forward / dQ) and 16 keys per wave (dK/dV) keep 2-3 blocks per CU resident; 64 queries per
+    // wave at one wave per SIMD measured up to 3x slower at d=40 (the softmax VALU work only overlaps MFMA across waves).
+    // dK/dV with 32 keys per wave halves the LDS fragment traffic per MFMA: measured (N=4096, B=16) 3075 -> 2661 us for
+    // the whole d=40 backward, neutral at d=64 -> only DP=48 uses it (SIDLSG_ATTN_KT2=0 switches it off for A/B runs).
     static const bool allow_kt2 = !(getenv("SIDLSG_ATTN_KT2") && atoi(getenv("SIDLSG_ATTN_KT2")) == 0);
     const bool kt2 = allow_kt2 && mode == 2 && p.Nk >= 1024;
     switch (dp) {
         case 16: return launch_attn<16, 2, 1>(p, mode, s);
         case 32: return launch_attn<32, 2, 1>(p, mode, s);
-        case 48: return big ? launch_attn<48, 4, 2>(p, mode, s) : (kt2 ? launch_attn<48, 2, 2>(p, mode, s) : launch_attn<48, 2, 1>(p, mode, s));
-        case 64: return big ? launch_attn<64, 4, 2>(p, mode, s) : launch_attn<64, 2, 1>(p, mode, s);
+        case 48: return kt2 ? launch_attn<48, 2, 2>(p, mode, s) : launch_attn<48, 2, 1>(p, mode, s);
+        case 64: return launch_attn<64, 2, 1>(p, mode, s);
         case 80: return launch_attn<80, 2, 1>(p, mode, s);
         case 96: return launch_attn<96, 2, 1>(p, mode, s);
         case 128: return launch_attn<128, 2, 1>(p, mode, s);
