@@ -52,7 +52,11 @@ TINY = UNetConfig(block_out_channels=(32, 64, 128, 128), num_heads=(2, 2, 4, 4),
 TINY40 = UNetConfig(block_out_channels=(80, 160, 320, 320), num_heads=(2, 2, 2, 2), cross_attention_dim=96,
                     norm_num_groups=8, text_len=77)
 
-CONFIGS = {'sd15': SD15, 'sd21-base': SD21_BASE, 'tiny': TINY, 'tiny40': TINY40}
+# SD2.1-base topology at tiny width: Linear proj_in/proj_out, head dim 64 everywhere (1/2/4/4 heads), 1024-style wide context
+TINY21 = UNetConfig(block_out_channels=(64, 128, 256, 256), num_heads=(1, 2, 4, 4), cross_attention_dim=128,
+                    norm_num_groups=8, text_len=77, use_linear_projection=True)
+
+CONFIGS = {'sd15': SD15, 'sd21-base': SD21_BASE, 'tiny': TINY, 'tiny40': TINY40, 'tiny21': TINY21}
 
 
 def timestep_embedding(t: torch.Tensor, dim: int) -> torch.Tensor:

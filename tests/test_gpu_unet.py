@@ -45,7 +45,7 @@ def make_pair(cfg_name, dev, seed=1234):
     return ref, hip
 
 
-@pytest.mark.parametrize('cfg_name,lat', [('tiny', 16), ('tiny40', 8)])
+@pytest.mark.parametrize('cfg_name,lat', [('tiny', 16), ('tiny40', 8), ('tiny21', 16)])
 def test_unet_forward_backward(dev, cfg_name, lat):
     from oracle.unet_ref import CONFIGS as RC
     ref, hip = make_pair(cfg_name, dev)
