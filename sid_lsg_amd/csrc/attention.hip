@@ -27,7 +27,8 @@ struct AttnParams {
     const bf16 *Q, *K, *V, *dO;
     bf16 *O, *dQ, *dK, *dV;
     float* LSE;          // [B][H][Nq], log2 domain: m + log2(l)
-    const float* delta;  // [B][H][Nq] = rowsum(dO * O)
+    const float* delta;  // [B][H][Nq] = rowsum(dO * O): written by the dQ kernel (delta_out), read by the dK/dV kernel
+    float* delta_out;
     int B, H, Nq, Nk, D;
     int ldq, ldk, ldv, ldo;        // token strides (elements)
     long long bsq, bsk, bsv, bso;  // batch strides (elements)
@@ -180,7 +181,20 @@ __global__ __launch_bounds__(256) void attn_q_kernel(AttnParams p) {
             const bf16* dOb = p.dO + b * p.bso + (long long)h * p.D;
             frag_from_global<DP>(fdo[qt], dOb + (long long)(ok ? q : 0) * p.ldo, lg, p.D, ok);
             lse[qt] = ok ? p.LSE[((long long)b * p.H + h) * p.Nq + q] : 0.f;
-            dl[qt] = ok ? p.delta[((long long)b * p.H + h) * p.Nq + q] : 0.f;
+            // delta = rowsum(dO * O), computed here from the fragments (lane holds 8 * N32 of the row's d values; the 4
+            // lane groups of a row are summed with two shuffles) and published for the dK/dV kernel: no separate pass
+            Frag<DP> fo;
+            const bf16* Ob = p.O + b * p.bso + (long long)h * p.D;
+            frag_from_global<DP>(fo, Ob + (long long)(ok ? q : 0) * p.ldo, lg, p.D, ok);
+            float dsum = 0.f;
+#pragma unroll
+            for (int s2 = 0; s2 < Frag<DP>::N32; s2++)
+#pragma unroll
+                for (int e = 0; e < 8; e++) dsum += bf2f(fdo[qt].w[s2][e]) * bf2f(fo.w[s2][e]);
+            dsum += __shfl_xor(dsum, 16, 64);
+            dsum += __shfl_xor(dsum, 32, 64);
+            dl[qt] = dsum;
+            if (ok && lg == 0) p.delta_out[((long long)b * p.H + h) * p.Nq + q] = dsum;
         }
     }
     f32x4 o[DT][QT];
@@ -451,23 +465,6 @@ __global__ __launch_bounds__(256) void attn_dkdv_kernel(AttnParams p) {
     }
 }
 
-// delta[b][h][q] = sum_d dO[q][h*D+d] * O[q][h*D+d]
-__global__ void attn_delta_kernel(const bf16* __restrict__ dO, const bf16* __restrict__ O, float* __restrict__ delta, int B,
-                                  int H, int Nq, int D, int ld, long long bs) {
-    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (long long)B * H * Nq) return;
-    const int q = (int)(idx % Nq); const int h = (int)((idx / Nq) % H); const int b = (int)(idx / ((long long)Nq * H));
-    const bf16* a = dO + b * bs + (long long)q * ld + (long long)h * D;
-    const bf16* c = O + b * bs + (long long)q * ld + (long long)h * D;
-    float t = 0.f;
-    for (int d = 0; d < D; d += 8) {
-        const bf16x8 x = ld8(a + d), y = ld8(c + d);
-#pragma unroll
-        for (int e = 0; e < 8; e++) t += bf2f(x[e]) * bf2f(y[e]);
-    }
-    delta[idx] = t;
-}
-
 template <int DP, int QT, int KT>
 static int launch_attn(const AttnParams& p, int mode, hipStream_t s) {
     const int qb = 4 * QT * 16, kb = 4 * KT * 16;
@@ -528,9 +525,7 @@ int sidlsg_attn_bwd(const void* Q, const void* K, const void* V, const void* O, 
     p.B = B; p.H = H; p.Nq = Nq; p.Nk = Nk; p.D = D; p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo;
     p.bsq = bsq; p.bsk = bsk; p.bsv = bsv; p.bso = bso;
     p.scale = 1.0f / sqrtf((float)D); p.scale2 = p.scale * 1.4426950408889634f;
-    const long long n = (long long)B * H * Nq;
-    hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const bf16*)dO, (const bf16*)O,
-                       delta, B, H, Nq, D, ldo, bso);
+    p.O = const_cast<bf16*>((const bf16*)O); p.delta_out = delta;
     if (int e = dispatch_attn(p, 1, s)) return e;
     return dispatch_attn(p, 2, s);
 }
