@@ -78,8 +78,8 @@ class KernelTimer:
 
 
 def conv_flops(*a):
-    # sidlsg_conv3x3_bf16(X, ldx, W, Y, ldc, bias, res, ldres, rowvec, B, H, Wd, Cin, Cout, stride, ups, alpha, flags, stream)
-    B, H, Wd, Cin, Cout, stride = a[9], a[10], a[11], a[12], a[13], a[14]
+    # sidlsg_conv3x3_bf16(X, ldx, W, Y, ldc, bias, res, ldres, rowvec, ld_rowvec, B, H, Wd, Cin, Cout, stride, ups, alpha, flags, stream)
+    B, H, Wd, Cin, Cout, stride = a[10], a[11], a[12], a[13], a[14], a[15]
     Ho, Wo = (H - 1) // stride + 1, (Wd - 1) // stride + 1
     return 2.0 * B * Ho * Wo * Cout * 9 * Cin
 

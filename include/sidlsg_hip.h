@@ -29,20 +29,22 @@ extern "C" {
 /* ---- contractions (MFMA bf16 -> fp32) ------------------------------------------------------
  * torch.nn.functional.linear / conv2d(k=1) inside diffusers Attention / FeedForward /
  * Transformer2DModel / ResnetBlock2D.time_emb_proj / conv_shortcut (call site sid_sd_util.py:184).
- * C[M][ldc] = act(alpha * A[M][K] W[N][K]^T + bias[N] + rowvec[m/rows_per_batch][N] + res[M][ldres])
- * K, lda multiples of 8.  bias/res/rowvec may be NULL. */
+ * C[M][ldc] = act(alpha * A[M][K] W[N][K]^T + bias[N] + rowvec[m/rows_per_batch][ld_rowvec] + res[M][ldres])
+ * K, lda multiples of 8.  bias/res/rowvec may be NULL; ld_rowvec <= 0 means N (a slice of a wider matrix otherwise). */
 int sidlsg_gemm_bf16(const void* A, int lda, const void* W, void* C, int ldc, const float* bias, const void* res, int ldres,
-                     const float* rowvec, int rows_per_batch, int M, int N, int K, float alpha, int flags, void* stream);
+                     const float* rowvec, int ld_rowvec, int rows_per_batch, int M, int N, int K, float alpha, int flags,
+                     void* stream);
 
 /* torch conv2d(k=3, pad=1, stride 1|2) of ResnetBlock2D.conv1/conv2, Downsample2D, Upsample2D
  * (ups=1 fuses the nearest x2 interpolate), conv_in/conv_out.  X: [B][Hs][Ws][ldx] with the virtual
  * (post-upsample) size H x Wd; W: [Cout][3][3][Cin]; Y: [B][Ho][Wo][ldc].  Same epilogue as the GEMM;
- * rowvec is the per-sample time-embedding projection [B][Cout].  Cin, ldx multiples of 8.
+ * rowvec is the per-sample time-embedding projection [B][ld_rowvec] (all ResBlocks' projections come out of ONE GEMM;
+ * each conv reads its column slice).  Cin, ldx multiples of 8.
  * The backward-data pass is the same entry point fed with dY and the transposed/flipped weights
  * made by sidlsg_transpose_w. */
 int sidlsg_conv3x3_bf16(const void* X, int ldx, const void* W, void* Y, int ldc, const float* bias, const void* res, int ldres,
-                        const float* rowvec, int B, int H, int Wd, int Cin, int Cout, int stride, int ups, float alpha,
-                        int flags, void* stream);
+                        const float* rowvec, int ld_rowvec, int B, int H, int Wd, int Cin, int Cout, int stride, int ups,
+                        float alpha, int flags, void* stream);
 
 /* Optional fp32 scratch (device memory owned by the caller): per-split partial-sum slabs for split-K GEMMs/convs with few
  * output tiles and long K (8x8 / 16x16 stages) and for the pixel-split weight gradients (without it they fall back to

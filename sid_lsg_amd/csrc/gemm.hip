@@ -30,7 +30,8 @@ struct GemmParams {
     void* C;              // [M][ldc] bf16 (or fp32 when OUT_F32)
     const float* bias;    // [N] or null
     const bf16* res;      // [M][ldres] or null
-    const float* rowvec;  // [M/rows_per_batch][N] or null (time-embedding broadcast)
+    const float* rowvec;  // [M/rows_per_batch][ldrv] or null (time-embedding broadcast)
+    int ldrv;
     int M, N, K;
     int lda, ldc, ldres;
     int rows_per_batch;
@@ -65,7 +66,7 @@ DEVFN void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[NT][MT], int mbase, i
     for (int mi = 0; mi < MT; mi++) {
         const int m = m0 + wm0 + mi * 16 + li;
         if (m >= p.M) continue;
-        const float* rv = p.rowvec ? p.rowvec + (size_t)(m / p.rows_per_batch) * p.N : nullptr;
+        const float* rv = p.rowvec ? p.rowvec + (size_t)(m / p.rows_per_batch) * p.ldrv : nullptr;
 #pragma unroll
         for (int pr = 0; pr < (NT + 1) / 2; pr++) {
             const bool paired = (2 * pr + 1) < NT;
@@ -364,7 +365,7 @@ __global__ void gemm_finish_kernel(GemmParams p) {
     f32x4 v = *reinterpret_cast<const f32x4*>(p.ws + i);
     const int nsp = (int)gridDim.y;                       // number of K splits (slabs)
     for (int sidx = 1; sidx < nsp; sidx++) v += *reinterpret_cast<const f32x4*>(p.ws + (size_t)sidx * p.M * p.N + i);
-    const float* rv = p.rowvec ? p.rowvec + (size_t)(m / p.rows_per_batch) * p.N : nullptr;
+    const float* rv = p.rowvec ? p.rowvec + (size_t)(m / p.rows_per_batch) * p.ldrv : nullptr;
 #pragma unroll
     for (int e = 0; e < 4; e++) {
         float x = v[e] * p.alpha;
@@ -1181,10 +1182,11 @@ int sidlsg_set_workspace(void* ptr, long long bytes) {
 
 // Dense GEMM: C[M,N] = act(alpha * A[M,K] W[N,K]^T + bias[N] + rowvec[m/rpb,N] + res[M,N])
 int sidlsg_gemm_bf16(const void* A, int lda, const void* W, void* C, int ldc, const float* bias, const void* res,
-                     int ldres, const float* rowvec, int rows_per_batch, int M, int N, int K, float alpha, int flags,
-                     void* stream) {
+                     int ldres, const float* rowvec, int ld_rowvec, int rows_per_batch, int M, int N, int K, float alpha,
+                     int flags, void* stream) {
     GemmParams p{};
     p.A = (const bf16*)A; p.W = (const bf16*)W; p.C = C; p.bias = bias; p.res = (const bf16*)res; p.rowvec = rowvec;
+    p.ldrv = ld_rowvec > 0 ? ld_rowvec : N;
     p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldc = ldc; p.ldres = ldres; p.rows_per_batch = rows_per_batch;
     p.alpha = alpha; p.flags = flags;
     if (int e = check_common(p)) return e;
@@ -1198,13 +1200,14 @@ int sidlsg_gemm_bf16(const void* A, int lda, const void* W, void* C, int ldc, co
 // W: [Cout][3][3][Cin], Y: [B][Ho][Wo][ldc].  `ups`=1 reads X through a nearest x2 upsample
 // (virtual input H x Wd = 2Hs x 2Ws).  stride in {1,2}.
 int sidlsg_conv3x3_bf16(const void* X, int ldx, const void* W, void* Y, int ldc, const float* bias, const void* res,
-                        int ldres, const float* rowvec, int B, int H, int Wd, int Cin, int Cout, int stride, int ups,
-                        float alpha, int flags, void* stream) {
+                        int ldres, const float* rowvec, int ld_rowvec, int B, int H, int Wd, int Cin, int Cout, int stride,
+                        int ups, float alpha, int flags, void* stream) {
     if (stride != 1 && stride != 2) return SIDLSG_EINVAL;
     if (Cin & 7) return SIDLSG_EINVAL;
     if (ups && ((H | Wd) & 1)) return SIDLSG_EINVAL;
     GemmParams p{};
     p.A = (const bf16*)X; p.W = (const bf16*)W; p.C = Y; p.bias = bias; p.res = (const bf16*)res; p.rowvec = rowvec;
+    p.ldrv = ld_rowvec > 0 ? ld_rowvec : Cout;
     p.H = H; p.Wd = Wd; p.Cin = Cin; p.stride = stride; p.ups = ups;
     p.Ho = (H + 2 - 3) / stride + 1; p.Wo = (Wd + 2 - 3) / stride + 1;
     p.M = B * p.Ho * p.Wo; p.N = Cout; p.K = 9 * Cin; p.lda = ldx; p.ldc = ldc; p.ldres = ldres;

@@ -65,7 +65,8 @@ def gemm(a, w16, out=None, bias=None, res=None, rowvec=None, rows_per_batch=1, a
     if out is None:
         out = torch.empty((M, N), device=a.device, dtype=F32 if out_f32 else BF16)
     lib.sidlsg_gemm_bf16(_p(a), lda, _p(w16), _p(out), out.stride(0), _p(bias), _p(res), res.stride(0) if res is not None else 0,
-                         _p(rowvec), rows_per_batch, M, N, K, float(alpha), 1 if out_f32 else 0, _s())
+                         _p(rowvec), rowvec.stride(0) if rowvec is not None else 0, rows_per_batch, M, N, K, float(alpha),
+                         1 if out_f32 else 0, _s())
     return out
 
 
@@ -78,7 +79,8 @@ def conv3x3(x, w16, bias=None, res=None, rowvec=None, stride=1, ups=0, out_f32=F
     ensure_workspace(x.device)
     out = torch.empty((B, Ho, Wo, Cout), device=x.device, dtype=F32 if out_f32 else BF16)
     lib.sidlsg_conv3x3_bf16(_p(x), Cin, _p(w16), _p(out), Cout, _p(bias), _p(res), Cout if res is not None else 0, _p(rowvec),
-                            B, H, W, Cin, Cout, stride, ups, 1.0, 1 if out_f32 else 0, _s())
+                            rowvec.stride(0) if rowvec is not None else 0, B, H, W, Cin, Cout, stride, ups, 1.0,
+                            1 if out_f32 else 0, _s())
     return out
 
 
@@ -542,6 +544,25 @@ def transpose_w(src_f32, n, k, taps=1):
     dst = torch.empty((k, taps * n), device=src_f32.device, dtype=BF16)
     lib.sidlsg_transpose_w(_p(src_f32), _p(dst), n, k, taps, _s())
     return dst
+
+
+class _SplitColumns(torch.autograd.Function):
+    """x [N, sum C] -> views x[:, off_i:off_i+C_i] (no copies); backward = one torch.cat of the column gradients."""
+
+    @staticmethod
+    def forward(ctx, x, sizes):
+        ctx.sizes, ctx.meta = sizes, (x.shape[0], x.dtype, x.device)
+        return tuple(x.split(sizes, dim=1))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        n, dtype, dev = ctx.meta
+        gs = [g if g is not None else torch.zeros((n, c), device=dev, dtype=dtype) for g, c in zip(grads, ctx.sizes)]
+        return torch.cat([g.to(dtype) for g in gs], dim=1), None
+
+
+def split_columns(x, sizes):
+    return _SplitColumns.apply(x, list(sizes))
 
 
 class _GradReady(torch.autograd.Function):

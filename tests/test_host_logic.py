@@ -33,8 +33,8 @@ def test_argument_validation_returns_einval_without_gpu():
     from sid_lsg_amd._lib import lib
     lib.load()
     # K not a multiple of 8, null pointers, bad stride: rejected before any launch
-    assert lib.sidlsg_gemm_bf16.raw(None, 8, None, None, 8, None, None, 0, None, 1, 4, 4, 8, 1.0, 0, None) == -22
-    assert lib.sidlsg_conv3x3_bf16.raw(None, 8, None, None, 8, None, None, 0, None, 1, 4, 4, 8, 8, 3, 0, 1.0, 0, None) == -22
+    assert lib.sidlsg_gemm_bf16.raw(None, 8, None, None, 8, None, None, 0, None, 0, 1, 4, 4, 8, 1.0, 0, None) == -22
+    assert lib.sidlsg_conv3x3_bf16.raw(None, 8, None, None, 8, None, None, 0, None, 0, 1, 4, 4, 8, 8, 3, 0, 1.0, 0, None) == -22
     assert lib.sidlsg_adam_ema.raw(None, None, None, None, None, None, None, 0, 1, None) == -22
 
 

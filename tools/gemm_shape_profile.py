@@ -22,10 +22,10 @@ def main():
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(); orig(*a); e1.record()
         if entry == 'sidlsg_gemm_bf16':
-            key = (a[10], a[11], a[12])                     # M, N, K
-            fl = 2.0 * a[10] * a[11] * a[12]
+            key = (a[11], a[12], a[13])                     # M, N, K
+            fl = 2.0 * a[11] * a[12] * a[13]
         else:
-            key = tuple(a[9:16])                             # B, H, W, Cin, Cout, stride, ups
+            key = tuple(a[10:17])                            # B, H, W, Cin, Cout, stride, ups
             fl = bench.conv_flops(*a)
         events.append((key, fl, e0, e1))
     lib.__dict__[entry] = timed
