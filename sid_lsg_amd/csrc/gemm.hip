@@ -915,13 +915,20 @@ __global__ __launch_bounds__(NTHREADS) void wgrad_bf16_kernel(WgradParams p) {
 // Blocks are numbered split-major and remapped so that one XCD works on consecutive (split, tile) pairs: the tiles of a
 // split share the same dY / X rows (the 9 taps re-read X shifted), which then stay in that XCD's L2.
 // Requires N % 8 == 0, K % 8 == 0 (conv: Cin % 8 == 0), ldy % 8 == 0, lda % 8 == 0, 16-byte aligned bases.
-constexpr int WG2_STAGE = 2 * WG_MB * WG_T;
-template <int MODE>
-__global__ __launch_bounds__(NTHREADS, 2) void wgrad_v2_kernel(WgradParams p) {
+// TN = n (dY column) extent of the tile: 160 when N % 160 == 0 (every SD channel count: 320 = 2 tiles instead of 3 of 128),
+// else 128.  The k (X column) extent stays 128.
+template <int TN> DEVFN int wg_yswz(int row) { return TN == 128 ? wg_swz(row) : ((row >> 3) & 1); }
+
+template <int MODE, int TN>
+DEVFN void wgrad_v2_body(const WgradParams& p) {
+    constexpr int NI = TN / 32;             // 16-column dY fragments per wave (wave = TN/2 x 64 of the tile)
+    constexpr int YI = TN / 32;             // dY DMA instructions per wave and stage (64 rows x TN/8 chunks / 256 lanes)
+    constexpr int YC = TN / 8;              // 16-byte chunks per dY row
+    constexpr int STAGE = WG_MB * (TN + WG_T);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16* ring = reinterpret_cast<bf16*>(smem);
     const int tiles_k = (p.K + WG_T - 1) / WG_T;
-    const int tiles = ((p.N + WG_T - 1) / WG_T) * tiles_k;
+    const int tiles = ((p.N + TN - 1) / TN) * tiles_k;
     int bid = blockIdx.x;
     {
         const int nblk = tiles * p.nsplits;
@@ -929,32 +936,39 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad_v2_kernel(WgradParams p) {
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
     const int split = bid / tiles, tile = bid - split * tiles;
-    const int n0 = (tile / tiles_k) * WG_T, k0 = (tile % tiles_k) * WG_T;
+    const int n0 = (tile / tiles_k) * TN, k0 = (tile % tiles_k) * WG_T;
     const int mbeg = split * p.m_per_split;
     const int mend = min(p.M, mbeg + p.m_per_split);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, lg = lane >> 4;
-    const int wn0 = (wave >> 1) * 64, wk0 = (wave & 1) * 64;
+    const int wn0 = (wave >> 1) * (TN / 2), wk0 = (wave & 1) * 64;
     const int q16 = tid & 15, r0 = tid >> 4;            // LDS chunk position and first row of this lane
     const int c16 = (((q16 >> 1) ^ wg_swz(r0)) << 1) | (q16 & 1);   // source chunk (wg_swz(r0 + 16 i) == wg_swz(r0))
     const int kA = k0 + c16 * 8;
     const bool kok = kA < p.K;
     int cA = kA, dh = 0, dw = 0;
     if (MODE == 1) { const int tap = kA / p.Cin; cA = kA - tap * p.Cin; dh = tap / 3; dw = tap - dh * 3; }
-    const int nY = n0 + c16 * 8;
-    const bool nok = nY < p.N;
     const int Hs = p.ups ? (p.H >> 1) : p.H, Ws = p.ups ? (p.Wd >> 1) : p.Wd;
     const int hw = (MODE == 1) ? p.Ho * p.Wo : 1;
     // buffer_load ... lds with one 32-bit byte offset per row; rows past the split / columns past N,K / the conv halo
     // carry an out-of-range offset (the buffer unit writes zeros).  dY and dense X advance by a wave-uniform soffset.
     const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(p.dY), 0, (int)p.y_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(p.A), 0, (int)p.a_bytes, 0x00020000);
-    unsigned yoff[4], xoff[4];
+    // dY: DMA instruction j of wave w fills LDS chunks [(w*YI + j)*64, +64) of the [64][YC] chunk grid; the lane's
+    // position (row, cpos) holds the source chunk whose swizzled position it is
+    unsigned yoff[YI], xoff[4];
+#pragma unroll
+    for (int j = 0; j < YI; j++) {
+        const int idx = (wave * YI + j) * 64 + lane;
+        const int row = idx / YC, cpos = idx - row * YC;
+        const int chunk = (((cpos >> 1) ^ wg_yswz<TN>(row)) << 1) | (cpos & 1);
+        const int nY = n0 + chunk * 8;
+        yoff[j] = nY < p.N ? ((unsigned)(mbeg + row) * (unsigned)p.ldy + (unsigned)nY) * 2u : OOB;
+    }
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         const unsigned m = (unsigned)(mbeg + r0 + 16 * i);
-        yoff[i] = nok ? (m * (unsigned)p.ldy + (unsigned)nY) * 2u : OOB;
         xoff[i] = (MODE == 0 && kok) ? (m * (unsigned)p.lda + (unsigned)kA) * 2u : OOB;
     }
 
@@ -971,15 +985,19 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad_v2_kernel(WgradParams p) {
             pwo[i] = rem - pho[i] * p.Wo;
         }
     }
-    auto issue = [&](int mb, int buf) {      // called with mb = mbeg, mbeg + WG_MB, ... in order; 8 DMA instructions per wave
-        bf16* ys = ring + buf * WG2_STAGE;
-        bf16* xs = ys + WG_MB * WG_T;
+    auto issue = [&](int mb, int buf) {      // called with mb = mbeg, mbeg + WG_MB, ... in order; YI + 4 DMA instructions per wave
+        bf16* ys = ring + buf * STAGE;
+        bf16* xs = ys + WG_MB * TN;
         const int ysoff = (mb - mbeg) * p.ldy * 2, xsoff = (mb - mbeg) * p.lda * 2;
         const bool tail = mb + WG_MB > mend;          // only the last stage of a split has rows past mend
 #pragma unroll
+        for (int j = 0; j < YI; j++) {
+            const bool mok = !tail || (mb + ((wave * YI + j) * 64 + lane) / YC < mend);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ry, (lptr_t)(ys + (wave * YI + j) * 512), 16, mok ? yoff[j] : OOB, ysoff, 0, 0);
+        }
+#pragma unroll
         for (int i = 0; i < 4; i++) {
             const bool mok = !tail || (mb + r0 + 16 * i < mend);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(ry, (lptr_t)(ys + (4 * wave + 16 * i) * WG_T), 16, mok ? yoff[i] : OOB, ysoff, 0, 0);
             if (MODE == 0) {
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lptr_t)(xs + (4 * wave + 16 * i) * WG_T), 16, mok ? xoff[i] : OOB, xsoff, 0, 0);
             } else {
@@ -998,55 +1016,56 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad_v2_kernel(WgradParams p) {
         }
     };
 
-    f32x4 acc[4][4];   // [n tile][k tile]
+    f32x4 acc[NI][4];   // [n tile][k tile]
 #pragma unroll
-    for (int i = 0; i < 4; i++)
+    for (int i = 0; i < NI; i++)
 #pragma unroll
         for (int j = 0; j < 4; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const bool do_bias = p.dB != nullptr && k0 == 0 && wk0 == 0;
-    f32x4 accb[4];
+    f32x4 accb[NI];
 #pragma unroll
-    for (int i = 0; i < 4; i++) accb[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < NI; i++) accb[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const bf16x8 ones = {f2bf(1.f), f2bf(1.f), f2bf(1.f), f2bf(1.f), f2bf(1.f), f2bf(1.f), f2bf(1.f), f2bf(1.f)};
 
     typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
     // per-lane LDS offsets of the two transpose reads of a fragment (rows 8*lg + (li>>2) and +4), excluding the
     // 16-column granule g of the fragment, which enters as (g ^ swz) << 4
     const int rA = 8 * lg + (li >> 2), rB = rA + 4;
-    const int sA = wg_swz(rA), sB = wg_swz(rB);      // kk*32 does not change the swizzle bits
-    const int oA = rA * WG_T + (li & 3) * 4, oB = rB * WG_T + (li & 3) * 4;
-    auto tr_frag = [&](const bf16* tilebase, int kk, int colbase) -> bf16x8 {
+    // kk*32 does not change the swizzle bits.  X tile: 256-byte rows, 3-bit granule XOR; dY tile: TN*2-byte rows (320 B
+    // rows alias the banks of rows 8 apart only -> 1-bit XOR with (row>>3)&1 for TN = 160)
+    const int sxA = wg_swz(rA), sxB = wg_swz(rB), syA = wg_yswz<TN>(rA), syB = wg_yswz<TN>(rB);
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    auto tr_frag = [&](const bf16* tilebase, int pitch, int sA, int sB, int kk, int colbase) -> bf16x8 {
         const int g = colbase >> 4;
-        const bf16* base = tilebase + kk * 32 * WG_T;
-        s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base + oA + ((g ^ sA) << 4)));
-        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base + oB + ((g ^ sB) << 4)));
-        typedef short s16x8 __attribute__((ext_vector_type(8)));
+        const bf16* base = tilebase + kk * 32 * pitch + (li & 3) * 4;
+        s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base + rA * pitch + ((g ^ sA) << 4)));
+        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base + rB * pitch + ((g ^ sB) << 4)));
         s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
         return __builtin_bit_cast(bf16x8, v);
     };
-    auto read_frags = [&](int buf, int kk, bf16x8 (&fy)[4], bf16x8 (&fx)[4]) {
-        const bf16* ys = ring + buf * WG2_STAGE;
-        const bf16* xs = ys + WG_MB * WG_T;
+    auto read_frags = [&](int buf, int kk, bf16x8 (&fy)[NI], bf16x8 (&fx)[4]) {
+        const bf16* ys = ring + buf * STAGE;
+        const bf16* xs = ys + WG_MB * TN;
 #pragma unroll
-        for (int i = 0; i < 4; i++) fy[i] = tr_frag(ys, kk, wn0 + i * 16);
+        for (int i = 0; i < NI; i++) fy[i] = tr_frag(ys, TN, syA, syB, kk, wn0 + i * 16);
 #pragma unroll
-        for (int j = 0; j < 4; j++) fx[j] = tr_frag(xs, kk, wk0 + j * 16);
+        for (int j = 0; j < 4; j++) fx[j] = tr_frag(xs, WG_T, sxA, sxB, kk, wk0 + j * 16);
     };
-    auto mfma_block = [&](const bf16x8 (&fy)[4], const bf16x8 (&fx)[4]) {
+    auto mfma_block = [&](const bf16x8 (&fy)[NI], const bf16x8 (&fx)[4]) {
 #pragma unroll
-        for (int i = 0; i < 4; i++)
+        for (int i = 0; i < NI; i++)
 #pragma unroll
             for (int j = 0; j < 4; j++)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fy[i], fx[j], acc[i][j], 0, 0, 0);
         if (do_bias) {
 #pragma unroll
-            for (int i = 0; i < 4; i++) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fy[i], ones, accb[i], 0, 0, 0);
+            for (int i = 0; i < NI; i++) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fy[i], ones, accb[i], 0, 0, 0);
         }
     };
 
     const int nsteps = (mend - mbeg + WG_MB - 1) / WG_MB;
     if (nsteps <= 0) return;
-    bf16x8 fy0[4], fx0[4], fy1[4], fx1[4];
+    bf16x8 fy0[NI], fx0[4], fy1[NI], fx1[4];
     issue(mbeg, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -1068,7 +1087,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad_v2_kernel(WgradParams p) {
     }
     if (do_bias && li == 0) {
 #pragma unroll
-        for (int i = 0; i < 4; i++)
+        for (int i = 0; i < NI; i++)
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 const int n = n0 + wn0 + 16 * i + lg * 4 + r;
@@ -1076,7 +1095,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad_v2_kernel(WgradParams p) {
             }
     }
 #pragma unroll
-    for (int i = 0; i < 4; i++)
+    for (int i = 0; i < NI; i++)
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             const int k = k0 + wk0 + 16 * j + li;
@@ -1092,6 +1111,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad_v2_kernel(WgradParams p) {
             }
         }
 }
+
+// (two plain kernels over one body: a kernel template with the second non-type parameter did not get a host stub from
+// hipcc 7.2 -- undefined symbol at load time, no diagnostic)
+template <int MODE>
+__global__ __launch_bounds__(NTHREADS, 2) void wgrad_v2_kernel(WgradParams p) { wgrad_v2_body<MODE, 128>(p); }
+template <int MODE>
+__global__ __launch_bounds__(NTHREADS, 2) void wgrad_v2w_kernel(WgradParams p) { wgrad_v2_body<MODE, 160>(p); }
 
 // dW[i] += sum_s slab[s][i]
 __global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dW, size_t n, int splits) {
@@ -1112,7 +1138,15 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restr
 
 template <int MODE>
 static int launch_wgrad(WgradParams p, hipStream_t s) {
-    const int tiles = ((p.N + WG_T - 1) / WG_T) * ((p.K + WG_T - 1) / WG_T);
+    static const bool v2_on = !(getenv("SIDLSG_WGRAD_V2") && atoi(getenv("SIDLSG_WGRAD_V2")) == 0);
+    static const bool tn160_on = !(getenv("SIDLSG_WGRAD_TN160") && atoi(getenv("SIDLSG_WGRAD_TN160")) == 0);   // A/B switch
+    const bool aligned = !(p.N & 7) && !(p.K & 7) && !(p.ldy & 7) && !(p.lda & 7) && !(MODE == 1 && (p.Cin & 7)) &&
+                         !(((uintptr_t)p.dY | (uintptr_t)p.A) & 15);
+    const bool v2 = v2_on && aligned;
+    // 160-wide n tiles: measured faster only where they cut the tile count by a third (conv, Cout = 320: 216 -> 178 us);
+    // for N = 640 (5 -> 4 tiles) and the dense shapes the leaner 128 kernel wins
+    const int tn = (v2 && tn160_on && MODE == 1 && p.N == 320) ? 160 : WG_T;
+    const int tiles = ((p.N + tn - 1) / tn) * ((p.K + WG_T - 1) / WG_T);
     // Split the pixel contraction so the grid fills the chip in whole rounds of 512 resident blocks (256 CUs x 2).
     // Small cost model (us): rounds * (rows per block * 24 ns + 3 us block overhead) + slab reduction at ~4 TB/s;
     // e.g. 69 tiles: ceil(768/69) = 12 splits ran 1.6 rounds, the model picks a whole number of rounds.
@@ -1150,17 +1184,16 @@ static int launch_wgrad(WgradParams p, hipStream_t s) {
     }
     p.m_per_split = mps;
     p.nsplits = splits;
-    static const bool v2_on = !(getenv("SIDLSG_WGRAD_V2") && atoi(getenv("SIDLSG_WGRAD_V2")) == 0);
-    const bool aligned = !(p.N & 7) && !(p.K & 7) && !(p.ldy & 7) && !(p.lda & 7) && !(MODE == 1 && (p.Cin & 7)) &&
-                         !(((uintptr_t)p.dY | (uintptr_t)p.A) & 15);
-    if (v2_on && aligned) {
-        const size_t lds = (size_t)2 * WG2_STAGE * sizeof(bf16);
+    if (v2) {
+        const size_t lds = (size_t)2 * WG_MB * (tn + WG_T) * sizeof(bf16);
         static bool attr_done = false;
         if (!attr_done) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_v2_kernel<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_v2_kernel<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * WG_MB * (128 + WG_T) * 2);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_v2w_kernel<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * WG_MB * (160 + WG_T) * 2);
             attr_done = true;
         }
-        hipLaunchKernelGGL((wgrad_v2_kernel<MODE>), dim3(tiles * splits), dim3(NTHREADS), lds, s, p);
+        if (tn == 160) hipLaunchKernelGGL((wgrad_v2w_kernel<MODE>), dim3(tiles * splits), dim3(NTHREADS), lds, s, p);
+        else hipLaunchKernelGGL((wgrad_v2_kernel<MODE>), dim3(tiles * splits), dim3(NTHREADS), lds, s, p);
     } else
     hipLaunchKernelGGL((wgrad_bf16_kernel<MODE>), dim3(tiles, splits), dim3(NTHREADS), 0, s, p);
     if (splits > 1 && p.ws)

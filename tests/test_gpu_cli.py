@@ -2,10 +2,16 @@
 import glob
 import os
 
+import numpy as np
 import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
+
+
+def _png_pixels(path):
+    import PIL.Image
+    return np.asarray(PIL.Image.open(path).convert('RGB'))
 
 
 def test_train_then_generate(tmp_path):
@@ -36,7 +42,11 @@ def test_train_then_generate(tmp_path):
         assert res.exit_code == 0, res.output
         files = sorted(glob.glob(str(out / '*.png')))
         assert [os.path.basename(f) for f in files] == [f'{i:06d}.png' for i in range(4)]
-        outs.append([open(f, 'rb').read() for f in files])
-    assert outs[0] == outs[1]              # per-sample seeding: an image does not depend on the batch it was generated in
+        outs.append([_png_pixels(f) for f in files])
+    # per-sample seeding: an image does not depend on the batch it was generated in (up to a few uint8 levels: the batch
+    # size changes tile / split-K choices, i.e. the fp32 summation order)
+    for a, b in zip(outs[0], outs[1]):
+        assert a.shape == b.shape == (512, 512, 3)
+        assert np.abs(a.astype(np.int32) - b.astype(np.int32)).max() <= 4
     with open(glob.glob(str(tmp_path / 'img_b2' / '*.png'))[0], 'rb') as f:
         assert f.read(8) == b'\x89PNG\r\n\x1a\n'
