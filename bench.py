@@ -123,6 +123,7 @@ def main():
     ap.add_argument('--batch-gpu', type=int, default=8)
     ap.add_argument('--arch', default='sd15')
     ap.add_argument('--kappa', type=float, default=1.5)
+    ap.add_argument('--resolution', type=int, default=512, help='image resolution (latents are resolution/8); 768 for BASELINE config #4')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true')
     args = ap.parse_args()
@@ -154,7 +155,7 @@ def main():
     lib.load()
 
     b = args.batch_gpu
-    lat = 64
+    lat = args.resolution // 8
     phi, vae, sched, text_encoder, tokenizer = load_sd15(f'random:{args.arch}', None, dev, torch.bfloat16, seed=0)
     psi = phi.clone_network()
     G = phi.clone_network()
@@ -208,13 +209,17 @@ def main():
     if rank != 0:
         return
     value = args.steps * batch_size / dt
-    f_tflop = 2 * F_GMAC.get(args.arch, 0.0) / 1000.0
+    f_gmac = F_GMAC.get(args.arch, 0.0)
+    if args.resolution != 512:          # analytic walk of the oracle for other latent sizes (attention is not linear in pixels)
+        from oracle.unet_ref import CONFIGS as _RC, unet_forward_macs
+        f_gmac = unet_forward_macs(_RC[args.arch], lat, lat) / 1e9
+    f_tflop = 2 * f_gmac / 1000.0
     img_tflop = 18 * f_tflop if args.kappa != 1 else 11 * f_tflop
     out = {
-        'metric': 'distillation images/sec (512^2, SD1.5, kappa=1.5)', 'value': value, 'unit': 'images/s', 'n_gpus': world,
+        'metric': 'distillation images/sec (512^2, SD1.5, kappa=1.5)' if (args.arch, args.resolution, args.kappa) == ('sd15', 512, 1.5) else f'distillation images/sec ({args.resolution}^2, {args.arch}, kappa={args.kappa})', 'value': value, 'unit': 'images/s', 'n_gpus': world,
         'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1000.0, 'higher_is_better': True,
         'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
-        'config': {'workload': f'{args.arch} SiD-LSG inner step, kappa={args.kappa} on all branches, 512x512 (64x64x4 latents), '
+        'config': {'workload': f'{args.arch} SiD-LSG inner step, kappa={args.kappa} on all branches, {args.resolution}x{args.resolution} ({lat}x{lat}x4 latents), '
                                f'batch_gpu={b}, fp32 masters + bf16 MFMA compute, Adam(beta1=0)+EMA, random-init weights',
                    'global_batch': batch_size, 'parallelism': f'dp{world}'},
         'step_tflops': value * img_tflop, 'step_mfma_frac': value * img_tflop / (PEAK_BF16_TFLOPS * world),
