@@ -9,16 +9,20 @@
 //   O^T[d][query] += mfma(A = V^T (LDS transpose-read of the row-major V tile), B = P^T).
 // Two 16-key tiles are packed into one K=32 MFMA.  Softmax statistics are per query = per lane
 // (replicated over the 4 lane groups), so the online rescale is a per-lane scalar.
-// Head dims that are not multiples of 32 use one trailing 16-wide MFMA (d=40 -> 32+16 padded with
-// zeros, d=80 -> 64+16); nothing is padded in HBM.
-// K/V (or Q/dO) tiles are prefetched global->registers one tile ahead of the MFMAs and committed
-// to the single LDS buffer after the compute phase, so HBM/L2 latency hides under the MFMAs.
-// Loads are branch-free buffer loads (rows past the sequence end read zeros).
+// Head dims that are not multiples of 32 are zero-padded to the next K=32 slice in the QK^T / dO V^T contractions
+// (d=40 -> 64, d=80 -> 96; see Frag) and to the next multiple of 16 in the output rows (d=40 -> 48); nothing is
+// padded in HBM.  At d=40 the loop is VALU(softmax)-bound, so the file is compiled with MFMA results in VGPRs
+// (-amdgpu-mfma-vgpr-form) and -fno-honor-nans, the forward gets its softmax denominator from a ones column in V's
+// padding, and the ragged-tile masking is peeled out of the main loop (391 -> 148 VALU instructions per 64-key tile).
+// K/V (or Q/dO) tiles are prefetched global->registers one tile ahead of the MFMAs and committed to the other LDS
+// buffer after the compute phase (one barrier per tile).  Loads are branch-free buffer loads (rows past the sequence
+// end read zeros).
 //
 // Backward = two kernels without atomics:
-//   attn_dq   : same loop as forward (per query block, over key tiles): dQ^T = K^T dS^T
-//   attn_dkdv : per key block, over query tiles, in the non-transposed orientation
-//               S[query][key] so that P / dS are B operands of the contractions over queries.
+//   attn_q<MODE 1> : same loop as forward (per query block, over key tiles): dQ^T = K^T dS^T; computes delta =
+//                    rowsum(dO*O) from its fragments in the prologue and publishes it for the second kernel
+//   attn_dkdv      : per key block, over query tiles, in the non-transposed orientation S[query][key] so that P / dS
+//                    are B operands of the contractions over queries.
 #include "common.h"
 #include <stdlib.h>
 #include <type_traits>

@@ -9,16 +9,19 @@
 // tap*Cin + c) so a K-tile of 64 lies inside one tap and an A-tile row is a contiguous
 // 128-byte run of channels of one input pixel.
 //
-// Tiling: 256 threads = 4 waves (2x2); block tile BM x BN x 64, wave tile 64 x BN/2 as
-// 16x16x32 MFMAs; LDS double buffer, 128-byte rows with a 16-byte-chunk XOR swizzle
-// (chunk ^= (row>>1)&7) that makes every ds_read_b128 lane group conflict free;
-// global->register->LDS staging issued one K-tile ahead of the MFMAs.
-// Loads are branch-free: every operand is read through a buffer resource with the hardware
-// range check -- an out-of-image tap / row >= M / k >= K lane simply gets the OOB offset and
-// reads zeros.  Row offsets are computed once per tap (a wave-uniform event every Cin/64 tiles),
-// so the steady-state cost of the im2col is one v_add per 16-byte chunk.
-// The MFMA is issued "transposed" (rows = output channel, cols = pixel) and W-tile rows are
-// permuted per tile pair so that each lane ends up with 8 consecutive output channels of one
+// Kernels in this file:
+//   gemm_v3_kernel<MODE>      the main kernel (N % 160 == 0, dense rows or conv with Cin % 64 == 0, >= 384 tiles or split-K):
+//                             128 x 160 x 64 tile, tiles staged by buffer_load ... lds (direct to LDS), see its header
+//   gemm_bf16_kernel<BM,BN,M> every other shape (ragged N, Cin % 64 != 0, small grids): register-staged loads
+//   gemm_finish_kernel        epilogue of split-K launches (fp32 slabs -> bias/residual/activation -> bf16)
+//   wgrad_v2_kernel / _v2w    weight (+ bias) gradient, direct-to-LDS staging, transpose reads; wgrad_bf16_kernel for
+//                             unaligned / ragged operands; wgrad_reduce_kernel folds the pixel-split slabs
+// Common tiling: 256 threads = 4 waves (2x2); block tile BM x BN x 64, wave tile 64 x BN/2 as 16x16x32 MFMAs; LDS double
+// buffer, 128-byte rows with a 16-byte-chunk XOR swizzle that makes every ds_read_b128 lane group conflict free.
+// Loads are branch-free: every operand is read through a buffer resource with the hardware range check -- an
+// out-of-image tap / row >= M / k >= K lane simply gets the OOB offset and reads zeros.  Row offsets are computed once
+// per tap (a wave-uniform event every Cin/64 tiles).  The MFMA is issued "transposed" (rows = output channel, cols =
+// pixel) and W-tile rows are permuted per tile pair so that each lane ends up with 8 consecutive output channels of one
 // pixel: the epilogue stores 16 bytes per lane.
 #include "common.h"
 #include <stdlib.h>
@@ -712,7 +715,7 @@ static int check_common(const GemmParams& p) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// Weight gradient:  dW[N][K] (+)= sum_m dY[m][N] * A[m][K]     (fp32 atomics, split over m)
+// Weight gradient:  dW[N][K] += sum_m dY[m][N] * A[m][K]     (split over m; partial sums in fp32 slabs)
 //
 // Both operands are stored pixel-major, i.e. the contraction index m is the ROW of both LDS
 // tiles.  MFMA wants 8 consecutive contraction elements per lane, so fragments are fetched
