@@ -42,7 +42,8 @@ def close(got, ref, tol, name=''):
 
 # ----------------------------------------------------------------------------------------------
 @pytest.mark.parametrize('M,N,K', [(256, 320, 320), (1000, 136, 72), (4096, 960, 320), (77 * 2, 640, 768), (130, 8, 2880), (64, 2560, 320),
-                                   (1000, 1280, 2560), (300, 136, 4096)])   # last two: split-K path (few tiles, long K)
+                                   (1000, 1280, 2560), (300, 136, 4096),     # split-K path (few tiles, long K)
+                                   (49152, 320, 320), (49160, 320, 328)])                     # direct-to-LDS kernel (+ ragged M, K tail)
 def test_gemm(dev, M, N, K):
     from sid_lsg_amd import ops
     a, w = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5)
