@@ -28,6 +28,13 @@ def _is_hip(net):
     return isinstance(_unwrap(net), HipUNet2DCondition)
 
 
+def _require_hip(net):
+    """The glue below drives the HIP kernels directly (NHWC bf16, fused scheduler arithmetic).  It has no generic /
+    CPU branch: a foreign UNet belongs with the reference's own sid_sd_util (mode 2)."""
+    if not _is_hip(net):
+        raise TypeError(f'sid_lsg_amd.sd_util works on HipUNet2DCondition networks only, got {type(_unwrap(net)).__name__}')
+
+
 def _arch_of(name):
     n = name.lower()
     if n.startswith('random:'):
@@ -130,23 +137,15 @@ def sid_sd_sampler(unet, latents, contexts, init_timesteps, noise_scheduler, tex
                    dtype=torch.float16, return_images=False, vae=None, guidance_scale=1, num_steps=1, train_sampler=True,
                    num_steps_eval=1):
     steps = num_steps if train_sampler else num_steps_eval
-    emb = encode_contexts(contexts, text_encoder, tokenizer, latents.device)
-    hip = _is_hip(unet)
-    if hip:
-        emb = emb.to(torch.bfloat16).contiguous()
+    _require_hip(unet)
+    emb = encode_contexts(contexts, text_encoder, tokenizer, latents.device).to(torch.bfloat16).contiguous()
     D_x = None
     ctxmgr = torch.enable_grad() if train_sampler else torch.no_grad()
     with ctxmgr:
         for i in range(steps):
             noise = latents if i == 0 else torch.randn_like(latents)
             t_i = (init_timesteps * (1 - i / steps)).to(torch.long)
-            if hip:
-                D_x = hip_generate(unet, noise.to(torch.float32).contiguous(), emb, t_i.contiguous(), noise_scheduler, x0=D_x)
-            else:
-                x0 = torch.zeros_like(latents) if D_x is None else D_x
-                x_t = noise_scheduler.add_noise(x0, noise, t_i).to(torch.float32)
-                eps = unet(noise_scheduler.scale_model_input(x_t, t_i).to(dtype), t_i, encoder_hidden_states=emb).sample
-                D_x = noise_scheduler.step(eps.to(torch.float32), t_i[0], x_t).pred_original_sample.to(torch.float32)
+            D_x = hip_generate(unet, noise.to(torch.float32).contiguous(), emb, t_i.contiguous(), noise_scheduler, x0=D_x)
     if not return_images:
         return D_x.to(torch.float32)
     upcast = vae.dtype == torch.float16 and getattr(vae.config, 'force_upcast', False)
@@ -160,25 +159,13 @@ def sid_sd_sampler(unet, latents, contexts, init_timesteps, noise_scheduler, tex
 
 def sid_sd_denoise(unet, images, noise, contexts, timesteps, noise_scheduler, text_encoder, tokenizer, resolution,
                    dtype=torch.float16, predict_x0=True, guidance_scale=1):
+    _require_hip(unet)
     b = images.shape[0]
     cond = encode_contexts(contexts, text_encoder, tokenizer, images.device)
     guided = guidance_scale != 1
     uncond = encode_contexts([''] * b, text_encoder, tokenizer, images.device) if guided else None
-    if _is_hip(unet):
-        bf = torch.bfloat16
-        prep = hip_prepare_denoise(images.to(torch.float32).contiguous(), noise.to(torch.float32).contiguous(),
-                                   timesteps.contiguous(), cond.to(bf).contiguous(),
-                                   uncond.to(bf).contiguous() if guided else None, noise_scheduler, guided)
-        return hip_denoise(unet, prep, float(guidance_scale), predict_x0)
-    x_t = noise_scheduler.add_noise(images, noise, timesteps)
-    if not guided:
-        eps = unet(noise_scheduler.scale_model_input(x_t, timesteps).to(dtype), timesteps,
-                   encoder_hidden_states=cond).sample.to(torch.float32)
-    else:
-        both = unet(noise_scheduler.scale_model_input(torch.cat([x_t, x_t]), None).to(dtype), torch.cat([timesteps, timesteps]),
-                    encoder_hidden_states=torch.cat([uncond, cond])).sample.to(torch.float32)
-        eps_u, eps_c = both.chunk(2)
-        eps = eps_u + guidance_scale * (eps_c - eps_u)
-    if not predict_x0:
-        return eps
-    return noise_scheduler.step(eps, timesteps, x_t.to(torch.float32)).pred_original_sample.to(torch.float32)
+    bf = torch.bfloat16
+    prep = hip_prepare_denoise(images.to(torch.float32).contiguous(), noise.to(torch.float32).contiguous(),
+                               timesteps.contiguous(), cond.to(bf).contiguous(),
+                               uncond.to(bf).contiguous() if guided else None, noise_scheduler, guided)
+    return hip_denoise(unet, prep, float(guidance_scale), predict_x0)
