@@ -202,6 +202,25 @@ def main():
     dt = time.time() - t0
     if timer is not None:
         timer.__exit__()
+    # north_star's second figure: MFMA utilisation of the CFG teacher pass alone (phi forward on the [uncond; cond] batch of
+    # 2b samples + guidance + x0), timed with events on a few extra passes after the timed region (rank 0)
+    teacher = None
+    if not args.no_kernel_timing and rank == 0:
+        from sid_lsg_amd.sd_util import hip_denoise, hip_prepare_denoise
+        with torch.no_grad():
+            prompts = synth_prompts(b, seed=12345)
+            img = torch.randn(b, 4, lat, lat, device=dev, generator=gen)
+            prep = hip_prepare_denoise(img, torch.randn(b, 4, lat, lat, device=dev, generator=gen),
+                                       torch.randint(20, 980, (b,), device=dev, generator=gen), cond.encode(prompts), cond.uncond(b),
+                                       sched, args.kappa != 1)
+            hip_denoise(phi, prep, args.kappa, predict_x0=True)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5):
+                hip_denoise(phi, prep, args.kappa, predict_x0=True)
+            e1.record()
+            torch.cuda.synchronize()
+            teacher = e0.elapsed_time(e1) / 5.0
     if world > 1:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
@@ -225,6 +244,11 @@ def main():
         'step_tflops': value * img_tflop, 'step_mfma_frac': value * img_tflop / (PEAK_BF16_TFLOPS * world),
         'loss_fake': float(lf), 'loss_G': float(lg),
     }
+    if teacher is not None:
+        n_fwd = (2 if args.kappa != 1 else 1) * b
+        tf = n_fwd * f_tflop / (teacher * 1e-3)
+        out['teacher_pass'] = {'what': f'phi forward on the CFG batch of {n_fwd} samples + guidance + x0 (no grad)', 'ms': teacher,
+                               'tflops': tf, 'mfma_frac': tf / PEAK_BF16_TFLOPS}
     if timer is not None:
         r = timer.result()
         ach = r['flops'] / (r['ms'] * 1e-3) / 1e12 if r['ms'] > 0 else 0.0
