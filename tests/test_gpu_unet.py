@@ -124,10 +124,12 @@ def test_sid_iteration_matches_oracle(dev, kappa, alpha):
 
 
 @pytest.mark.skipif(os.environ.get('SIDLSG_FULLSIZE', '0') != '1', reason='minutes of CPU oracle time: set SIDLSG_FULLSIZE=1')
-def test_sid_iteration_full_size_config1(dev):
+@pytest.mark.parametrize('kappa', [1.5, 4.5])
+def test_sid_iteration_full_size_config1(dev, kappa):
     """BASELINE.json configs[0]: the reference's own CPU-runnable case -- full SD1.5 UNet (859.5 M parameters), kappa = 1.5,
-    batch 1, 64x64x4 latents; one complete iteration of the bf16 HIP path against the fp32 CPU oracle."""
-    _iteration_parity(dev, 'sd15', lat=64, b=1, rounds=1, lr=1e-6, kappa=1.5, alpha=1.0, iters=1,
+    batch 1, 64x64x4 latents; one complete iteration of the bf16 HIP path against the fp32 CPU oracle.  kappa = 4.5 is the
+    guidance scale of configs[2]."""
+    _iteration_parity(dev, 'sd15', lat=64, b=1, rounds=1, lr=1e-6, kappa=kappa, alpha=1.0, iters=1,
                       ema_names=('conv_in.weight', 'conv_out.bias'))
 
 
