@@ -33,6 +33,16 @@ def test_train_then_generate(tmp_path):
     assert snaps and glob.glob(os.path.join(run_dir, 'training-state-*.pt'))
     assert os.path.isfile(os.path.join(run_dir, 'training_options.json'))
 
+    # --transfer: a second run starts its generator from the snapshot; --resume: from the training state
+    states = sorted(glob.glob(os.path.join(run_dir, 'training-state-*.pt')))
+    for extra in (['--transfer', snaps[-1]], ['--resume', states[-1]]):
+        res = CliRunner().invoke(sid_train.main, [
+            '--outdir', str(runs), '--data_prompt_text', str(tmp_path), '--sd_model', 'random:tiny', '--seed', '2', '--batch', '4',
+            '--batch-gpu', '2', '--duration', '0.00003', '--ema', '0.00001', '--tick', '1', '--snap', '50', '--dump', '50',
+            '--resolution', '128'] + extra, catch_exceptions=False)
+        assert res.exit_code == 0, res.output
+    assert len(glob.glob(str(runs / '0000[0-9]-*'))) == 3
+
     outs = []
     for batch in (2, 4):
         out = tmp_path / f'img_b{batch}'
