@@ -37,7 +37,15 @@ def _chk(t, dtype=None):
 
 
 def _wants_grad(p):
-    return p is not None and p.requires_grad and p.grad is not None
+    """Weight gradients are wanted iff the parameter requires grad.  Its `.grad` must then be the pre-bound view of the
+    network's flat gradient buffer: HipUNet2DCondition re-binds (and zeroes) the views at the start of every forward if a
+    foreign optimizer ran `zero_grad(set_to_none=True)` (sid_training_loop.py:390,469), so a None here is a caller bug."""
+    if p is None or not p.requires_grad:
+        return False
+    if p.grad is None:
+        raise RuntimeError('parameter requires grad but has no gradient buffer bound (zero_grad(set_to_none=True) between '
+                           'forward and backward?): weight gradients would be lost')
+    return True
 
 
 # ------------------------------------------------------------------------------------------------
@@ -583,6 +591,25 @@ class _GradReady(torch.autograd.Function):
 
 def grad_ready_marker(x, cb):
     return _GradReady.apply(x, cb) if (cb is not None and x.requires_grad) else x
+
+
+class _AfterBackward(torch.autograd.Function):
+    """Identity on the network output; its backward (the FIRST node of that network's backward) queues `cb` on the
+    autograd engine, which runs it once the whole backward pass has finished."""
+
+    @staticmethod
+    def forward(ctx, x, cb):
+        ctx.cb = cb
+        return x.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, g):
+        torch.autograd.Variable._execution_engine.queue_callback(ctx.cb)
+        return g, None
+
+
+def after_backward(x, cb):
+    return _AfterBackward.apply(x, cb) if x.requires_grad else x
 
 
 def transpose_w_batched(jobs, njobs, nblocks):

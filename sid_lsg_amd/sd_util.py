@@ -3,10 +3,9 @@
     sid_sd_sampler   :163-211  one-step (or few-step) generator  z -> x_hat (or decoded images)
     sid_sd_denoise   :214-274  add_noise -> (CFG-batched) UNet -> guided eps or x0 prediction
 
-When `unet` is a HipUNet2DCondition the whole glue runs as fused HIP kernels
-(sidlsg_noisy_input / UNet / sidlsg_cfg_x0: no per-sample python loop, no host syncs, the CFG pair
-[uncond ; cond] shares one x_t).  For any other duck-typed `unet` (e.g. the CPU oracle net in the
-host-logic tests) the same arithmetic is expressed with tensor ops on whatever device it lives on.
+`unet` must be a HipUNet2DCondition (bare or wrapped in DistributedDataParallel, as the reference's loop passes it):
+the whole glue runs as fused HIP kernels (sidlsg_noisy_input / UNet / sidlsg_cfg_x0: no per-sample python loop, no
+host syncs, the CFG pair [uncond ; cond] shares one x_t).  There is no generic / CPU branch: any other network raises.
 """
 import os
 from types import SimpleNamespace
@@ -22,6 +21,26 @@ from .unet import CONFIGS, HipUNet2DCondition
 
 def _unwrap(net):
     return net.module if hasattr(net, 'module') and isinstance(net.module, torch.nn.Module) else net
+
+
+def _ddp_exchange(net, out):
+    """INTEGRATION.md mode 2: the reference wraps fake_score / G in DistributedDataParallel (sid_training_loop.py:316-323)
+    and hands the WRAPPER to sid_sd_sampler / sid_sd_denoise.  The HIP networks accumulate weight gradients in place in
+    one flat buffer (autograd never sees per-parameter gradients), so DDP's bucket hooks cannot fire; the wrapper is
+    honoured as a marker instead: when it is in sync mode (outside `no_sync()`, i.e. the last accumulation round of
+    misc.ddp_sync, torch_utils/misc.py:168-175) the flat gradient buffer is all-reduced to the mean once this backward
+    pass has finished -- the same result DDP's buckets produce, as one exchange."""
+    inner = _unwrap(net)
+    if inner is net or not (torch.distributed.is_available() and torch.distributed.is_initialized()):
+        return out
+    world = torch.distributed.get_world_size()
+    if world == 1 or not getattr(net, 'require_backward_grad_sync', True) or not inner._train_params:
+        return out
+
+    def exchange():
+        torch.distributed.all_reduce(inner.flat_grads)
+        inner.flat_grads.div_(world)
+    return ops.after_backward(out, exchange)
 
 
 def _is_hip(net):
@@ -79,7 +98,12 @@ def load_sd15(pretrained_model_name_or_path, pretrained_vae_model_name_or_path, 
         from safetensors.torch import load_file
         te = os.path.join(name, 'text_encoder', 'model.safetensors')
         if os.path.isfile(te):
-            text_encoder.load_state_dict(load_file(te), strict=False)
+            res = text_encoder.load_state_dict(load_file(te), strict=False)
+            # transformers checkpoints may carry the (non-parameter) position-id buffer; anything else missing or
+            # unexpected would silently leave seeded random weights in the conditioning of all three networks
+            bad = [k for k in list(res.missing_keys) + list(res.unexpected_keys) if not k.endswith('position_ids')]
+            if bad:
+                raise RuntimeError(f'{te}: text-encoder checkpoint does not match the architecture: {bad[:8]}')
         vj, mt = os.path.join(name, 'tokenizer', 'vocab.json'), os.path.join(name, 'tokenizer', 'merges.txt')
         if os.path.isfile(vj) and os.path.isfile(mt):
             tokenizer = CLIPBPETokenizer.from_files(vj, mt, model_max_length=cfg.text_len, pad_token_id=tokenizer.pad_token_id)
@@ -113,7 +137,7 @@ def hip_generate(unet, z, ctx16, init_t, sched, x0=None):
     """x_t = s0*x0 + s1*z at t_init ; eps = G(x_t) ; x_hat = (x_t - s1*eps)/s0   (sid_sd_util.py:182-185)"""
     s0, s1 = sched.coefficients(init_t)
     xin, xt = ops.noisy_input(x0, z, s0, s1, 1)
-    eps = _unwrap(unet).forward_nhwc(xin, init_t, ctx16)
+    eps = _ddp_exchange(unet, _unwrap(unet).forward_nhwc(xin, init_t, ctx16))
     return ops.cfg_x0(eps, xt, s0, s1, 1.0, True)
 
 
@@ -128,7 +152,7 @@ def hip_prepare_denoise(images, noise, t, cond16, uncond16, sched, guided):
 
 
 def hip_denoise(unet, prep, guidance_scale, predict_x0):
-    eps = _unwrap(unet).forward_nhwc(prep.xin, prep.tt, prep.ctx)
+    eps = _ddp_exchange(unet, _unwrap(unet).forward_nhwc(prep.xin, prep.tt, prep.ctx))
     return ops.cfg_x0(eps, prep.xt, prep.s0, prep.s1, guidance_scale, predict_x0)  # u + k(c-u), then x0 (:264-272)
 
 

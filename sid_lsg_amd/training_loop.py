@@ -4,11 +4,16 @@ the minimal harness around it that the reference also has: dataset + prompt stre
 construction by class name, accumulation rounds, EMA schedule, tick statistics (`stats_{alpha}.jsonl`,
 `Timing/sec_per_kimg`), snapshots (`network-snapshot-*.pkl`) and training-state dumps.
 
-Kept bit-for-bit in meaning: seeding (:238-239), batch_gpu / accumulation arithmetic (:246-250), the 16 consumed
-example prompt batches (:277-281), prompt dropout 10% iff kappa1 or kappa2 != 1 (:208-211, 393-396), RNG draw order
-inside a round (dropout flags, z, noise, t), EMA beta schedule (:553-558), `cur_nimg` accounting (:567).
+Kept in meaning and in RNG consumption: seeding (:238-239), batch_gpu / accumulation arithmetic (:246-250), the base-seed
+draw `iter(DataLoader)` makes from the default CPU generator (:275), the 16 consumed example prompt batches (:277-281),
+prompt dropout 10% iff kappa1 or kappa2 != 1 (:208-211, 393-396), the draw order inside a round (dropout flags on the
+CPU generator; z, noise, t on `device`), EMA beta schedule (:553-558), `cur_nimg` accounting (:567).  `PromptStream`
+below is that stream; tests/test_host_logic.py pins it (prompt order, dropout flags, z / noise / t on the CPU
+generator) to the restatement that reproduces the reference's golden loss curves, and tests/test_gpu_unet.py runs this
+loop against tests/golden/loop_*.npz (curves produced by the UNMODIFIED reference training_loop).
 Not reproduced: preview PNG grids / FID metrics (cold path), torch.cuda.empty_cache +
-gc.collect every iteration (:384-385, a pure slowdown).
+gc.collect every iteration (:384-385, a pure slowdown).  Rejected loudly rather than ignored: num_steps != 1 (the
+reference's own multi-step training sampler is marked unfinished, sid_sd_util.py:165).
 """
 import copy
 import json
@@ -47,6 +52,38 @@ class Stats:
         self.acc = {}
 
 
+class PromptStream:
+    """The per-rank input stream of the loop: which prompts, which of them are dropped, and z / noise / t of every
+    accumulation round, with the reference's RNG consumption order (sid_training_loop.py:238-239, 274-281, 391-413,
+    472-484).  `rng_device` is where z / noise / t are drawn: the training device in production (as the reference
+    does, device=device at :398-399, 413), 'cpu' when a run has to reproduce a CPU-generated reference curve."""
+
+    def __init__(self, dataset_obj, *, seed, rank, world, batch_gpu, lat, tmin, tmax, device, rng_device=None):
+        np.random.seed((seed * world + rank) % (1 << 31))                                   # :238
+        torch.manual_seed(np.random.randint(1 << 31))                                       # :239
+        self.device = torch.device(device)
+        self.rng_device = torch.device(rng_device) if rng_device is not None else self.device
+        self.lat, self.tmin, self.tmax = lat, tmin, tmax
+        sampler = InfiniteSampler(dataset_obj, rank=rank, num_replicas=world, seed=seed)    # :274
+        # :275 iter(DataLoader(...)) draws the iterator's base seed from the default CPU generator: part of the stream
+        # the dropout flags below come from
+        torch.empty((), dtype=torch.int64).random_()
+        self.prompts_it = prompt_batches(dataset_obj, sampler, batch_gpu)
+
+    def next_prompts(self):
+        return next(self.prompts_it)
+
+    def round(self, dropout):
+        prompts = self.next_prompts()
+        if dropout:
+            flags = (torch.rand(len(prompts)) < 0.1).tolist()                               # :394 (CPU generator)
+            prompts = ['' if f else p for f, p in zip(flags, prompts)]
+        z = torch.randn([len(prompts), 4, self.lat, self.lat], device=self.rng_device, dtype=torch.float32)   # :398 / :479
+        noise = torch.randn_like(z)                                                         # :399 / :480
+        t = torch.randint(self.tmin, self.tmax, (len(prompts),), device=self.rng_device, dtype=torch.long)    # :413 / :484
+        return prompts, z.to(self.device), noise.to(self.device), t.to(self.device)
+
+
 def training_loop(
     run_dir='.', dataset_kwargs={}, data_loader_kwargs={}, network_kwargs={}, loss_kwargs={},
     fake_score_optimizer_kwargs={}, g_optimizer_kwargs={}, augment_kwargs=None, seed=0, batch_size=512, batch_gpu=None,
@@ -57,10 +94,19 @@ def training_loop(
     pretrained_vae_model_name_or_path='runwayml/stable-diffusion-v1-5', fake_score_use_lora=False,
     dataset_prompt_text_kwargs={}, cfg_train_fake=1, cfg_eval_fake=1, cfg_eval_real=1, num_steps=1, train_mode=True,
     network_pkl=None, enable_xformers=True, gradient_checkpointing=False, resolution=512, on_iteration=None,
+    rng_device=None,
 ):
     if not train_mode:
         raise NotImplementedError('evaluation mode (FID/CLIP metrics) is outside the hot-path scope (SURVEY.md section 8(f))')
+    if num_steps != 1:
+        raise NotImplementedError(f'num_steps={num_steps}: only the one-step generator is trained (the reference marks its '
+                                  'multi-step training sampler as unfinished, sid_sd_util.py:165)')
     rank, world = dist.get_rank(), dist.get_world_size()
+    if dict(network_kwargs).get('use_fp16'):
+        dist.print0('note: --fp16 is accepted for compatibility; this path keeps fp32 masters and computes in bf16 (no fp16 '
+                    'weights / optimizer state, hence no fp16 gradient clipping)')
+    if gradient_checkpointing:
+        dist.print0('note: gradient_checkpointing is ignored (as in the reference loop, sid_training_loop.py:224-228)')
     dist.print0('Loading dataset...')
     dataset_obj = construct_class_by_name(**dataset_prompt_text_kwargs)
     dtype = torch.bfloat16   # compute dtype of the HIP path (masters fp32); network_kwargs.use_fp16 is accepted and ignored
@@ -76,8 +122,6 @@ def training_loop(
     dist.print0('Loading network completed')
 
     start_time = time.time()
-    np.random.seed((seed * world + rank) % (1 << 31))
-    torch.manual_seed(np.random.randint(1 << 31))
     batch_gpu_total = batch_size // world
     if batch_gpu is None or batch_gpu > batch_gpu_total:
         batch_gpu = batch_gpu_total
@@ -85,11 +129,11 @@ def training_loop(
     assert batch_size == batch_gpu * rounds * world
     lat = resolution // (2 ** (len(vae.config.block_out_channels) - 1))
 
-    sampler = InfiniteSampler(dataset_obj, rank=rank, num_replicas=world, seed=seed)
-    prompts_it = prompt_batches(dataset_obj, sampler, batch_gpu)
+    stream = PromptStream(dataset_obj, seed=seed, rank=rank, world=world, batch_gpu=batch_gpu, lat=lat, tmin=tmin, tmax=tmax,
+                          device=device, rng_device=rng_device)
     dist.print0('Example text prompts used for distillation:')
     for i in range(16):
-        dist.print0(i, next(prompts_it))
+        dist.print0(i, stream.next_prompts())
 
     true_score = unet.eval().requires_grad_(False)
     fake_score = copy.deepcopy(true_score).train().requires_grad_(True)
@@ -128,13 +172,7 @@ def training_loop(
                    world_size=world)
 
     def make_round(dropout):
-        prompts = next(prompts_it)
-        if dropout:
-            flags = (torch.rand(len(prompts)) < 0.1).tolist()
-            prompts = ['' if f else p for f, p in zip(flags, prompts)]
-        z = torch.randn([len(prompts), 4, lat, lat], device=device, dtype=torch.float32)
-        noise = torch.randn_like(z)
-        t = torch.randint(tmin, tmax, (len(prompts),), device=device, dtype=torch.long)
+        prompts, z, noise, t = stream.round(dropout)
         return dict(z=z, noise=noise, t=t, cond=cond.encode(prompts), uncond=cond.uncond(len(prompts)))
 
     dist.print0(f'Training for {total_kimg} kimg...')

@@ -241,3 +241,53 @@ def test_generate_cli_helpers():
     a = g.StackedRandomGenerator('cpu', [7, 8]).randn([2, 4, 3, 3])
     b = g.StackedRandomGenerator('cpu', [8]).randn([1, 4, 3, 3])
     assert torch.equal(a[1], b[0])          # a sample depends on its own seed only, not on the batch
+
+
+@pytest.mark.parametrize('golden', ['loop_k15_a1', 'loop_k1_a12', 'loop_k45_a1'])
+def test_prompt_stream_matches_reference_rng_order(golden_dir, tmp_path, golden):
+    """the PRODUCT loop's input stream (prompt order, dropout flags, z, noise, t) equals, draw
+    for draw, the stream of oracle.sid_ref.training_loop_ref -- the restatement that reproduces the loss curves the
+    UNMODIFIED reference training_loop produced for tests/golden/loop_*.npz (tests/test_oracle_pinned.py), including the
+    base-seed draw of iter(DataLoader) (sid_training_loop.py:275).  Everything on the CPU generator (rng_device='cpu')."""
+    from oracle import fixtures, sid_ref
+    from sid_lsg_amd.data import PromptDataset
+    from sid_lsg_amd.training_loop import PromptStream
+    g = np.load(os.path.join(golden_dir, golden + '.npz'))
+    prompts = [str(p) for p in g['prompts']]
+    kw = dict(iterations=int(g['kw_iterations']), batch_size=int(g['kw_batch_size']), batch_gpu=int(g['kw_batch_gpu']),
+              seed=int(g['kw_seed']), kappa=tuple(float(k) for k in g['kw_kappa']), resolution=int(g['kw_resolution']))
+    # --- oracle stream: record the inputs of every iteration
+    recorded = []
+    orig_iter = sid_ref.sid_iteration_ref
+    try:   # replace the compute by a recorder: the stream must not depend on it
+        sid_ref.sid_iteration_ref = lambda nets, st, sched, inputs, hp: (recorded.append(inputs), dict(loss_fake=0.0, loss_G=0.0))[1]
+        sid_ref.training_loop_ref(lambda: fixtures.factory(str(g['cfg'])), prompts, alpha=float(g['kw_alpha']), **kw)
+    finally:
+        sid_ref.sid_iteration_ref = orig_iter
+    # --- product stream
+    pdir = tmp_path / 'p'
+    pdir.mkdir()
+    (pdir / 'aesthetics_6_plus.txt').write_text('\n'.join(prompts) + '\n')
+    ds = PromptDataset(str(pdir), resolution=kw['resolution'])
+    rounds = kw['batch_size'] // kw['batch_gpu']
+    _, _, _, te, tok = fixtures.factory(str(g['cfg']))       # (module construction consumes RNG: before the stream is seeded)
+    stream = PromptStream(ds, seed=kw['seed'], rank=0, world=1, batch_gpu=kw['batch_gpu'], lat=kw['resolution'] // 8, tmin=20,
+                          tmax=980, device='cpu', rng_device='cpu')
+    for _ in range(16):
+        stream.next_prompts()
+    use_dropout = kw['kappa'][0] != 1 or kw['kappa'][1] != 1
+
+    def embed(ps):
+        ids = tok(ps, padding='max_length', max_length=tok.model_max_length, truncation=True, return_tensors='pt').input_ids
+        with torch.no_grad():
+            return te(ids)[0]
+    ndrop = 0
+    for it in range(kw['iterations']):
+        for ph, drop in (('A', use_dropout), ('B', False)):
+            for r in range(rounds):
+                ps, z, noise, t = stream.round(drop)
+                ref = recorded[it][ph][r]
+                assert torch.equal(z, ref['z']) and torch.equal(noise, ref['noise']) and torch.equal(t, ref['t']), (it, ph, r)
+                assert torch.equal(embed(ps), ref['cond']), f'prompts / dropout flags differ at iteration {it} phase {ph} round {r}'
+                ndrop += sum(p == '' for p in ps)
+    print(golden, 'dropped prompts in the stream:', ndrop)
