@@ -147,6 +147,61 @@ int sidlsg_transpose_w_batched(const void* jobs, int njobs, int nblocks, void* s
 int sidlsg_bias_act(const void* x, const void* b, const void* dy, void* out, long long n, int stepB, int sizeB, int act,
                     float alpha, float gain, float clamp, int grad, int dtype, void* stream);
 
+/* ---- fp32-accurate compute mode ------------------------------------------------------------------------------
+ * The reference's default precision is fp32 (training/sid_training_loop.py:205 `dtype = float16 if use_fp16 else float32`,
+ * run_sid.sh:63-88) and BASELINE.json configs[0] is fp32.  Every entry point above that touches bf16 activations also
+ * exists with the suffix _f32: same arguments and semantics, but activations (A/X/C/Y/res, x/y/dy/dx, Q/K/V/O, ...) and
+ * the compute copies of the weights (W, transposed W) are fp32 and the contractions run on the f32-input matrix
+ * cores (v_mfma_f32_16x16x4_f32: exact fp32 products, fp32 accumulation).  Selected per network by
+ * HipUNet2DCondition(compute_dtype=torch.float32); used by the parity suite to assert north_star's 1e-3 bound.
+ * Differences: K, lda, ldx, ldy multiples of 4; flags: only SIDLSG_SILU / SIDLSG_ACCUM (C is always fp32); the
+ * weight-gradient entry points take dBias = NULL (the bias gradient is a sidlsg_colsum_f32 call); no workspace is used;
+ * sidlsg_transpose_w(_batched)_f32 write fp32 destinations. */
+int sidlsg_gemm_f32(const void* A, int lda, const void* W, void* C, int ldc, const float* bias, const void* res, int ldres,
+                    const float* rowvec, int ld_rowvec, int rows_per_batch, int M, int N, int K, float alpha, int flags,
+                    void* stream);
+int sidlsg_conv3x3_f32(const void* X, int ldx, const void* W, void* Y, int ldc, const float* bias, const void* res, int ldres,
+                       const float* rowvec, int ld_rowvec, int B, int H, int Wd, int Cin, int Cout, int stride, int ups,
+                       float alpha, int flags, void* stream);
+int sidlsg_wgrad_f32(const void* dY, int ldy, const void* A, int lda, float* dW, float* dBias, int M, int N, int K,
+                     void* stream);
+int sidlsg_conv3x3_wgrad_f32(const void* dY, int ldy, const void* X, int ldx, float* dW, float* dBias, int B, int H, int Wd,
+                             int Cin, int Cout, int stride, int ups, void* stream);
+int sidlsg_groupnorm_fwd_f32(const void* x, const float* gamma, const float* beta, void* y, float* stats, float* ws, int B,
+                             int HW, int C, int G, float eps, int silu, void* stream);
+int sidlsg_groupnorm_bwd_f32(const void* x, const void* dy, const float* stats, const float* gamma, const float* beta,
+                             const void* dres, void* dx, float* dgamma, float* dbeta, float* ws, int B, int HW, int C, int G,
+                             int silu, void* stream);
+int sidlsg_layernorm_fwd_f32(const void* x, const float* gamma, const float* beta, void* y, float* stats, int rows, int C,
+                             float eps, void* stream);
+int sidlsg_layernorm_bwd_f32(const void* x, const void* dy, const float* stats, const float* gamma, const void* dres, void* dx,
+                             float* dgamma, float* dbeta, float* ws, int rows, int C, void* stream);
+int sidlsg_attn_fwd_f32(const void* Q, const void* K, const void* V, void* O, float* LSE, int B, int H, int Nq, int Nk, int D,
+                        int ldq, int ldk, int ldv, int ldo, long long bsq, long long bsk, long long bsv, long long bso,
+                        void* stream);
+int sidlsg_attn_bwd_f32(const void* Q, const void* K, const void* V, const void* O, const void* dO, const float* LSE, void* dQ,
+                        void* dK, void* dV, float* delta, int B, int H, int Nq, int Nk, int D, int ldq, int ldk, int ldv,
+                        int ldo, long long bsq, long long bsk, long long bsv, long long bso, void* stream);
+int sidlsg_noisy_input_f32(const float* x0, const float* noise, const float* s0, const float* s1, void* out, float* xt, int B,
+                           int C, int HW, int Cp, int dup, void* stream);
+int sidlsg_noisy_input_bwd_f32(const void* g, const float* s0, float* dx0, int B, int C, int HW, int Cp, int dup,
+                               int accumulate, void* stream);
+int sidlsg_cfg_x0_bwd_f32(const float* g, const float* s0, const float* s1, void* deps, float* dxt, int B, int C, int HW,
+                          int Cp, int dup, float kappa, int predict_x0, void* stream);
+int sidlsg_timestep_embed_f32(const long long* t, void* out, int B, int dim, void* stream);
+int sidlsg_silu_fwd_f32(const void* x, void* y, long long n, void* stream);
+int sidlsg_silu_bwd_f32(const void* x, const void* dy, void* dx, long long n, void* stream);
+int sidlsg_geglu_fwd_f32(const void* h, void* y, long long M, int F, void* stream);
+int sidlsg_geglu_bwd_f32(const void* h, const void* dy, void* dh, long long M, int F, void* stream);
+int sidlsg_concat2_f32(void* a, void* b, void* out, long long M, int C1, int C2, int to_parts, void* stream);
+int sidlsg_sumpool2x2_f32(const void* g, void* out, int B, int H, int W, int C, void* stream);
+int sidlsg_zero_insert2_f32(const void* g, void* out, int B, int Ho, int Wo, int H, int W, int C, void* stream);
+int sidlsg_add_f32(const void* a, const void* b, void* o, long long n, void* stream);
+int sidlsg_colsum_f32(const void* g, int ldg, float* per_batch, float* total, float* ws, int B, int rows_per_batch, int N,
+                      void* stream);
+int sidlsg_transpose_w_f32(const float* src, void* dst, int N, int K, int T, void* stream);
+int sidlsg_transpose_w_batched_f32(const void* jobs, int njobs, int nblocks, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

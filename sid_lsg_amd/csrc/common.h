@@ -54,5 +54,33 @@ DEVFN bf16x8 zero8() {
     return __builtin_bit_cast(bf16x8, z);
 }
 
+// 8 consecutive activation elements as fp32 registers.  The kernels are templated on the activation storage type T:
+// bf16 (production: 16 bytes per lane) or float (the fp32-accurate parity mode: two 16-byte accesses per lane).
+template <typename T> DEVFN void ldv8(const T* p, float (&v)[8]);
+template <> DEVFN void ldv8<bf16>(const bf16* p, float (&v)[8]) {
+    const bf16x8 t = ld8(p);
+#pragma unroll
+    for (int e = 0; e < 8; e++) v[e] = bf2f(t[e]);
+}
+template <> DEVFN void ldv8<float>(const float* p, float (&v)[8]) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
+    v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
+}
+template <typename T> DEVFN void stv8(T* p, const float (&v)[8]);
+template <> DEVFN void stv8<bf16>(bf16* p, const float (&v)[8]) {
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; e++) o[e] = f2bf(v[e]);
+    st8(p, o);
+}
+template <> DEVFN void stv8<float>(float* p, const float (&v)[8]) {
+    *reinterpret_cast<f32x4*>(p) = (f32x4){v[0], v[1], v[2], v[3]};
+    *reinterpret_cast<f32x4*>(p + 4) = (f32x4){v[4], v[5], v[6], v[7]};
+}
+template <typename T> DEVFN void zerov8(T* p) {
+    const float z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    stv8<T>(p, z);
+}
+
 // Launch-error helper for the extern "C" entry points: returns the HIP error code (0 = ok).
 static inline int sidlsg_last_error() { return (int)hipGetLastError(); }

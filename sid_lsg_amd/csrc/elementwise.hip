@@ -5,40 +5,45 @@
 #define GRID1D(n, per) dim3((unsigned)((((size_t)(n)) + (per) - 1) / (per)))
 
 // ---- layout ---------------------------------------------------------------------------------
-// x_t = s0[b]*x0 + s1[b]*noise (x0 may be null), written as NHWC bf16 with Cp (>=C, mult of 8)
+// Kernels below that touch activations are templated on the activation storage type T: bf16 (production) or float
+// (the fp32-accurate parity mode; entry points with the _f32 suffix).  Math is fp32 inside either way.
+// x_t = s0[b]*x0 + s1[b]*noise (x0 may be null), written as NHWC with Cp (>=C, mult of 8)
 // channels (zero padded), replicated `dup` times along batch (CFG: [uncond ; cond] share x_t).
 // Also optionally stores x_t in fp32 NCHW (needed later for the x0 prediction).
+template <typename T>
 __global__ void noisy_input_kernel(const float* __restrict__ x0, const float* __restrict__ noise,
                                    const float* __restrict__ s0, const float* __restrict__ s1,
-                                   bf16* __restrict__ out, float* __restrict__ xt, int B, int C, int HW, int Cp, int dup) {
+                                   T* __restrict__ out, float* __restrict__ xt, int B, int C, int HW, int Cp, int dup) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;  // over B*HW
     if (idx >= B * HW) return;
     const int b = idx / HW, p = idx - b * HW;
-    bf16x8 o = zero8();
+    float o[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int c = 0; c < C; c++) {
         const size_t i = ((size_t)b * C + c) * HW + p;
         float v = s1[b] * noise[i];
         if (x0) v += s0[b] * x0[i];
         if (xt) xt[i] = v;
-        o[c] = f2bf(v);
+        o[c] = v;
     }
     for (int d = 0; d < dup; d++) {
-        bf16* dst = out + ((size_t)(d * B + b) * HW + p) * Cp;
-        st8(dst, o);
-        for (int c = 8; c < Cp; c += 8) st8(dst + c, zero8());
+        T* dst = out + ((size_t)(d * B + b) * HW + p) * Cp;
+        stv8<T>(dst, o);
+        for (int c = 8; c < Cp; c += 8) zerov8<T>(dst + c);
     }
 }
 
-// d_x0[b,c,p] = s0[b] * sum_d g[(d*B+b), p, c]   (backward of noisy_input wrt x0); g NHWC bf16
-__global__ void noisy_input_bwd_kernel(const bf16* __restrict__ g, const float* __restrict__ s0, float* __restrict__ dx0,
+// d_x0[b,c,p] = s0[b] * sum_d g[(d*B+b), p, c]   (backward of noisy_input wrt x0); g NHWC
+template <typename T>
+__global__ void noisy_input_bwd_kernel(const T* __restrict__ g, const float* __restrict__ s0, float* __restrict__ dx0,
                                        int B, int C, int HW, int Cp, int dup, int accumulate) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= B * HW) return;
     const int b = idx / HW, p = idx - b * HW;
     float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int d = 0; d < dup; d++) {
-        const bf16x8 v = ld8(g + ((size_t)(d * B + b) * HW + p) * Cp);
-        for (int c = 0; c < 8; c++) acc[c] += bf2f(v[c]);
+        float v[8];
+        ldv8<T>(g + ((size_t)(d * B + b) * HW + p) * Cp, v);
+        for (int c = 0; c < 8; c++) acc[c] += v[c];
     }
     for (int c = 0; c < C; c++) {
         const size_t i = ((size_t)b * C + c) * HW + p;
@@ -63,147 +68,158 @@ __global__ void cfg_x0_kernel(const float* __restrict__ eps, const float* __rest
     }
 }
 
-// backward of cfg_x0: d_eps (NHWC bf16 [dup*B][HW][Cp], zero padded) and, when predict_x0, d_xt = g/s0 (fp32 NCHW)
+// backward of cfg_x0: d_eps (NHWC [dup*B][HW][Cp], zero padded) and, when predict_x0, d_xt = g/s0 (fp32 NCHW)
+template <typename T>
 __global__ void cfg_x0_bwd_kernel(const float* __restrict__ g, const float* __restrict__ s0, const float* __restrict__ s1,
-                                  bf16* __restrict__ deps, float* __restrict__ dxt, int B, int C, int HW, int Cp, int dup,
+                                  T* __restrict__ deps, float* __restrict__ dxt, int B, int C, int HW, int Cp, int dup,
                                   float kappa, int predict_x0) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= B * HW) return;
     const int b = idx / HW, p = idx - b * HW;
-    bf16x8 du = zero8(), dc = zero8();
+    float du[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int c = 0; c < C; c++) {
         const size_t i = ((size_t)b * C + c) * HW + p;
         const float go = g[i];
         const float ge = predict_x0 ? -go * s1[b] / s0[b] : go;
         if (dxt) dxt[i] = predict_x0 ? go / s0[b] : 0.f;
-        if (dup == 2) { du[c] = f2bf((1.f - kappa) * ge); dc[c] = f2bf(kappa * ge); }
-        else du[c] = f2bf(ge);
+        if (dup == 2) { du[c] = (1.f - kappa) * ge; dc[c] = kappa * ge; }
+        else du[c] = ge;
     }
-    bf16* d0 = deps + ((size_t)b * HW + p) * Cp;
-    st8(d0, du);
-    for (int c = 8; c < Cp; c += 8) st8(d0 + c, zero8());
+    T* d0 = deps + ((size_t)b * HW + p) * Cp;
+    stv8<T>(d0, du);
+    for (int c = 8; c < Cp; c += 8) zerov8<T>(d0 + c);
     if (dup == 2) {
-        bf16* d1 = deps + ((size_t)(B + b) * HW + p) * Cp;
-        st8(d1, dc);
-        for (int c = 8; c < Cp; c += 8) st8(d1 + c, zero8());
+        T* d1 = deps + ((size_t)(B + b) * HW + p) * Cp;
+        stv8<T>(d1, dc);
+        for (int c = 8; c < Cp; c += 8) zerov8<T>(d1 + c);
     }
 }
 
-// ---- timestep embedding: [cos | sin] of t * exp(-ln(1e4) * i/half), bf16 [B][dim] -----------
-__global__ void timestep_embed_kernel(const long long* __restrict__ t, bf16* __restrict__ out, int B, int dim) {
+// ---- timestep embedding: [cos | sin] of t * exp(-ln(1e4) * i/half), [B][dim] ---------------
+template <typename T>
+__global__ void timestep_embed_kernel(const long long* __restrict__ t, T* __restrict__ out, int B, int dim) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     const int half = dim >> 1;
     if (idx >= B * half) return;
     const int b = idx / half, i = idx - b * half;
     const float freq = expf(-9.210340371976184f * (float)i / (float)half);
     const float a = (float)t[b] * freq;
-    out[(size_t)b * dim + i] = f2bf(cosf(a));
-    out[(size_t)b * dim + half + i] = f2bf(sinf(a));
+    out[(size_t)b * dim + i] = (T)cosf(a);
+    out[(size_t)b * dim + half + i] = (T)sinf(a);
 }
 
 // ---- activations ----------------------------------------------------------------------------
-__global__ void silu_fwd_kernel(const bf16* __restrict__ x, bf16* __restrict__ y, size_t n8) {
+template <typename T>
+__global__ void silu_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, size_t n8) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n8) return;
-    const bf16x8 v = ld8(x + i * 8);
-    bf16x8 o;
+    float v[8];
+    ldv8<T>(x + i * 8, v);
 #pragma unroll
-    for (int e = 0; e < 8; e++) o[e] = f2bf(silu_f(bf2f(v[e])));
-    st8(y + i * 8, o);
+    for (int e = 0; e < 8; e++) v[e] = silu_f(v[e]);
+    stv8<T>(y + i * 8, v);
 }
-__global__ void silu_bwd_kernel(const bf16* __restrict__ x, const bf16* __restrict__ dy, bf16* __restrict__ dx, size_t n8) {
+template <typename T>
+__global__ void silu_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ dx, size_t n8) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n8) return;
-    const bf16x8 v = ld8(x + i * 8), d = ld8(dy + i * 8);
-    bf16x8 o;
+    float v[8], d[8];
+    ldv8<T>(x + i * 8, v); ldv8<T>(dy + i * 8, d);
 #pragma unroll
-    for (int e = 0; e < 8; e++) o[e] = f2bf(bf2f(d[e]) * silu_grad_f(bf2f(v[e])));
-    st8(dx + i * 8, o);
+    for (int e = 0; e < 8; e++) d[e] *= silu_grad_f(v[e]);
+    stv8<T>(dx + i * 8, d);
 }
 
 // GEGLU: h [M][2F] -> y [M][F] = h[:, :F] * gelu(h[:, F:])
-__global__ void geglu_fwd_kernel(const bf16* __restrict__ h, bf16* __restrict__ y, size_t M, int F) {
+template <typename T>
+__global__ void geglu_fwd_kernel(const T* __restrict__ h, T* __restrict__ y, size_t M, int F) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int F8 = F >> 3;
     if (i >= M * F8) return;
     const size_t m = i / F8; const int c = (int)(i - m * F8) * 8;
-    const bf16x8 a = ld8(h + m * 2 * F + c), g = ld8(h + m * 2 * F + F + c);
-    bf16x8 o;
+    float a[8], g[8];
+    ldv8<T>(h + m * 2 * F + c, a); ldv8<T>(h + m * 2 * F + F + c, g);
 #pragma unroll
-    for (int e = 0; e < 8; e++) o[e] = f2bf(bf2f(a[e]) * gelu_f(bf2f(g[e])));
-    st8(y + m * F + c, o);
+    for (int e = 0; e < 8; e++) a[e] *= gelu_f(g[e]);
+    stv8<T>(y + m * F + c, a);
 }
-__global__ void geglu_bwd_kernel(const bf16* __restrict__ h, const bf16* __restrict__ dy, bf16* __restrict__ dh, size_t M, int F) {
+template <typename T>
+__global__ void geglu_bwd_kernel(const T* __restrict__ h, const T* __restrict__ dy, T* __restrict__ dh, size_t M, int F) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int F8 = F >> 3;
     if (i >= M * F8) return;
     const size_t m = i / F8; const int c = (int)(i - m * F8) * 8;
-    const bf16x8 a = ld8(h + m * 2 * F + c), g = ld8(h + m * 2 * F + F + c), d = ld8(dy + m * F + c);
-    bf16x8 da, dg;
+    float a[8], g[8], d[8], da[8], dg[8];
+    ldv8<T>(h + m * 2 * F + c, a); ldv8<T>(h + m * 2 * F + F + c, g); ldv8<T>(dy + m * F + c, d);
 #pragma unroll
     for (int e = 0; e < 8; e++) {
-        const float gf = bf2f(g[e]), df = bf2f(d[e]);
-        da[e] = f2bf(df * gelu_f(gf));
-        dg[e] = f2bf(df * bf2f(a[e]) * gelu_grad_f(gf));
+        da[e] = d[e] * gelu_f(g[e]);
+        dg[e] = d[e] * a[e] * gelu_grad_f(g[e]);
     }
-    st8(dh + m * 2 * F + c, da);
-    st8(dh + m * 2 * F + F + c, dg);
+    stv8<T>(dh + m * 2 * F + c, da);
+    stv8<T>(dh + m * 2 * F + F + c, dg);
 }
 
 // ---- channel concat / split (NHWC) ----------------------------------------------------------
 // out[m][0:C1]=a[m], out[m][C1:C1+C2]=b[m]   (split = same kernel with to_parts=1)
-__global__ void concat2_kernel(bf16* __restrict__ a, bf16* __restrict__ b, bf16* __restrict__ out, size_t M, int C1, int C2,
+template <typename T>
+__global__ void concat2_kernel(T* __restrict__ a, T* __restrict__ b, T* __restrict__ out, size_t M, int C1, int C2,
                                int to_parts) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int C8 = (C1 + C2) >> 3;
     if (i >= M * C8) return;
     const size_t m = i / C8; const int c = (int)(i - m * C8) * 8;
-    bf16* part = c < C1 ? a + m * C1 + c : b + m * C2 + (c - C1);
-    bf16* full = out + m * (C1 + C2) + c;
-    if (to_parts) st8(part, ld8(full)); else st8(full, ld8(part));
+    T* part = c < C1 ? a + m * C1 + c : b + m * C2 + (c - C1);
+    T* full = out + m * (C1 + C2) + c;
+    float v[8];
+    if (to_parts) { ldv8<T>(full, v); stv8<T>(part, v); } else { ldv8<T>(part, v); stv8<T>(full, v); }
 }
 
 // backward of nearest x2 upsample: out[b][h][w][c] = sum of the 2x2 block of g [b][2h..][2w..][c]
-__global__ void sumpool2x2_kernel(const bf16* __restrict__ g, bf16* __restrict__ out, int B, int H, int W, int C) {
+template <typename T>
+__global__ void sumpool2x2_kernel(const T* __restrict__ g, T* __restrict__ out, int B, int H, int W, int C) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int C8 = C >> 3;
     if (i >= (size_t)B * H * W * C8) return;
     const int c = (int)(i % C8) * 8; size_t r = i / C8;
     const int w = (int)(r % W); r /= W; const int h = (int)(r % H); const int b = (int)(r / H);
-    const bf16* s = g + (((size_t)b * 2 * H + 2 * h) * 2 * W + 2 * w) * C + c;
-    const bf16x8 v0 = ld8(s), v1 = ld8(s + C), v2 = ld8(s + (size_t)2 * W * C), v3 = ld8(s + (size_t)2 * W * C + C);
-    bf16x8 o;
+    const T* s = g + (((size_t)b * 2 * H + 2 * h) * 2 * W + 2 * w) * C + c;
+    float v0[8], v1[8], v2[8], v3[8];
+    ldv8<T>(s, v0); ldv8<T>(s + C, v1); ldv8<T>(s + (size_t)2 * W * C, v2); ldv8<T>(s + (size_t)2 * W * C + C, v3);
 #pragma unroll
-    for (int e = 0; e < 8; e++) o[e] = f2bf(bf2f(v0[e]) + bf2f(v1[e]) + bf2f(v2[e]) + bf2f(v3[e]));
-    st8(out + (((size_t)b * H + h) * W + w) * C + c, o);
+    for (int e = 0; e < 8; e++) v0[e] = v0[e] + v1[e] + v2[e] + v3[e];
+    stv8<T>(out + (((size_t)b * H + h) * W + w) * C + c, v0);
 }
 
 // zero insertion (backward-data of a stride-2 conv): out [B][H][W][C], out[2h][2w]=g[h][w], else 0
 // (H = 2Ho or 2Ho-1: the original input size of the strided conv)
-__global__ void zero_insert2_kernel(const bf16* __restrict__ g, bf16* __restrict__ out, int B, int Ho, int Wo, int H, int W, int C) {
+template <typename T>
+__global__ void zero_insert2_kernel(const T* __restrict__ g, T* __restrict__ out, int B, int Ho, int Wo, int H, int W, int C) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int C8 = C >> 3;
     if (i >= (size_t)B * H * W * C8) return;
     const int c = (int)(i % C8) * 8; size_t r = i / C8;
     const int w = (int)(r % W); r /= W; const int h = (int)(r % H); const int b = (int)(r / H);
-    bf16x8 v = zero8();
-    if (!(h & 1) && !(w & 1)) v = ld8(g + (((size_t)b * Ho + (h >> 1)) * Wo + (w >> 1)) * C + c);
-    st8(out + (((size_t)b * H + h) * W + w) * C + c, v);
+    float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (!(h & 1) && !(w & 1)) ldv8<T>(g + (((size_t)b * Ho + (h >> 1)) * Wo + (w >> 1)) * C + c, v);
+    stv8<T>(out + (((size_t)b * H + h) * W + w) * C + c, v);
 }
 
-__global__ void add_bf16_kernel(const bf16* __restrict__ a, const bf16* __restrict__ b, bf16* __restrict__ o, size_t n8) {
+template <typename T>
+__global__ void add_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ o, size_t n8) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n8) return;
-    const bf16x8 x = ld8(a + i * 8), y = ld8(b + i * 8);
-    bf16x8 r;
+    float x[8], y[8];
+    ldv8<T>(a + i * 8, x); ldv8<T>(b + i * 8, y);
 #pragma unroll
-    for (int e = 0; e < 8; e++) r[e] = f2bf(bf2f(x[e]) + bf2f(y[e]));
-    st8(o + i * 8, r);
+    for (int e = 0; e < 8; e++) x[e] += y[e];
+    stv8<T>(o + i * 8, x);
 }
 
 // ---- column sums of g [B][rows][N]: per_batch[b][n] += , total[n] += (fp32 atomics; callers zero per_batch) -----
 // grid (row chunks, B) fills the chip; 256 threads walk columns in passes of cpp 8-wide chunks, rows split over 256/cpp lanes.
-__global__ __launch_bounds__(256) void colsum_kernel(const bf16* __restrict__ g, float* __restrict__ per_batch,
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ g, float* __restrict__ per_batch,
                                                      float* __restrict__ total, int rows_per_batch, int N, int ldg,
                                                      int rows_per_chunk) {
     __shared__ float sm[256 * 8];
@@ -218,9 +234,10 @@ __global__ __launch_bounds__(256) void colsum_kernel(const bf16* __restrict__ g,
         float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         if (rl < rows && cc < N8)
             for (int r = r0 + rl; r < r1; r += rows) {
-                const bf16x8 v = ld8(g + ((size_t)b * rows_per_batch + r) * ldg + cc * 8);
+                float v[8];
+                ldv8<T>(g + ((size_t)b * rows_per_batch + r) * ldg + cc * 8, v);
 #pragma unroll
-                for (int e = 0; e < 8; e++) s[e] += bf2f(v[e]);
+                for (int e = 0; e < 8; e++) s[e] += v[e];
             }
         __syncthreads();
         if (rl < rows)
@@ -255,7 +272,8 @@ __global__ void cast_bf16_f32_kernel(const bf16* __restrict__ x, float* __restri
 }
 
 // dgrad weight: src fp32 [N][T][K] -> dst bf16 [K][T][N] with taps reversed (T=1: plain transpose)
-__global__ void transpose_w_kernel(const float* __restrict__ src, bf16* __restrict__ dst, int N, int K, int T) {
+template <typename D>
+__global__ void transpose_w_kernel(const float* __restrict__ src, D* __restrict__ dst, int N, int K, int T) {
     __shared__ float tile[32][33];
     const int tap = blockIdx.z;
     const int n0 = blockIdx.y * 32, k0 = blockIdx.x * 32;
@@ -267,14 +285,15 @@ __global__ void transpose_w_kernel(const float* __restrict__ src, bf16* __restri
     __syncthreads();
     for (int j = ty; j < 32; j += 8) {
         const int k = k0 + j, n = n0 + tx;
-        if (n < N && k < K) dst[((size_t)k * T + (T - 1 - tap)) * N + n] = f2bf(tile[tx][j]);
+        if (n < N && k < K) dst[((size_t)k * T + (T - 1 - tap)) * N + n] = (D)tile[tx][j];
     }
 }
 
 // Batched variant: one launch refreshes every backward-data operand of a network (~500 weights after each optimizer
 // step; launched one by one they were ~3 % of the step, launch- and tail-bound).  jobs[] is a device table sorted by
 // blk0 (first 32x32-tile index of the job); a block finds its job by binary search.  Layout = sidlsg_tw_job in the header.
-struct TwJob { const float* src; bf16* dst; int N, K, T, blk0; };
+struct TwJob { const float* src; void* dst; int N, K, T, blk0; };
+template <typename D>
 __global__ void transpose_w_batched_kernel(const TwJob* __restrict__ jobs, int njobs) {
     __shared__ float tile[32][33];
     int lo = 0, hi = njobs - 1;
@@ -296,7 +315,7 @@ __global__ void transpose_w_batched_kernel(const TwJob* __restrict__ jobs, int n
     __syncthreads();
     for (int r = ty; r < 32; r += 8) {
         const int k = k0 + r, n = n0 + tx;
-        if (n < j.N && k < j.K) j.dst[((size_t)k * j.T + (j.T - 1 - tap)) * j.N + n] = f2bf(tile[tx][r]);
+        if (n < j.N && k < j.K) reinterpret_cast<D*>(j.dst)[((size_t)k * j.T + (j.T - 1 - tap)) * j.N + n] = (D)tile[tx][r];
     }
 }
 
@@ -426,22 +445,130 @@ __global__ void bias_act_kernel(const T* __restrict__ x, const T* __restrict__ b
     }
 }
 
-extern "C" {
-
-int sidlsg_noisy_input(const float* x0, const float* noise, const float* s0, const float* s1, void* out, float* xt, int B,
-                       int C, int HW, int Cp, int dup, void* stream) {
+// ---- typed host launchers (T = activation storage type) + the two C entry-point families ----------------------------
+template <typename T>
+static int noisy_input_t(const float* x0, const float* noise, const float* s0, const float* s1, void* out, float* xt, int B,
+                         int C, int HW, int Cp, int dup, void* stream) {
     if (C > 8 || Cp % 8 || Cp < 8 || dup < 1) return SIDLSG_EINVAL;
-    hipLaunchKernelGGL(noisy_input_kernel, GRID1D((size_t)B * HW, 256), dim3(256), 0, (hipStream_t)stream, x0, noise, s0, s1,
-                       (bf16*)out, xt, B, C, HW, Cp, dup);
+    hipLaunchKernelGGL(noisy_input_kernel<T>, GRID1D((size_t)B * HW, 256), dim3(256), 0, (hipStream_t)stream, x0, noise, s0, s1,
+                       (T*)out, xt, B, C, HW, Cp, dup);
     return sidlsg_last_error();
 }
-int sidlsg_noisy_input_bwd(const void* g, const float* s0, float* dx0, int B, int C, int HW, int Cp, int dup, int accumulate,
-                           void* stream) {
+template <typename T>
+static int noisy_input_bwd_t(const void* g, const float* s0, float* dx0, int B, int C, int HW, int Cp, int dup, int accumulate,
+                             void* stream) {
     if (C > 8 || Cp % 8) return SIDLSG_EINVAL;
-    hipLaunchKernelGGL(noisy_input_bwd_kernel, GRID1D((size_t)B * HW, 256), dim3(256), 0, (hipStream_t)stream, (const bf16*)g,
+    hipLaunchKernelGGL(noisy_input_bwd_kernel<T>, GRID1D((size_t)B * HW, 256), dim3(256), 0, (hipStream_t)stream, (const T*)g,
                        s0, dx0, B, C, HW, Cp, dup, accumulate);
     return sidlsg_last_error();
 }
+template <typename T>
+static int cfg_x0_bwd_t(const float* g, const float* s0, const float* s1, void* deps, float* dxt, int B, int C, int HW, int Cp,
+                        int dup, float kappa, int predict_x0, void* stream) {
+    if (C > 8 || Cp % 8) return SIDLSG_EINVAL;
+    hipLaunchKernelGGL(cfg_x0_bwd_kernel<T>, GRID1D((size_t)B * HW, 256), dim3(256), 0, (hipStream_t)stream, g, s0, s1,
+                       (T*)deps, dxt, B, C, HW, Cp, dup, kappa, predict_x0);
+    return sidlsg_last_error();
+}
+template <typename T>
+static int timestep_embed_t(const long long* t, void* out, int B, int dim, void* stream) {
+    hipLaunchKernelGGL(timestep_embed_kernel<T>, GRID1D((size_t)B * (dim / 2), 256), dim3(256), 0, (hipStream_t)stream, t,
+                       (T*)out, B, dim);
+    return sidlsg_last_error();
+}
+template <typename T>
+static int silu_fwd_t(const void* x, void* y, long long n, void* stream) {
+    if (n % 8) return SIDLSG_EINVAL;
+    hipLaunchKernelGGL(silu_fwd_kernel<T>, GRID1D(n / 8, 256), dim3(256), 0, (hipStream_t)stream, (const T*)x, (T*)y, (size_t)n / 8);
+    return sidlsg_last_error();
+}
+template <typename T>
+static int silu_bwd_t(const void* x, const void* dy, void* dx, long long n, void* stream) {
+    if (n % 8) return SIDLSG_EINVAL;
+    hipLaunchKernelGGL(silu_bwd_kernel<T>, GRID1D(n / 8, 256), dim3(256), 0, (hipStream_t)stream, (const T*)x, (const T*)dy,
+                       (T*)dx, (size_t)n / 8);
+    return sidlsg_last_error();
+}
+template <typename T>
+static int geglu_fwd_t(const void* h, void* y, long long M, int F, void* stream) {
+    if (F % 8) return SIDLSG_EINVAL;
+    hipLaunchKernelGGL(geglu_fwd_kernel<T>, GRID1D((size_t)M * (F / 8), 256), dim3(256), 0, (hipStream_t)stream, (const T*)h,
+                       (T*)y, (size_t)M, F);
+    return sidlsg_last_error();
+}
+template <typename T>
+static int geglu_bwd_t(const void* h, const void* dy, void* dh, long long M, int F, void* stream) {
+    if (F % 8) return SIDLSG_EINVAL;
+    hipLaunchKernelGGL(geglu_bwd_kernel<T>, GRID1D((size_t)M * (F / 8), 256), dim3(256), 0, (hipStream_t)stream, (const T*)h,
+                       (const T*)dy, (T*)dh, (size_t)M, F);
+    return sidlsg_last_error();
+}
+template <typename T>
+static int concat2_t(void* a, void* b, void* out, long long M, int C1, int C2, int to_parts, void* stream) {
+    if (C1 % 8 || C2 % 8) return SIDLSG_EINVAL;
+    hipLaunchKernelGGL(concat2_kernel<T>, GRID1D((size_t)M * ((C1 + C2) / 8), 256), dim3(256), 0, (hipStream_t)stream, (T*)a,
+                       (T*)b, (T*)out, (size_t)M, C1, C2, to_parts);
+    return sidlsg_last_error();
+}
+template <typename T>
+static int sumpool2x2_t(const void* g, void* out, int B, int H, int W, int C, void* stream) {
+    if (C % 8) return SIDLSG_EINVAL;
+    hipLaunchKernelGGL(sumpool2x2_kernel<T>, GRID1D((size_t)B * H * W * (C / 8), 256), dim3(256), 0, (hipStream_t)stream,
+                       (const T*)g, (T*)out, B, H, W, C);
+    return sidlsg_last_error();
+}
+template <typename T>
+static int zero_insert2_t(const void* g, void* out, int B, int Ho, int Wo, int H, int W, int C, void* stream) {
+    if (C % 8 || (H + 1) / 2 != Ho || (W + 1) / 2 != Wo) return SIDLSG_EINVAL;
+    hipLaunchKernelGGL(zero_insert2_kernel<T>, GRID1D((size_t)B * H * W * (C / 8), 256), dim3(256), 0, (hipStream_t)stream,
+                       (const T*)g, (T*)out, B, Ho, Wo, H, W, C);
+    return sidlsg_last_error();
+}
+template <typename T>
+static int add_t(const void* a, const void* b, void* o, long long n, void* stream) {
+    if (n % 8) return SIDLSG_EINVAL;
+    hipLaunchKernelGGL(add_kernel<T>, GRID1D(n / 8, 256), dim3(256), 0, (hipStream_t)stream, (const T*)a, (const T*)b,
+                       (T*)o, (size_t)n / 8);
+    return sidlsg_last_error();
+}
+static int colsum_nchunks(int B, int rows_per_batch) {
+    int want = (512 + B - 1) / B; int maxch = (rows_per_batch + 63) / 64;
+    int nch = want < maxch ? want : maxch; if (nch < 1) nch = 1; if (nch > 128) nch = 128; return nch;
+}
+template <typename T>
+static int colsum_t(const void* g, int ldg, float* per_batch, float* total, int B, int rows_per_batch, int N, void* stream) {
+    if (N % 8 || N <= 0) return SIDLSG_EINVAL;
+    const int nch = colsum_nchunks(B, rows_per_batch);
+    const int rpc = (rows_per_batch + nch - 1) / nch;
+    hipLaunchKernelGGL(colsum_kernel<T>, dim3(nch, B), dim3(256), 0, (hipStream_t)stream, (const T*)g, per_batch, total,
+                       rows_per_batch, N, ldg, rpc);
+    return sidlsg_last_error();
+}
+template <typename D>
+static int transpose_w_t(const float* src, void* dst, int N, int K, int T, void* stream) {
+    hipLaunchKernelGGL(transpose_w_kernel<D>, dim3((K + 31) / 32, (N + 31) / 32, T), dim3(256), 0, (hipStream_t)stream, src,
+                       (D*)dst, N, K, T);
+    return sidlsg_last_error();
+}
+template <typename D>
+static int transpose_w_batched_t(const void* jobs, int njobs, int nblocks, void* stream) {
+    if (!jobs || njobs <= 0 || nblocks <= 0) return SIDLSG_EINVAL;
+    hipLaunchKernelGGL(transpose_w_batched_kernel<D>, dim3(nblocks), dim3(256), 0, (hipStream_t)stream, (const TwJob*)jobs, njobs);
+    return sidlsg_last_error();
+}
+
+extern "C" {
+
+#define SIDLSG_BOTH(name, tmpl, params, args) \
+    int name params { return tmpl<bf16> args; }  \
+    int name##_f32 params { return tmpl<float> args; }
+
+SIDLSG_BOTH(sidlsg_noisy_input, noisy_input_t,
+            (const float* x0, const float* noise, const float* s0, const float* s1, void* out, float* xt, int B, int C, int HW, int Cp, int dup, void* stream),
+            (x0, noise, s0, s1, out, xt, B, C, HW, Cp, dup, stream))
+SIDLSG_BOTH(sidlsg_noisy_input_bwd, noisy_input_bwd_t,
+            (const void* g, const float* s0, float* dx0, int B, int C, int HW, int Cp, int dup, int accumulate, void* stream),
+            (g, s0, dx0, B, C, HW, Cp, dup, accumulate, stream))
 int sidlsg_cfg_x0(const float* eps, const float* xt, const float* s0, const float* s1, float* out, int B, int C, int HW,
                   int Ce, int dup, float kappa, int predict_x0, void* stream) {
     if (Ce < C) return SIDLSG_EINVAL;
@@ -449,80 +576,30 @@ int sidlsg_cfg_x0(const float* eps, const float* xt, const float* s0, const floa
                        C, HW, Ce, dup, kappa, predict_x0);
     return sidlsg_last_error();
 }
-int sidlsg_cfg_x0_bwd(const float* g, const float* s0, const float* s1, void* deps, float* dxt, int B, int C, int HW, int Cp,
-                      int dup, float kappa, int predict_x0, void* stream) {
-    if (C > 8 || Cp % 8) return SIDLSG_EINVAL;
-    hipLaunchKernelGGL(cfg_x0_bwd_kernel, GRID1D((size_t)B * HW, 256), dim3(256), 0, (hipStream_t)stream, g, s0, s1,
-                       (bf16*)deps, dxt, B, C, HW, Cp, dup, kappa, predict_x0);
-    return sidlsg_last_error();
+SIDLSG_BOTH(sidlsg_cfg_x0_bwd, cfg_x0_bwd_t,
+            (const float* g, const float* s0, const float* s1, void* deps, float* dxt, int B, int C, int HW, int Cp, int dup, float kappa, int predict_x0, void* stream),
+            (g, s0, s1, deps, dxt, B, C, HW, Cp, dup, kappa, predict_x0, stream))
+SIDLSG_BOTH(sidlsg_timestep_embed, timestep_embed_t, (const long long* t, void* out, int B, int dim, void* stream), (t, out, B, dim, stream))
+SIDLSG_BOTH(sidlsg_silu_fwd, silu_fwd_t, (const void* x, void* y, long long n, void* stream), (x, y, n, stream))
+SIDLSG_BOTH(sidlsg_silu_bwd, silu_bwd_t, (const void* x, const void* dy, void* dx, long long n, void* stream), (x, dy, dx, n, stream))
+SIDLSG_BOTH(sidlsg_geglu_fwd, geglu_fwd_t, (const void* h, void* y, long long M, int F, void* stream), (h, y, M, F, stream))
+SIDLSG_BOTH(sidlsg_geglu_bwd, geglu_bwd_t, (const void* h, const void* dy, void* dh, long long M, int F, void* stream), (h, dy, dh, M, F, stream))
+SIDLSG_BOTH(sidlsg_concat2, concat2_t, (void* a, void* b, void* out, long long M, int C1, int C2, int to_parts, void* stream),
+            (a, b, out, M, C1, C2, to_parts, stream))
+SIDLSG_BOTH(sidlsg_sumpool2x2, sumpool2x2_t, (const void* g, void* out, int B, int H, int W, int C, void* stream), (g, out, B, H, W, C, stream))
+SIDLSG_BOTH(sidlsg_zero_insert2, zero_insert2_t, (const void* g, void* out, int B, int Ho, int Wo, int H, int W, int C, void* stream),
+            (g, out, B, Ho, Wo, H, W, C, stream))
+int sidlsg_add_bf16(const void* a, const void* b, void* o, long long n, void* stream) { return add_t<bf16>(a, b, o, n, stream); }
+int sidlsg_add_f32(const void* a, const void* b, void* o, long long n, void* stream) { return add_t<float>(a, b, o, n, stream); }
+// column sums of g [B][rows_per_batch][N] (row stride ldg): per_batch [B][N] (+=, zero it first) and/or total [N] (+=); ws unused
+int sidlsg_colsum_nchunks(int B, int rows_per_batch) { return colsum_nchunks(B, rows_per_batch); }
+int sidlsg_colsum(const void* g, int ldg, float* per_batch, float* total, float* ws, int B, int rows_per_batch, int N, void* stream) {
+    (void)ws;   // kept in the ABI; the reduction is single-pass with atomics
+    return colsum_t<bf16>(g, ldg, per_batch, total, B, rows_per_batch, N, stream);
 }
-int sidlsg_timestep_embed(const long long* t, void* out, int B, int dim, void* stream) {
-    hipLaunchKernelGGL(timestep_embed_kernel, GRID1D((size_t)B * (dim / 2), 256), dim3(256), 0, (hipStream_t)stream, t,
-                       (bf16*)out, B, dim);
-    return sidlsg_last_error();
-}
-int sidlsg_silu_fwd(const void* x, void* y, long long n, void* stream) {
-    if (n % 8) return SIDLSG_EINVAL;
-    hipLaunchKernelGGL(silu_fwd_kernel, GRID1D(n / 8, 256), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, (bf16*)y, (size_t)n / 8);
-    return sidlsg_last_error();
-}
-int sidlsg_silu_bwd(const void* x, const void* dy, void* dx, long long n, void* stream) {
-    if (n % 8) return SIDLSG_EINVAL;
-    hipLaunchKernelGGL(silu_bwd_kernel, GRID1D(n / 8, 256), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, (const bf16*)dy,
-                       (bf16*)dx, (size_t)n / 8);
-    return sidlsg_last_error();
-}
-int sidlsg_geglu_fwd(const void* h, void* y, long long M, int F, void* stream) {
-    if (F % 8) return SIDLSG_EINVAL;
-    hipLaunchKernelGGL(geglu_fwd_kernel, GRID1D((size_t)M * (F / 8), 256), dim3(256), 0, (hipStream_t)stream, (const bf16*)h,
-                       (bf16*)y, (size_t)M, F);
-    return sidlsg_last_error();
-}
-int sidlsg_geglu_bwd(const void* h, const void* dy, void* dh, long long M, int F, void* stream) {
-    if (F % 8) return SIDLSG_EINVAL;
-    hipLaunchKernelGGL(geglu_bwd_kernel, GRID1D((size_t)M * (F / 8), 256), dim3(256), 0, (hipStream_t)stream, (const bf16*)h,
-                       (const bf16*)dy, (bf16*)dh, (size_t)M, F);
-    return sidlsg_last_error();
-}
-int sidlsg_concat2(void* a, void* b, void* out, long long M, int C1, int C2, int to_parts, void* stream) {
-    if (C1 % 8 || C2 % 8) return SIDLSG_EINVAL;
-    hipLaunchKernelGGL(concat2_kernel, GRID1D((size_t)M * ((C1 + C2) / 8), 256), dim3(256), 0, (hipStream_t)stream, (bf16*)a,
-                       (bf16*)b, (bf16*)out, (size_t)M, C1, C2, to_parts);
-    return sidlsg_last_error();
-}
-int sidlsg_sumpool2x2(const void* g, void* out, int B, int H, int W, int C, void* stream) {
-    if (C % 8) return SIDLSG_EINVAL;
-    hipLaunchKernelGGL(sumpool2x2_kernel, GRID1D((size_t)B * H * W * (C / 8), 256), dim3(256), 0, (hipStream_t)stream,
-                       (const bf16*)g, (bf16*)out, B, H, W, C);
-    return sidlsg_last_error();
-}
-int sidlsg_zero_insert2(const void* g, void* out, int B, int Ho, int Wo, int H, int W, int C, void* stream) {
-    if (C % 8 || (H + 1) / 2 != Ho || (W + 1) / 2 != Wo) return SIDLSG_EINVAL;
-    hipLaunchKernelGGL(zero_insert2_kernel, GRID1D((size_t)B * H * W * (C / 8), 256), dim3(256), 0, (hipStream_t)stream,
-                       (const bf16*)g, (bf16*)out, B, Ho, Wo, H, W, C);
-    return sidlsg_last_error();
-}
-int sidlsg_add_bf16(const void* a, const void* b, void* o, long long n, void* stream) {
-    if (n % 8) return SIDLSG_EINVAL;
-    hipLaunchKernelGGL(add_bf16_kernel, GRID1D(n / 8, 256), dim3(256), 0, (hipStream_t)stream, (const bf16*)a, (const bf16*)b,
-                       (bf16*)o, (size_t)n / 8);
-    return sidlsg_last_error();
-}
-// column sums of g [B][rows_per_batch][N] (row stride ldg): per_batch [B][N] (=) and/or total [N] (+=).
-// ws: B * nch * N floats, nch = sidlsg_colsum_nchunks(...)
-int sidlsg_colsum_nchunks(int B, int rows_per_batch) {
-    int want = (512 + B - 1) / B; int maxch = (rows_per_batch + 63) / 64;
-    int nch = want < maxch ? want : maxch; if (nch < 1) nch = 1; if (nch > 128) nch = 128; return nch;
-}
-int sidlsg_colsum(const void* g, int ldg, float* per_batch, float* total, float* ws, int B, int rows_per_batch, int N,
-                  void* stream) {
-    (void)ws;   // kept in the ABI; the reduction is single-pass with atomics (per_batch must be zeroed by the caller)
-    if (N % 8 || N <= 0) return SIDLSG_EINVAL;
-    const int nch = sidlsg_colsum_nchunks(B, rows_per_batch);
-    const int rpc = (rows_per_batch + nch - 1) / nch;
-    hipLaunchKernelGGL(colsum_kernel, dim3(nch, B), dim3(256), 0, (hipStream_t)stream, (const bf16*)g, per_batch, total,
-                       rows_per_batch, N, ldg, rpc);
-    return sidlsg_last_error();
+int sidlsg_colsum_f32(const void* g, int ldg, float* per_batch, float* total, float* ws, int B, int rows_per_batch, int N, void* stream) {
+    (void)ws;
+    return colsum_t<float>(g, ldg, per_batch, total, B, rows_per_batch, N, stream);
 }
 int sidlsg_cast_f32_bf16(const float* x, void* y, long long n, void* stream) {
     hipLaunchKernelGGL(cast_f32_bf16_kernel, GRID1D((n + 7) / 8, 256), dim3(256), 0, (hipStream_t)stream, x, (bf16*)y, (size_t)n);
@@ -532,17 +609,9 @@ int sidlsg_cast_bf16_f32(const void* x, float* y, long long n, void* stream) {
     hipLaunchKernelGGL(cast_bf16_f32_kernel, GRID1D(n, 256), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, y, (size_t)n);
     return sidlsg_last_error();
 }
-// src fp32 [N][T][K] -> dst bf16 [K][T][N], taps reversed
-int sidlsg_transpose_w_batched(const void* jobs, int njobs, int nblocks, void* stream) {
-    if (!jobs || njobs <= 0 || nblocks <= 0) return SIDLSG_EINVAL;
-    hipLaunchKernelGGL(transpose_w_batched_kernel, dim3(nblocks), dim3(256), 0, (hipStream_t)stream, (const TwJob*)jobs, njobs);
-    return sidlsg_last_error();
-}
-int sidlsg_transpose_w(const float* src, void* dst, int N, int K, int T, void* stream) {
-    hipLaunchKernelGGL(transpose_w_kernel, dim3((K + 31) / 32, (N + 31) / 32, T), dim3(256), 0, (hipStream_t)stream, src,
-                       (bf16*)dst, N, K, T);
-    return sidlsg_last_error();
-}
+// src fp32 [N][T][K] -> dst [K][T][N], taps reversed (bf16, or fp32 for the _f32 family)
+SIDLSG_BOTH(sidlsg_transpose_w, transpose_w_t, (const float* src, void* dst, int N, int K, int T, void* stream), (src, dst, N, K, T, stream))
+SIDLSG_BOTH(sidlsg_transpose_w_batched, transpose_w_batched_t, (const void* jobs, int njobs, int nblocks, void* stream), (jobs, njobs, nblocks, stream))
 // Generator loss (A7).  x,yr,yf: [S][n] fp32.  ws: >= S*2 + S*GB floats.  loss[0] = value (already * scale).
 #define SID_GB 8
 int sidlsg_g_loss(const float* x, const float* yr, const float* yf, float* dx, float* dyr, float* dyf, float* loss, float* ws,

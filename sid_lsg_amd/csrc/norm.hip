@@ -25,7 +25,8 @@ struct GnGeom {
     int C, HW, G, cpg, C8, rows, nch, ppb;  // ppb: pixels per block (chunk)
 };
 
-__global__ void gn_stats_kernel(const bf16* __restrict__ x, float* __restrict__ part, GnGeom g) {
+template <typename T>
+__global__ void gn_stats_kernel(const T* __restrict__ x, float* __restrict__ part, GnGeom g) {
     extern __shared__ float sm[];  // [rows][C][2]
     const int b = blockIdx.y, chunk = blockIdx.x;
     const int cc = threadIdx.x % g.C8, rl = threadIdx.x / g.C8;
@@ -33,21 +34,22 @@ __global__ void gn_stats_kernel(const bf16* __restrict__ x, float* __restrict__ 
     float s[8], q[8];
 #pragma unroll
     for (int e = 0; e < 8; e++) s[e] = q[e] = 0.f;
-    const bf16* xb = x + (size_t)b * g.HW * g.C + cc * 8;
+    const T* xb = x + (size_t)b * g.HW * g.C + cc * 8;
     int p = p0 + rl;
     for (; p + 3 * g.rows < p1; p += 4 * g.rows) {        // 4 independent 16-byte loads in flight per thread
-        bf16x8 v[4];
+        float v[4][8];
 #pragma unroll
-        for (int u = 0; u < 4; u++) v[u] = ld8(xb + (size_t)(p + u * g.rows) * g.C);
+        for (int u = 0; u < 4; u++) ldv8<T>(xb + (size_t)(p + u * g.rows) * g.C, v[u]);
 #pragma unroll
         for (int u = 0; u < 4; u++)
 #pragma unroll
-            for (int e = 0; e < 8; e++) { const float f = bf2f(v[u][e]); s[e] += f; q[e] += f * f; }
+            for (int e = 0; e < 8; e++) { const float f = v[u][e]; s[e] += f; q[e] += f * f; }
     }
     for (; p < p1; p += g.rows) {
-        const bf16x8 v = ld8(xb + (size_t)p * g.C);
+        float v[8];
+        ldv8<T>(xb + (size_t)p * g.C, v);
 #pragma unroll
-        for (int e = 0; e < 8; e++) { const float f = bf2f(v[e]); s[e] += f; q[e] += f * f; }
+        for (int e = 0; e < 8; e++) { const float f = v[e]; s[e] += f; q[e] += f * f; }
     }
     float* row = sm + (size_t)rl * g.C * 2;
 #pragma unroll
@@ -65,9 +67,10 @@ __global__ void gn_stats_kernel(const bf16* __restrict__ x, float* __restrict__ 
     }
 }
 
-__global__ void gn_apply_kernel(const bf16* __restrict__ x, const float* __restrict__ part,
+template <typename T>
+__global__ void gn_apply_kernel(const T* __restrict__ x, const float* __restrict__ part,
                                 const float* __restrict__ gamma, const float* __restrict__ beta,
-                                bf16* __restrict__ y, float* __restrict__ stats, GnGeom g, float eps, int act) {
+                                T* __restrict__ y, float* __restrict__ stats, GnGeom g, float eps, int act) {
     extern __shared__ float sm[];  // mean[G], rstd[G]
     const int b = blockIdx.y, chunk = blockIdx.x;
     for (int grp = threadIdx.x; grp < g.G; grp += blockDim.x) {
@@ -96,35 +99,35 @@ __global__ void gn_apply_kernel(const bf16* __restrict__ x, const float* __restr
     const size_t base = (size_t)b * g.HW * g.C + cc * 8;
     int p = p0 + rl;
     for (; p + 3 * g.rows < p1; p += 4 * g.rows) {
-        bf16x8 v[4];
+        float v[4][8];
 #pragma unroll
-        for (int u = 0; u < 4; u++) v[u] = ld8(x + base + (size_t)(p + u * g.rows) * g.C);
+        for (int u = 0; u < 4; u++) ldv8<T>(x + base + (size_t)(p + u * g.rows) * g.C, v[u]);
 #pragma unroll
         for (int u = 0; u < 4; u++) {
-            bf16x8 o;
 #pragma unroll
             for (int e = 0; e < 8; e++) {
-                float f = bf2f(v[u][e]) * sc[e] + sh[e];
+                float f = v[u][e] * sc[e] + sh[e];
                 if (act) f = silu_f(f);
-                o[e] = f2bf(f);
+                v[u][e] = f;
             }
-            st8(y + base + (size_t)(p + u * g.rows) * g.C, o);
+            stv8<T>(y + base + (size_t)(p + u * g.rows) * g.C, v[u]);
         }
     }
     for (; p < p1; p += g.rows) {
-        const bf16x8 v = ld8(x + base + (size_t)p * g.C);
-        bf16x8 o;
+        float v[8];
+        ldv8<T>(x + base + (size_t)p * g.C, v);
 #pragma unroll
         for (int e = 0; e < 8; e++) {
-            float f = bf2f(v[e]) * sc[e] + sh[e];
+            float f = v[e] * sc[e] + sh[e];
             if (act) f = silu_f(f);
-            o[e] = f2bf(f);
+            v[e] = f;
         }
-        st8(y + base + (size_t)p * g.C, o);
+        stv8<T>(y + base + (size_t)p * g.C, v);
     }
 }
 
-__global__ void gn_bwd_stats_kernel(const bf16* __restrict__ x, const bf16* __restrict__ dy,
+template <typename T>
+__global__ void gn_bwd_stats_kernel(const T* __restrict__ x, const T* __restrict__ dy,
                                     const float* __restrict__ stats, const float* __restrict__ gamma,
                                     const float* __restrict__ beta, float* __restrict__ part, GnGeom g, int act) {
     extern __shared__ float sm[];  // [rows][C][2]
@@ -141,25 +144,26 @@ __global__ void gn_bwd_stats_kernel(const bf16* __restrict__ x, const bf16* __re
     const size_t base = (size_t)b * g.HW * g.C + cc * 8;
     int p = p0 + rl;
     for (; p + g.rows < p1; p += 2 * g.rows) {            // 4 independent loads (2 pixels x {x, dy}) in flight
-        bf16x8 xv[2], dv[2];
+        float xv[2][8], dv[2][8];
 #pragma unroll
-        for (int u = 0; u < 2; u++) { xv[u] = ld8(x + base + (size_t)(p + u * g.rows) * g.C); dv[u] = ld8(dy + base + (size_t)(p + u * g.rows) * g.C); }
+        for (int u = 0; u < 2; u++) { ldv8<T>(x + base + (size_t)(p + u * g.rows) * g.C, xv[u]); ldv8<T>(dy + base + (size_t)(p + u * g.rows) * g.C, dv[u]); }
 #pragma unroll
         for (int u = 0; u < 2; u++)
 #pragma unroll
             for (int e = 0; e < 8; e++) {
-                const float xh = (bf2f(xv[u][e]) - mu[e]) * rs[e];
-                float d = bf2f(dv[u][e]);
+                const float xh = (xv[u][e] - mu[e]) * rs[e];
+                float d = dv[u][e];
                 if (act) d *= silu_grad_f(xh * ga[e] + be[e]);
                 a[e] += d * xh; c[e] += d;
             }
     }
     for (; p < p1; p += g.rows) {
-        const bf16x8 xv = ld8(x + base + (size_t)p * g.C), dv = ld8(dy + base + (size_t)p * g.C);
+        float xv[8], dv[8];
+        ldv8<T>(x + base + (size_t)p * g.C, xv); ldv8<T>(dy + base + (size_t)p * g.C, dv);
 #pragma unroll
         for (int e = 0; e < 8; e++) {
-            const float xh = (bf2f(xv[e]) - mu[e]) * rs[e];
-            float d = bf2f(dv[e]);
+            const float xh = (xv[e] - mu[e]) * rs[e];
+            float d = dv[e];
             if (act) d *= silu_grad_f(xh * ga[e] + be[e]);
             a[e] += d * xh; c[e] += d;
         }
@@ -185,10 +189,11 @@ __global__ void gn_bwd_stats_kernel(const bf16* __restrict__ x, const bf16* __re
     }
 }
 
-__global__ void gn_bwd_apply_kernel(const bf16* __restrict__ x, const bf16* __restrict__ dy,
+template <typename T>
+__global__ void gn_bwd_apply_kernel(const T* __restrict__ x, const T* __restrict__ dy,
                                     const float* __restrict__ stats, const float* __restrict__ gamma,
                                     const float* __restrict__ beta, const float* __restrict__ part,
-                                    const bf16* __restrict__ add, bf16* __restrict__ dx, GnGeom g, int act) {
+                                    const T* __restrict__ add, T* __restrict__ dx, GnGeom g, int act) {
     // add (may be null): gradient arriving at x through its OTHER consumer (residual / shortcut branch); summed here
     // instead of in a separate elementwise kernel
     extern __shared__ float sm[];  // s1[G], s2[G]
@@ -216,35 +221,35 @@ __global__ void gn_bwd_apply_kernel(const bf16* __restrict__ x, const bf16* __re
     const size_t base = (size_t)b * g.HW * g.C + cc * 8;
     int p = p0 + rl;
     for (; p + g.rows < p1; p += 2 * g.rows) {
-        bf16x8 xv[2], dv[2];
+        float xv[2][8], dv[2][8];
 #pragma unroll
-        for (int u = 0; u < 2; u++) { xv[u] = ld8(x + base + (size_t)(p + u * g.rows) * g.C); dv[u] = ld8(dy + base + (size_t)(p + u * g.rows) * g.C); }
+        for (int u = 0; u < 2; u++) { ldv8<T>(x + base + (size_t)(p + u * g.rows) * g.C, xv[u]); ldv8<T>(dy + base + (size_t)(p + u * g.rows) * g.C, dv[u]); }
 #pragma unroll
         for (int u = 0; u < 2; u++) {
-            bf16x8 o, av = zero8();
-            if (add) av = ld8(add + base + (size_t)(p + u * g.rows) * g.C);
+            float o[8], av[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (add) ldv8<T>(add + base + (size_t)(p + u * g.rows) * g.C, av);
 #pragma unroll
             for (int e = 0; e < 8; e++) {
-                const float xh = (bf2f(xv[u][e]) - mu[e]) * rs[e];
-                float d = bf2f(dv[u][e]);
+                const float xh = (xv[u][e] - mu[e]) * rs[e];
+                float d = dv[u][e];
                 if (act) d *= silu_grad_f(xh * ga[e] + be[e]);
-                o[e] = f2bf(rs[e] * (d * ga[e] - m1[e] - xh * m2[e]) + bf2f(av[e]));
+                o[e] = rs[e] * (d * ga[e] - m1[e] - xh * m2[e]) + av[e];
             }
-            st8(dx + base + (size_t)(p + u * g.rows) * g.C, o);
+            stv8<T>(dx + base + (size_t)(p + u * g.rows) * g.C, o);
         }
     }
     for (; p < p1; p += g.rows) {
-        const bf16x8 xv = ld8(x + base + (size_t)p * g.C), dv = ld8(dy + base + (size_t)p * g.C);
-        bf16x8 o, av = zero8();
-        if (add) av = ld8(add + base + (size_t)p * g.C);
+        float xv[8], dv[8], o[8], av[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        ldv8<T>(x + base + (size_t)p * g.C, xv); ldv8<T>(dy + base + (size_t)p * g.C, dv);
+        if (add) ldv8<T>(add + base + (size_t)p * g.C, av);
 #pragma unroll
         for (int e = 0; e < 8; e++) {
-            const float xh = (bf2f(xv[e]) - mu[e]) * rs[e];
-            float d = bf2f(dv[e]);
+            const float xh = (xv[e] - mu[e]) * rs[e];
+            float d = dv[e];
             if (act) d *= silu_grad_f(xh * ga[e] + be[e]);
-            o[e] = f2bf(rs[e] * (d * ga[e] - m1[e] - xh * m2[e]) + bf2f(av[e]));
+            o[e] = rs[e] * (d * ga[e] - m1[e] - xh * m2[e]) + av[e];
         }
-        st8(dx + base + (size_t)p * g.C, o);
+        stv8<T>(dx + base + (size_t)p * g.C, o);
     }
 }
 
@@ -274,9 +279,9 @@ static dim3 reduce_grid(int n, int P) {
 // the first reduction).  (The generic 4-chunk version held 160 VGPRs and one row per wave in flight: 2.8 TB/s.)
 constexpr int LN_MAXCH = 4;   // chunks of 8 per lane -> C <= 2048
 
-template <int NCH, int R>
-__global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16* __restrict__ x, const float* __restrict__ gamma,
-                                                     const float* __restrict__ beta, bf16* __restrict__ y,
+template <typename T, int NCH, int R>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, T* __restrict__ y,
                                                      float* __restrict__ stats, int rows, int C, float eps, int rpw) {
     const int lane = threadIdx.x & 63;
     const int C8 = C >> 3;
@@ -292,13 +297,17 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16* __restrict__ x,
     }
     const float invC = 1.0f / (float)C;
     for (int r0 = rbeg; r0 < rend; r0 += R) {
-        bf16x8 v[R][NCH];
+        float v[R][NCH][8];
 #pragma unroll
         for (int r = 0; r < R; r++)
 #pragma unroll
             for (int i = 0; i < NCH; i++) {
                 const int cc = lane + 64 * i;
-                v[r][i] = (r0 + r < rend && cc < C8) ? ld8(x + (size_t)(r0 + r) * C + cc * 8) : zero8();
+                if (r0 + r < rend && cc < C8) ldv8<T>(x + (size_t)(r0 + r) * C + cc * 8, v[r][i]);
+                else {
+#pragma unroll
+                    for (int e = 0; e < 8; e++) v[r][i][e] = 0.f;
+                }
             }
         float mean[R], rstd[R];
 #pragma unroll
@@ -307,7 +316,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16* __restrict__ x,
 #pragma unroll
             for (int i = 0; i < NCH; i++)
 #pragma unroll
-                for (int e = 0; e < 8; e++) t += bf2f(v[r][i][e]);
+                for (int e = 0; e < 8; e++) t += v[r][i][e];
             mean[r] = t;
         }
 #pragma unroll
@@ -320,7 +329,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16* __restrict__ x,
                 const int cc = lane + 64 * i;
                 if (cc < C8) {
 #pragma unroll
-                    for (int e = 0; e < 8; e++) { const float d = bf2f(v[r][i][e]) - mean[r]; q += d * d; }
+                    for (int e = 0; e < 8; e++) { const float d = v[r][i][e] - mean[r]; q += d * d; }
                 }
             }
             rstd[r] = q;
@@ -336,10 +345,10 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16* __restrict__ x,
             for (int i = 0; i < NCH; i++) {
                 const int cc = lane + 64 * i;
                 if (cc < C8) {
-                    bf16x8 o;
+                    float o[8];
 #pragma unroll
-                    for (int e = 0; e < 8; e++) o[e] = f2bf((bf2f(v[r][i][e]) - mean[r]) * rstd[r] * ga[i][e] + be[i][e]);
-                    st8(y + (size_t)row * C + cc * 8, o);
+                    for (int e = 0; e < 8; e++) o[e] = (v[r][i][e] - mean[r]) * rstd[r] * ga[i][e] + be[i][e];
+                    stv8<T>(y + (size_t)row * C + cc * 8, o);
                 }
             }
         }
@@ -347,10 +356,10 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16* __restrict__ x,
 }
 
 // dx = rstd*(dy*gamma - mean(dy*gamma) - xhat*mean(dy*gamma*xhat)); per-block partial dgamma/dbeta.
-template <int NCH, int R>
-__global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* __restrict__ x, const bf16* __restrict__ dy,
+template <typename T, int NCH, int R>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy,
                                                      const float* __restrict__ stats, const float* __restrict__ gamma,
-                                                     const bf16* __restrict__ add, bf16* __restrict__ dx,
+                                                     const T* __restrict__ add, T* __restrict__ dx,
                                                      float* __restrict__ part, int rows, int C, int rows_per_block) {
     extern __shared__ float dyn[];  // [4 waves][C][2] for the param-grad partials
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -367,7 +376,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* __restrict__ x,
     const float invC = 1.0f / (float)C;
     const int rbeg = blockIdx.x * rows_per_block, rend = min(rows, rbeg + rows_per_block);
     for (int r0 = rbeg + wave * R; r0 < rend; r0 += 4 * R) {
-        bf16x8 xv[R][NCH], dv[R][NCH];
+        float xv[R][NCH][8], dv[R][NCH][8];
         float mean[R], rstd[R];
 #pragma unroll
         for (int r = 0; r < R; r++) {
@@ -378,8 +387,11 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* __restrict__ x,
             for (int i = 0; i < NCH; i++) {
                 const int cc = lane + 64 * i;
                 const bool okc = ok && cc < C8;
-                xv[r][i] = okc ? ld8(x + (size_t)(r0 + r) * C + cc * 8) : zero8();
-                dv[r][i] = okc ? ld8(dy + (size_t)(r0 + r) * C + cc * 8) : zero8();
+                if (okc) { ldv8<T>(x + (size_t)(r0 + r) * C + cc * 8, xv[r][i]); ldv8<T>(dy + (size_t)(r0 + r) * C + cc * 8, dv[r][i]); }
+                else {
+#pragma unroll
+                    for (int e = 0; e < 8; e++) xv[r][i][e] = dv[r][i][e] = 0.f;
+                }
             }
         }
         float s1[R], s2[R];
@@ -390,8 +402,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* __restrict__ x,
             for (int i = 0; i < NCH; i++)
 #pragma unroll
                 for (int e = 0; e < 8; e++) {
-                    const float xh = (bf2f(xv[r][i][e]) - mean[r]) * rstd[r];     // zero rows: mean = rstd = 0 -> xh = 0
-                    const float d = bf2f(dv[r][i][e]);
+                    const float xh = (xv[r][i][e] - mean[r]) * rstd[r];     // zero rows: mean = rstd = 0 -> xh = 0
+                    const float d = dv[r][i][e];
                     pg[i][e] += d * xh; pb[i][e] += d;
                     const float dg = d * ga[i][e];
                     a += dg; c += dg * xh;
@@ -408,14 +420,14 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* __restrict__ x,
             for (int i = 0; i < NCH; i++) {
                 const int cc = lane + 64 * i;
                 if (cc < C8) {
-                    bf16x8 o, av = zero8();
-                    if (add) av = ld8(add + (size_t)row * C + cc * 8);       // residual-branch gradient, summed here
+                    float o[8], av[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                    if (add) ldv8<T>(add + (size_t)row * C + cc * 8, av);       // residual-branch gradient, summed here
 #pragma unroll
                     for (int e = 0; e < 8; e++) {
-                        const float xh = (bf2f(xv[r][i][e]) - mean[r]) * rstd[r];
-                        o[e] = f2bf(rstd[r] * (bf2f(dv[r][i][e]) * ga[i][e] - s1[r] - xh * s2[r]) + bf2f(av[e]));
+                        const float xh = (xv[r][i][e] - mean[r]) * rstd[r];
+                        o[e] = rstd[r] * (dv[r][i][e] * ga[i][e] - s1[r] - xh * s2[r]) + av[e];
                     }
-                    st8(dx + (size_t)row * C + cc * 8, o);
+                    stv8<T>(dx + (size_t)row * C + cc * 8, o);
                 }
             }
         }
@@ -468,30 +480,34 @@ int sidlsg_groupnorm_nchunks(int B, int HW, int C, int G) {
     return g.nch;
 }
 
-// y = act(GroupNorm(x)); x,y: [B][HW][C] bf16; stats: [B][G][2] fp32 (mean, rstd) saved for backward
-int sidlsg_groupnorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* stats, float* ws,
-                         int B, int HW, int C, int G, float eps, int silu, void* stream) {
+}  // extern "C" (reopened below)
+
+// y = act(GroupNorm(x)); x,y: [B][HW][C]; stats: [B][G][2] fp32 (mean, rstd) saved for backward
+template <typename T>
+static int groupnorm_fwd_t(const void* x, const float* gamma, const float* beta, void* y, float* stats, float* ws,
+                           int B, int HW, int C, int G, float eps, int silu, void* stream) {
     GnGeom g; if (int e = gn_geom(g, B, HW, C, G)) return e;
     hipStream_t s = (hipStream_t)stream;
     const int threads = g.C8 * g.rows;
-    hipLaunchKernelGGL(gn_stats_kernel, dim3(g.nch, B), dim3(threads), (size_t)g.rows * C * 2 * sizeof(float), s,
-                       (const bf16*)x, ws, g);
-    hipLaunchKernelGGL(gn_apply_kernel, dim3(g.nch, B), dim3(threads), (size_t)2 * G * sizeof(float), s,
-                       (const bf16*)x, ws, gamma, beta, (bf16*)y, stats, g, eps, silu);
+    hipLaunchKernelGGL(gn_stats_kernel<T>, dim3(g.nch, B), dim3(threads), (size_t)g.rows * C * 2 * sizeof(float), s,
+                       (const T*)x, ws, g);
+    hipLaunchKernelGGL(gn_apply_kernel<T>, dim3(g.nch, B), dim3(threads), (size_t)2 * G * sizeof(float), s,
+                       (const T*)x, ws, gamma, beta, (T*)y, stats, g, eps, silu);
     return sidlsg_last_error();
 }
 
 // dx (and optionally dgamma/dbeta +=) of y = act(GroupNorm(x))
-int sidlsg_groupnorm_bwd(const void* x, const void* dy, const float* stats, const float* gamma, const float* beta,
-                         const void* dres, void* dx, float* dgamma, float* dbeta, float* ws, int B, int HW, int C, int G,
-                         int silu, void* stream) {
+template <typename T>
+static int groupnorm_bwd_t(const void* x, const void* dy, const float* stats, const float* gamma, const float* beta,
+                           const void* dres, void* dx, float* dgamma, float* dbeta, float* ws, int B, int HW, int C, int G,
+                           int silu, void* stream) {
     GnGeom g; if (int e = gn_geom(g, B, HW, C, G)) return e;
     hipStream_t s = (hipStream_t)stream;
     const int threads = g.C8 * g.rows;
-    hipLaunchKernelGGL(gn_bwd_stats_kernel, dim3(g.nch, B), dim3(threads), (size_t)g.rows * C * 2 * sizeof(float), s,
-                       (const bf16*)x, (const bf16*)dy, stats, gamma, beta, ws, g, silu);
-    hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(g.nch, B), dim3(threads), (size_t)2 * G * sizeof(float), s,
-                       (const bf16*)x, (const bf16*)dy, stats, gamma, beta, ws, (const bf16*)dres, (bf16*)dx, g, silu);
+    hipLaunchKernelGGL(gn_bwd_stats_kernel<T>, dim3(g.nch, B), dim3(threads), (size_t)g.rows * C * 2 * sizeof(float), s,
+                       (const T*)x, (const T*)dy, stats, gamma, beta, ws, g, silu);
+    hipLaunchKernelGGL(gn_bwd_apply_kernel<T>, dim3(g.nch, B), dim3(threads), (size_t)2 * G * sizeof(float), s,
+                       (const T*)x, (const T*)dy, stats, gamma, beta, ws, (const T*)dres, (T*)dx, g, silu);
     if (dgamma && dbeta) {
         const int P = B * g.nch;
         hipLaunchKernelGGL(colsum_reduce_kernel, reduce_grid(C, P), dim3(256), 0, s, ws, dgamma, P, (size_t)C * 2, 2, 0, C, 1);
@@ -500,37 +516,39 @@ int sidlsg_groupnorm_bwd(const void* x, const void* dy, const float* stats, cons
     return sidlsg_last_error();
 }
 
-// y = LayerNorm(x) over C; x,y [rows][C] bf16; stats [rows][2]
-int sidlsg_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* stats, int rows, int C,
-                         float eps, void* stream) {
+// y = LayerNorm(x) over C; x,y [rows][C]; stats [rows][2]
+template <typename T>
+static int layernorm_fwd_t(const void* x, const float* gamma, const float* beta, void* y, float* stats, int rows, int C,
+                           float eps, void* stream) {
     if (C % 8 || C > 8 * 64 * LN_MAXCH || rows <= 0) return SIDLSG_EINVAL;
     const int nch = (C / 8 + 63) / 64;
     const int R = nch <= 1 ? 4 : 2;
     // rows per wave: enough waves to fill the chip (>= ~4096), at most 16 rows (amortises the gamma/beta loads)
     int rpw = rows / 4096; rpw = rpw < R ? R : (rpw > 16 ? 16 : rpw); rpw = (rpw + R - 1) / R * R;
     const dim3 grid((rows + 4 * rpw - 1) / (4 * rpw));
-#define LN_FWD(NCH, RR) hipLaunchKernelGGL((ln_fwd_kernel<NCH, RR>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)x, gamma, \
-                                           beta, (bf16*)y, stats, rows, C, eps, rpw)
+#define LN_FWD(NCH, RR) hipLaunchKernelGGL((ln_fwd_kernel<T, NCH, RR>), grid, dim3(256), 0, (hipStream_t)stream, (const T*)x, gamma, \
+                                           beta, (T*)y, stats, rows, C, eps, rpw)
     if (nch == 1) LN_FWD(1, 4); else if (nch == 2) LN_FWD(2, 2); else if (nch == 3) LN_FWD(3, 2); else LN_FWD(4, 2);
 #undef LN_FWD
     return sidlsg_last_error();
 }
-int sidlsg_layernorm_bwd_nblocks(int rows) {
+static int layernorm_bwd_nblocks(int rows) {
     int nb = (rows + 15) / 16; if (nb > 1024) nb = 1024; if (nb < 1) nb = 1; return nb;
 }
 
 // dx, and dgamma/dbeta (+=) when non-null; ws: [nblocks][C][2] floats
-int sidlsg_layernorm_bwd(const void* x, const void* dy, const float* stats, const float* gamma, const void* dres, void* dx,
-                         float* dgamma, float* dbeta, float* ws, int rows, int C, void* stream) {
+template <typename T>
+static int layernorm_bwd_t(const void* x, const void* dy, const float* stats, const float* gamma, const void* dres, void* dx,
+                           float* dgamma, float* dbeta, float* ws, int rows, int C, void* stream) {
     if (C % 8 || C > 8 * 64 * LN_MAXCH || rows <= 0) return SIDLSG_EINVAL;
     hipStream_t s = (hipStream_t)stream;
-    const int nb = sidlsg_layernorm_bwd_nblocks(rows);
+    const int nb = layernorm_bwd_nblocks(rows);
     const int rpb = (rows + nb - 1) / nb;
     const bool pg = dgamma && dbeta;
     const int nch = (C / 8 + 63) / 64;
     const size_t lds = pg ? (size_t)4 * C * 2 * sizeof(float) : 0;
-#define LN_BWD(NCH, R) hipLaunchKernelGGL((ln_bwd_kernel<NCH, R>), dim3(nb), dim3(256), lds, s, (const bf16*)x, (const bf16*)dy, \
-                                          stats, gamma, (const bf16*)dres, (bf16*)dx, pg ? ws : nullptr, rows, C, rpb)
+#define LN_BWD(NCH, R) hipLaunchKernelGGL((ln_bwd_kernel<T, NCH, R>), dim3(nb), dim3(256), lds, s, (const T*)x, (const T*)dy, \
+                                          stats, gamma, (const T*)dres, (T*)dx, pg ? ws : nullptr, rows, C, rpb)
     if (nch == 1) LN_BWD(1, 2); else if (nch == 2) LN_BWD(2, 2); else if (nch == 3) LN_BWD(3, 1); else LN_BWD(4, 1);
 #undef LN_BWD
     if (pg) {
@@ -539,5 +557,25 @@ int sidlsg_layernorm_bwd(const void* x, const void* dy, const float* stats, cons
     }
     return sidlsg_last_error();
 }
+
+extern "C" {
+
+#define SIDLSG_BOTH(name, tmpl, params, args) \
+    int name params { return tmpl<bf16> args; }  \
+    int name##_f32 params { return tmpl<float> args; }
+
+SIDLSG_BOTH(sidlsg_groupnorm_fwd, groupnorm_fwd_t,
+            (const void* x, const float* gamma, const float* beta, void* y, float* stats, float* ws, int B, int HW, int C, int G, float eps, int silu, void* stream),
+            (x, gamma, beta, y, stats, ws, B, HW, C, G, eps, silu, stream))
+SIDLSG_BOTH(sidlsg_groupnorm_bwd, groupnorm_bwd_t,
+            (const void* x, const void* dy, const float* stats, const float* gamma, const float* beta, const void* dres, void* dx, float* dgamma, float* dbeta, float* ws, int B, int HW, int C, int G, int silu, void* stream),
+            (x, dy, stats, gamma, beta, dres, dx, dgamma, dbeta, ws, B, HW, C, G, silu, stream))
+SIDLSG_BOTH(sidlsg_layernorm_fwd, layernorm_fwd_t,
+            (const void* x, const float* gamma, const float* beta, void* y, float* stats, int rows, int C, float eps, void* stream),
+            (x, gamma, beta, y, stats, rows, C, eps, stream))
+int sidlsg_layernorm_bwd_nblocks(int rows) { return layernorm_bwd_nblocks(rows); }
+SIDLSG_BOTH(sidlsg_layernorm_bwd, layernorm_bwd_t,
+            (const void* x, const void* dy, const float* stats, const float* gamma, const void* dres, void* dx, float* dgamma, float* dbeta, float* ws, int rows, int C, void* stream),
+            (x, dy, stats, gamma, dres, dx, dgamma, dbeta, ws, rows, C, stream))
 
 }  // extern "C"

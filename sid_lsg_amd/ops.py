@@ -5,7 +5,9 @@ cached autograd.Function -> plugin call on the current stream) with one delibera
 there is no `impl='ref'` fallback.  If the library is absent or a tensor is not on the GPU these
 raise.  PyTorch is used only for device memory, the current stream and autograd bookkeeping.
 
-Conventions: activations are bf16, NHWC / token-major and contiguous; parameters are fp32
+Conventions: activations are bf16 (production) or fp32 (the fp32-accurate parity mode: same call graph, the `_f32`
+entry-point family of include/sidlsg_hip.h, chosen by the dtype of the activation tensor), NHWC / token-major and
+contiguous; parameters are fp32
 "masters" whose `.grad` is a pre-allocated fp32 view into the network's flat gradient buffer --
 weight/bias gradients are ACCUMULATED IN PLACE by the kernels (atomics / +=) and the autograd
 functions return None for them, so no per-parameter gradient tensors are ever materialised.
@@ -26,14 +28,25 @@ def _s():
     return torch.cuda.current_stream().cuda_stream
 
 
+ACT = 'act'   # _chk: an activation tensor (bf16 or fp32)
+
+
 def _chk(t, dtype=None):
     if not t.is_cuda:
         raise RuntimeError('sid_lsg_amd ops need CUDA(HIP) tensors: there is no CPU fallback')
-    if dtype is not None and t.dtype != dtype:
+    if dtype is ACT:
+        if t.dtype not in (BF16, F32):
+            raise RuntimeError(f'expected a bf16 or fp32 activation tensor, got {t.dtype}')
+    elif dtype is not None and t.dtype != dtype:
         raise RuntimeError(f'expected {dtype}, got {t.dtype}')
     if not t.is_contiguous():
         raise RuntimeError('expected a contiguous tensor')
     return t
+
+
+def _fn(name, dtype, bf16_suffix=''):
+    """C entry point of the activation dtype: `sidlsg_<name><bf16_suffix>` for bf16, `sidlsg_<name>_f32` for fp32."""
+    return getattr(lib, f'sidlsg_{name}_f32' if dtype == F32 else f'sidlsg_{name}{bf16_suffix}')
 
 
 def _wants_grad(p):
@@ -69,12 +82,15 @@ def gemm(a, w16, out=None, bias=None, res=None, rowvec=None, rows_per_batch=1, a
     K = w16.shape[1]
     N = w16.shape[0]
     lda = a.stride(0) if lda is None else lda
+    f32 = a.dtype == F32
+    if f32 and w16.dtype != F32:
+        raise RuntimeError('fp32 activations need the fp32 compute copy of the weights')
     ensure_workspace(a.device)
     if out is None:
-        out = torch.empty((M, N), device=a.device, dtype=F32 if out_f32 else BF16)
-    lib.sidlsg_gemm_bf16(_p(a), lda, _p(w16), _p(out), out.stride(0), _p(bias), _p(res), res.stride(0) if res is not None else 0,
-                         _p(rowvec), rowvec.stride(0) if rowvec is not None else 0, rows_per_batch, M, N, K, float(alpha),
-                         1 if out_f32 else 0, _s())
+        out = torch.empty((M, N), device=a.device, dtype=F32 if (out_f32 or f32) else BF16)
+    _fn('gemm', a.dtype, '_bf16')(_p(a), lda, _p(w16), _p(out), out.stride(0), _p(bias), _p(res), res.stride(0) if res is not None else 0,
+                                  _p(rowvec), rowvec.stride(0) if rowvec is not None else 0, rows_per_batch, M, N, K, float(alpha),
+                                  0 if f32 else (1 if out_f32 else 0), _s())
     return out
 
 
@@ -84,20 +100,23 @@ def conv3x3(x, w16, bias=None, res=None, rowvec=None, stride=1, ups=0, out_f32=F
     H, W = (2 * Hs, 2 * Ws) if ups else (Hs, Ws)
     Cout = w16.shape[0]
     Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    f32 = x.dtype == F32
+    if f32 and w16.dtype != F32:
+        raise RuntimeError('fp32 activations need the fp32 compute copy of the weights')
     ensure_workspace(x.device)
-    out = torch.empty((B, Ho, Wo, Cout), device=x.device, dtype=F32 if out_f32 else BF16)
-    lib.sidlsg_conv3x3_bf16(_p(x), Cin, _p(w16), _p(out), Cout, _p(bias), _p(res), Cout if res is not None else 0, _p(rowvec),
-                            rowvec.stride(0) if rowvec is not None else 0, B, H, W, Cin, Cout, stride, ups, 1.0,
-                            1 if out_f32 else 0, _s())
+    out = torch.empty((B, Ho, Wo, Cout), device=x.device, dtype=F32 if (out_f32 or f32) else BF16)
+    _fn('conv3x3', x.dtype, '_bf16')(_p(x), Cin, _p(w16), _p(out), Cout, _p(bias), _p(res), Cout if res is not None else 0, _p(rowvec),
+                                     rowvec.stride(0) if rowvec is not None else 0, B, H, W, Cin, Cout, stride, ups, 1.0,
+                                     0 if f32 else (1 if out_f32 else 0), _s())
     return out
 
 
 def colsum(g2d, rows_per_batch, per_batch=False, total=None):
-    """g2d: [B*rows_per_batch, N] bf16.  total (fp32 [N]) is accumulated in place; returns per-batch sums if asked."""
+    """g2d: [B*rows_per_batch, N].  total (fp32 [N]) is accumulated in place; returns per-batch sums if asked."""
     R, N = g2d.shape
     B = R // rows_per_batch
     pb = torch.zeros((B, N), device=g2d.device, dtype=F32) if per_batch else None
-    lib.sidlsg_colsum(_p(g2d), g2d.stride(0), _p(pb), _p(total), None, B, rows_per_batch, N, _s())
+    _fn('colsum', g2d.dtype)(_p(g2d), g2d.stride(0), _p(pb), _p(total), None, B, rows_per_batch, N, _s())
     return pb
 
 
@@ -107,7 +126,7 @@ class _Linear(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, w16, w16t, res, rowvec, rows_per_batch, out_f32):
-        _chk(x, BF16)
+        _chk(x, ACT)
         y = gemm(x, w16, bias=bias, res=res, rowvec=rowvec, rows_per_batch=rows_per_batch, out_f32=out_f32)
         ctx.save_for_backward(x, weight, bias, w16t)
         ctx.rpb = rows_per_batch
@@ -119,16 +138,17 @@ class _Linear(torch.autograd.Function):
     def backward(ctx, dy):
         x, weight, bias, w16t = ctx.saved_tensors
         dy = dy.contiguous()
-        if dy.dtype != BF16:
-            dy = dy.to(BF16)
+        if dy.dtype != x.dtype:
+            dy = dy.to(x.dtype)
         dx = gemm(dy, w16t) if ctx.needs_input_grad[0] else None
         need_b = _wants_grad(bias)
         need_rv = ctx.has_rv and ctx.needs_input_grad[6]
-        fused_b = need_b and not need_rv and _wants_grad(weight)    # bias gradient comes out of the wgrad kernel
+        # bias gradient comes out of the bf16 wgrad kernel (the fp32 family computes it with a column sum)
+        fused_b = need_b and not need_rv and _wants_grad(weight) and x.dtype == BF16
         if _wants_grad(weight):
             M, K = x.shape
-            lib.sidlsg_wgrad_bf16(_p(dy), dy.stride(0), _p(x), x.stride(0), _p(weight.grad), _p(bias.grad) if fused_b else None,
-                                  M, weight.shape[0], K, _s())
+            _fn('wgrad', x.dtype, '_bf16')(_p(dy), dy.stride(0), _p(x), x.stride(0), _p(weight.grad), _p(bias.grad) if fused_b else None,
+                                           M, weight.shape[0], K, _s())
         drv = None
         if need_rv:
             drv = colsum(dy, ctx.rpb, per_batch=True, total=bias.grad if need_b else None)
@@ -147,7 +167,7 @@ class _Conv3x3(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, w16, w16t, res, rowvec, stride, ups, out_f32, bias_p):
-        _chk(x, BF16)
+        _chk(x, ACT)
         y = conv3x3(x, w16, bias=bias_p if bias_p is not None else bias, res=res, rowvec=rowvec, stride=stride, ups=ups,
                     out_f32=out_f32)
         ctx.save_for_backward(x, weight, bias, w16t)
@@ -159,34 +179,36 @@ class _Conv3x3(torch.autograd.Function):
         x, weight, bias, w16t = ctx.saved_tensors
         stride, ups, has_res, has_rv = ctx.cfg
         dy = dy.contiguous()
-        if dy.dtype != BF16:
-            dy = dy.to(BF16)
+        if dy.dtype != x.dtype:
+            dy = dy.to(x.dtype)
         B, Ho, Wo, Cout = dy.shape
         Cin = x.shape[3]
         dx = None
         if ctx.needs_input_grad[0]:
             g = dy
             if stride == 2:
-                g = torch.empty((B, x.shape[1], x.shape[2], Cout), device=dy.device, dtype=BF16)
-                lib.sidlsg_zero_insert2(_p(dy), _p(g), B, Ho, Wo, x.shape[1], x.shape[2], Cout, _s())
+                g = torch.empty((B, x.shape[1], x.shape[2], Cout), device=dy.device, dtype=x.dtype)
+                _fn('zero_insert2', x.dtype)(_p(dy), _p(g), B, Ho, Wo, x.shape[1], x.shape[2], Cout, _s())
             dx = conv3x3(g, w16t)           # w16t: [Cin, 9*Cout], taps flipped
             if ups:
                 full = dx
                 dx = torch.empty_like(x)
-                lib.sidlsg_sumpool2x2(_p(full), _p(dx), B, x.shape[1], x.shape[2], Cin, _s())
+                _fn('sumpool2x2', x.dtype)(_p(full), _p(dx), B, x.shape[1], x.shape[2], Cin, _s())
         co_w, ci_w = weight.shape[0], weight.shape[1]     # logical (unpadded) sizes of the master
         padded = (co_w != Cout) or (ci_w != Cin)           # conv_in (Cin 4->8) / conv_out (Cout 4->8)
         need_b = _wants_grad(bias)
         need_rv = has_rv and ctx.needs_input_grad[6]
-        fused_b = need_b and not need_rv and not padded and _wants_grad(weight)   # bias gradient from the wgrad kernel
+        # bias gradient from the (bf16) wgrad kernel
+        fused_b = need_b and not need_rv and not padded and _wants_grad(weight) and x.dtype == BF16
         if _wants_grad(weight):
             H, W = (2 * x.shape[1], 2 * x.shape[2]) if ups else (x.shape[1], x.shape[2])
+            wgrad = _fn('conv3x3_wgrad', x.dtype, '_bf16')
             if not padded:
-                lib.sidlsg_conv3x3_wgrad_bf16(_p(dy), Cout, _p(x), Cin, _p(weight.grad), _p(bias.grad) if fused_b else None,
-                                              B, H, W, Cin, Cout, stride, ups, _s())
+                wgrad(_p(dy), Cout, _p(x), Cin, _p(weight.grad), _p(bias.grad) if fused_b else None,
+                      B, H, W, Cin, Cout, stride, ups, _s())
             else:
                 tmp = torch.zeros((Cout, 9, Cin), device=dy.device, dtype=F32)
-                lib.sidlsg_conv3x3_wgrad_bf16(_p(dy), Cout, _p(x), Cin, _p(tmp), None, B, H, W, Cin, Cout, stride, ups, _s())
+                wgrad(_p(dy), Cout, _p(x), Cin, _p(tmp), None, B, H, W, Cin, Cout, stride, ups, _s())
                 weight.grad.permute(0, 2, 3, 1).reshape(co_w, 9, ci_w).add_(tmp[:co_w, :, :ci_w])
         dy2 = dy.view(B * Ho * Wo, Cout)
         drv = None
@@ -214,7 +236,7 @@ class _GroupNorm(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, gamma, beta, groups, eps, silu, fork):
-        _chk(x, BF16)
+        _chk(x, ACT)
         B, C = x.shape[0], x.shape[-1]
         HW = x.numel() // (B * C)
         n = lib.sidlsg_groupnorm_ws_floats.raw(B, HW, C, groups)
@@ -223,7 +245,7 @@ class _GroupNorm(torch.autograd.Function):
         ws = torch.empty(n, device=x.device, dtype=F32)
         stats = torch.empty((B, groups, 2), device=x.device, dtype=F32)
         y = torch.empty_like(x)
-        lib.sidlsg_groupnorm_fwd(_p(x), _p(gamma), _p(beta), _p(y), _p(stats), _p(ws), B, HW, C, groups, float(eps), int(silu), _s())
+        _fn('groupnorm_fwd', x.dtype)(_p(x), _p(gamma), _p(beta), _p(y), _p(stats), _p(ws), B, HW, C, groups, float(eps), int(silu), _s())
         ctx.save_for_backward(x, gamma, beta, stats)
         ctx.cfg = (B, HW, C, groups, int(silu), n)
         if fork:
@@ -237,15 +259,17 @@ class _GroupNorm(torch.autograd.Function):
         if dy is None:                       # only the pass-through output was used
             return dkeep, None, None, None, None, None, None
         dy = dy.contiguous()
+        if dy.dtype != x.dtype:
+            dy = dy.to(x.dtype)
         if dkeep is not None:
             dkeep = dkeep.contiguous()
-            if dkeep.dtype != BF16:
-                dkeep = dkeep.to(BF16)
+            if dkeep.dtype != x.dtype:
+                dkeep = dkeep.to(x.dtype)
         ws = torch.empty(n, device=x.device, dtype=F32)
         dx = torch.empty_like(x)
         pg = _wants_grad(gamma) and _wants_grad(beta)
-        lib.sidlsg_groupnorm_bwd(_p(x), _p(dy), _p(stats), _p(gamma), _p(beta), _p(dkeep) if dkeep is not None else None, _p(dx),
-                                 _p(gamma.grad) if pg else None, _p(beta.grad) if pg else None, _p(ws), B, HW, C, groups, silu, _s())
+        _fn('groupnorm_bwd', x.dtype)(_p(x), _p(dy), _p(stats), _p(gamma), _p(beta), _p(dkeep) if dkeep is not None else None, _p(dx),
+                                      _p(gamma.grad) if pg else None, _p(beta.grad) if pg else None, _p(ws), B, HW, C, groups, silu, _s())
         return dx, None, None, None, None, None, None
 
 
@@ -258,12 +282,12 @@ class _LayerNorm(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, gamma, beta, eps, fork):
-        _chk(x, BF16)
+        _chk(x, ACT)
         C = x.shape[-1]
         rows = x.numel() // C
         y = torch.empty_like(x)
         stats = torch.empty((rows, 2), device=x.device, dtype=F32)
-        lib.sidlsg_layernorm_fwd(_p(x), _p(gamma), _p(beta), _p(y), _p(stats), rows, C, float(eps), _s())
+        _fn('layernorm_fwd', x.dtype)(_p(x), _p(gamma), _p(beta), _p(y), _p(stats), rows, C, float(eps), _s())
         ctx.save_for_backward(x, gamma, beta, stats)
         if fork:
             return y, x.view(x.shape)
@@ -277,15 +301,17 @@ class _LayerNorm(torch.autograd.Function):
         C = x.shape[-1]
         rows = x.numel() // C
         dy = dy.contiguous()
+        if dy.dtype != x.dtype:
+            dy = dy.to(x.dtype)
         if dkeep is not None:
             dkeep = dkeep.contiguous()
-            if dkeep.dtype != BF16:
-                dkeep = dkeep.to(BF16)
+            if dkeep.dtype != x.dtype:
+                dkeep = dkeep.to(x.dtype)
         dx = torch.empty_like(x)
         pg = _wants_grad(gamma) and _wants_grad(beta)
         ws = torch.empty(lib.sidlsg_layernorm_bwd_nblocks.raw(rows) * C * 2, device=x.device, dtype=F32) if pg else None
-        lib.sidlsg_layernorm_bwd(_p(x), _p(dy), _p(stats), _p(gamma), _p(dkeep) if dkeep is not None else None, _p(dx),
-                                 _p(gamma.grad) if pg else None, _p(beta.grad) if pg else None, _p(ws), rows, C, _s())
+        _fn('layernorm_bwd', x.dtype)(_p(x), _p(dy), _p(stats), _p(gamma), _p(dkeep) if dkeep is not None else None, _p(dx),
+                                      _p(gamma.grad) if pg else None, _p(beta.grad) if pg else None, _p(ws), rows, C, _s())
         return dx, None, None, None, None
 
 
@@ -298,16 +324,16 @@ class _Attention(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, qbuf, kvbuf, heads, D, qoff, koff, voff):
-        _chk(qbuf, BF16)
-        _chk(kvbuf, BF16)
+        _chk(qbuf, ACT)
+        _chk(kvbuf, qbuf.dtype)
         B, Nq, ldq = qbuf.shape
         Nk, ldk = kvbuf.shape[1], kvbuf.shape[2]
         C = heads * D
-        o = torch.empty((B, Nq, C), device=qbuf.device, dtype=BF16)
+        o = torch.empty((B, Nq, C), device=qbuf.device, dtype=qbuf.dtype)
         lse = torch.empty((B, heads, Nq), device=qbuf.device, dtype=F32)
         es = qbuf.element_size()
-        lib.sidlsg_attn_fwd(qbuf.data_ptr() + qoff * es, kvbuf.data_ptr() + koff * es, kvbuf.data_ptr() + voff * es, _p(o), _p(lse),
-                            B, heads, Nq, Nk, D, ldq, ldk, ldk, C, Nq * ldq, Nk * ldk, Nk * ldk, Nq * C, _s())
+        _fn('attn_fwd', qbuf.dtype)(qbuf.data_ptr() + qoff * es, kvbuf.data_ptr() + koff * es, kvbuf.data_ptr() + voff * es, _p(o), _p(lse),
+                                    B, heads, Nq, Nk, D, ldq, ldk, ldk, C, Nq * ldq, Nk * ldk, Nk * ldk, Nq * C, _s())
         ctx.save_for_backward(qbuf, kvbuf, o, lse)
         ctx.cfg = (heads, D, qoff, koff, voff)
         return o
@@ -320,12 +346,14 @@ class _Attention(torch.autograd.Function):
         Nk, ldk = kvbuf.shape[1], kvbuf.shape[2]
         C = heads * D
         do = do.contiguous()
+        if do.dtype != qbuf.dtype:
+            do = do.to(qbuf.dtype)
         same = qbuf.data_ptr() == kvbuf.data_ptr()
         dq = torch.empty_like(qbuf)
         dkv = dq if same else torch.empty_like(kvbuf)
         delta = torch.empty((B, heads, Nq), device=qbuf.device, dtype=F32)
-        es = 2
-        lib.sidlsg_attn_bwd(qbuf.data_ptr() + qoff * es, kvbuf.data_ptr() + koff * es, kvbuf.data_ptr() + voff * es, _p(o), _p(do),
+        es = qbuf.element_size()
+        _fn('attn_bwd', qbuf.dtype)(qbuf.data_ptr() + qoff * es, kvbuf.data_ptr() + koff * es, kvbuf.data_ptr() + voff * es, _p(o), _p(do),
                             _p(lse), dq.data_ptr() + qoff * es, dkv.data_ptr() + koff * es, dkv.data_ptr() + voff * es, _p(delta),
                             B, heads, Nq, Nk, D, ldq, ldk, ldk, C, Nq * ldq, Nk * ldk, Nk * ldk, Nq * C, _s())
         return dq, (None if same else dkv), None, None, None, None, None
@@ -346,11 +374,11 @@ def cross_attention(q, kv, heads):
 class _GEGLU(torch.autograd.Function):
     @staticmethod
     def forward(ctx, h):
-        _chk(h, BF16)
+        _chk(h, ACT)
         F2 = h.shape[-1]
         M = h.numel() // F2
-        y = torch.empty(h.shape[:-1] + (F2 // 2,), device=h.device, dtype=BF16)
-        lib.sidlsg_geglu_fwd(_p(h), _p(y), M, F2 // 2, _s())
+        y = torch.empty(h.shape[:-1] + (F2 // 2,), device=h.device, dtype=h.dtype)
+        _fn('geglu_fwd', h.dtype)(_p(h), _p(y), M, F2 // 2, _s())
         ctx.save_for_backward(h)
         return y
 
@@ -359,7 +387,7 @@ class _GEGLU(torch.autograd.Function):
         (h,) = ctx.saved_tensors
         F2 = h.shape[-1]
         dh = torch.empty_like(h)
-        lib.sidlsg_geglu_bwd(_p(h), _p(dy.contiguous()), _p(dh), h.numel() // F2, F2 // 2, _s())
+        _fn('geglu_bwd', h.dtype)(_p(h), _p(dy.contiguous().to(h.dtype)), _p(dh), h.numel() // F2, F2 // 2, _s())
         return dh
 
 
@@ -370,9 +398,9 @@ def geglu(h):
 class _SiLU(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):
-        _chk(x, BF16)
+        _chk(x, ACT)
         y = torch.empty_like(x)
-        lib.sidlsg_silu_fwd(_p(x), _p(y), x.numel(), _s())
+        _fn('silu_fwd', x.dtype)(_p(x), _p(y), x.numel(), _s())
         ctx.save_for_backward(x)
         return y
 
@@ -380,7 +408,7 @@ class _SiLU(torch.autograd.Function):
     def backward(ctx, dy):
         (x,) = ctx.saved_tensors
         dx = torch.empty_like(x)
-        lib.sidlsg_silu_bwd(_p(x), _p(dy.contiguous()), _p(dx), x.numel(), _s())
+        _fn('silu_bwd', x.dtype)(_p(x), _p(dy.contiguous().to(x.dtype)), _p(dx), x.numel(), _s())
         return dx
 
 
@@ -391,12 +419,12 @@ def silu(x):
 class _Concat(torch.autograd.Function):
     @staticmethod
     def forward(ctx, a, b):
-        _chk(a, BF16)
-        _chk(b, BF16)
+        _chk(a, ACT)
+        _chk(b, a.dtype)
         C1, C2 = a.shape[-1], b.shape[-1]
         M = a.numel() // C1
-        out = torch.empty(a.shape[:-1] + (C1 + C2,), device=a.device, dtype=BF16)
-        lib.sidlsg_concat2(_p(a), _p(b), _p(out), M, C1, C2, 0, _s())
+        out = torch.empty(a.shape[:-1] + (C1 + C2,), device=a.device, dtype=a.dtype)
+        _fn('concat2', a.dtype)(_p(a), _p(b), _p(out), M, C1, C2, 0, _s())
         ctx.shapes = (a.shape, b.shape)
         return out
 
@@ -404,9 +432,9 @@ class _Concat(torch.autograd.Function):
     def backward(ctx, g):
         sa, sb = ctx.shapes
         g = g.contiguous()
-        da = torch.empty(sa, device=g.device, dtype=BF16)
-        db = torch.empty(sb, device=g.device, dtype=BF16)
-        lib.sidlsg_concat2(_p(da), _p(db), _p(g), da.numel() // sa[-1], sa[-1], sb[-1], 1, _s())
+        da = torch.empty(sa, device=g.device, dtype=g.dtype)
+        db = torch.empty(sb, device=g.device, dtype=g.dtype)
+        _fn('concat2', g.dtype)(_p(da), _p(db), _p(g), da.numel() // sa[-1], sa[-1], sb[-1], 1, _s())
         return da, db
 
 
@@ -418,7 +446,7 @@ class _Add(torch.autograd.Function):
     @staticmethod
     def forward(ctx, a, b):
         o = torch.empty_like(a)
-        lib.sidlsg_add_bf16(_p(_chk(a, BF16)), _p(_chk(b, BF16)), _p(o), a.numel(), _s())
+        _fn('add', a.dtype, '_bf16')(_p(_chk(a, ACT)), _p(_chk(b, a.dtype)), _p(o), a.numel(), _s())
         return o
 
     @staticmethod
@@ -430,23 +458,23 @@ def add(a, b):
     return _Add.apply(a, b)
 
 
-def timestep_embed(t, dim):
-    out = torch.empty((t.shape[0], dim), device=t.device, dtype=BF16)
-    lib.sidlsg_timestep_embed(_p(_chk(t, torch.int64)), _p(out), t.shape[0], dim, _s())
+def timestep_embed(t, dim, dtype=BF16):
+    out = torch.empty((t.shape[0], dim), device=t.device, dtype=dtype)
+    _fn('timestep_embed', dtype)(_p(_chk(t, torch.int64)), _p(out), t.shape[0], dim, _s())
     return out
 
 
 # ------------------------------------------------------------------------------------------------
 # scheduler / guidance glue and losses
 class _NoisyInput(torch.autograd.Function):
-    """x_t = s0*x0 + s1*noise -> (NHWC bf16 [dup*B,H,W,8], x_t fp32 NCHW).  x0 may be None."""
+    """x_t = s0*x0 + s1*noise -> (NHWC activations [dup*B,H,W,8] of `dtype`, x_t fp32 NCHW).  x0 may be None."""
 
     @staticmethod
-    def forward(ctx, x0, noise, s0, s1, dup):
+    def forward(ctx, x0, noise, s0, s1, dup, dtype):
         B, C, H, W = noise.shape
-        out = torch.empty((dup * B, H, W, 8), device=noise.device, dtype=BF16)
+        out = torch.empty((dup * B, H, W, 8), device=noise.device, dtype=dtype)
         xt = torch.empty_like(noise)
-        lib.sidlsg_noisy_input(_p(x0), _p(_chk(noise, F32)), _p(s0), _p(s1), _p(out), _p(xt), B, C, H * W, 8, dup, _s())
+        _fn('noisy_input', dtype)(_p(x0), _p(_chk(noise, F32)), _p(s0), _p(s1), _p(out), _p(xt), B, C, H * W, 8, dup, _s())
         ctx.save_for_backward(s0, s1)
         ctx.cfg = (B, C, H, W, dup)
         return out, xt
@@ -462,43 +490,43 @@ class _NoisyInput(torch.autograd.Function):
                 outs.append(None)
                 continue
             d = torch.empty((B, C, H, W), device=g.device, dtype=F32)
-            lib.sidlsg_noisy_input_bwd(_p(g), _p(sc), _p(d), B, C, H * W, 8, dup, 0, _s())
+            _fn('noisy_input_bwd', g.dtype)(_p(g), _p(sc), _p(d), B, C, H * W, 8, dup, 0, _s())
             if gxt is not None:
                 d = d + gxt * sc.view(B, 1, 1, 1)
             outs.append(d)
-        return outs[0], outs[1], None, None, None
+        return outs[0], outs[1], None, None, None, None
 
 
-def noisy_input(x0, noise, s0, s1, dup):
-    return _NoisyInput.apply(x0, noise, s0, s1, dup)
+def noisy_input(x0, noise, s0, s1, dup, dtype=BF16):
+    return _NoisyInput.apply(x0, noise, s0, s1, dup, dtype)
 
 
 class _CfgX0(torch.autograd.Function):
     """eps [dup*B,HW,C] fp32 (+ x_t) -> NCHW fp32 guided eps or x0 prediction."""
 
     @staticmethod
-    def forward(ctx, eps, xt, s0, s1, kappa, predict_x0):
+    def forward(ctx, eps, xt, s0, s1, kappa, predict_x0, act_dtype):
         B, C, H, W = xt.shape
         dup = eps.shape[0] // B
         out = torch.empty_like(xt)
         lib.sidlsg_cfg_x0(_p(_chk(eps, F32)), _p(_chk(xt, F32)), _p(s0), _p(s1), _p(out), B, C, H * W, eps.shape[-1], dup,
                           float(kappa), int(predict_x0), _s())
         ctx.save_for_backward(s0, s1)
-        ctx.cfg = (B, C, H, W, dup, float(kappa), int(predict_x0))
+        ctx.cfg = (B, C, H, W, dup, float(kappa), int(predict_x0), act_dtype)
         return out
 
     @staticmethod
     def backward(ctx, g):
         s0, s1 = ctx.saved_tensors
-        B, C, H, W, dup, kappa, px0 = ctx.cfg
-        deps = torch.empty((dup * B, H * W, 8), device=g.device, dtype=BF16)
+        B, C, H, W, dup, kappa, px0, act_dtype = ctx.cfg
+        deps = torch.empty((dup * B, H * W, 8), device=g.device, dtype=act_dtype)    # the network's activation dtype
         dxt = torch.empty((B, C, H, W), device=g.device, dtype=F32) if ctx.needs_input_grad[1] else None
-        lib.sidlsg_cfg_x0_bwd(_p(g.contiguous()), _p(s0), _p(s1), _p(deps), _p(dxt), B, C, H * W, 8, dup, kappa, px0, _s())
-        return deps, dxt, None, None, None, None
+        _fn('cfg_x0_bwd', act_dtype)(_p(g.contiguous()), _p(s0), _p(s1), _p(deps), _p(dxt), B, C, H * W, 8, dup, kappa, px0, _s())
+        return deps, dxt, None, None, None, None, None
 
 
-def cfg_x0(eps, xt, s0, s1, kappa, predict_x0):
-    return _CfgX0.apply(eps, xt, s0, s1, kappa, predict_x0)
+def cfg_x0(eps, xt, s0, s1, kappa, predict_x0, act_dtype=BF16):
+    return _CfgX0.apply(eps, xt, s0, s1, kappa, predict_x0, act_dtype)
 
 
 class _GLoss(torch.autograd.Function):
@@ -547,10 +575,10 @@ def sid_fake_score_loss(e, noise, scale):
 
 
 # ------------------------------------------------------------------------------------------------
-def transpose_w(src_f32, n, k, taps=1):
-    """fp32 master [N][T][K] -> bf16 [K][T reversed][N]  (the dgrad operand)"""
-    dst = torch.empty((k, taps * n), device=src_f32.device, dtype=BF16)
-    lib.sidlsg_transpose_w(_p(src_f32), _p(dst), n, k, taps, _s())
+def transpose_w(src_f32, n, k, taps=1, dtype=BF16):
+    """fp32 master [N][T][K] -> [K][T reversed][N] of the compute dtype (the dgrad operand)"""
+    dst = torch.empty((k, taps * n), device=src_f32.device, dtype=dtype)
+    _fn('transpose_w', dtype)(_p(src_f32), _p(dst), n, k, taps, _s())
     return dst
 
 
@@ -612,9 +640,9 @@ def after_backward(x, cb):
     return _AfterBackward.apply(x, cb) if x.requires_grad else x
 
 
-def transpose_w_batched(jobs, njobs, nblocks):
-    """jobs: device uint8 tensor holding njobs sidlsg_tw_job records (see include/sidlsg_hip.h)."""
-    lib.sidlsg_transpose_w_batched(_p(jobs), njobs, nblocks, _s())
+def transpose_w_batched(jobs, njobs, nblocks, dtype=BF16):
+    """jobs: device uint8 tensor holding njobs sidlsg_tw_job records (see include/sidlsg_hip.h); dtype: of the destinations."""
+    _fn('transpose_w_batched', dtype)(_p(jobs), njobs, nblocks, _s())
 
 
 def cast_bf16(src_f32, out=None):

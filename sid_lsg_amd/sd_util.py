@@ -63,14 +63,27 @@ def _arch_of(name):
     return 'sd15'
 
 
+def resolve_compute_dtype(compute_dtype=None):
+    if compute_dtype is None:
+        compute_dtype = os.environ.get('SIDLSG_COMPUTE_DTYPE', 'bf16')
+    if isinstance(compute_dtype, str):
+        try:
+            compute_dtype = {'bf16': torch.bfloat16, 'bfloat16': torch.bfloat16, 'fp32': torch.float32, 'float32': torch.float32}[compute_dtype.lower()]
+        except KeyError:
+            raise ValueError(f'compute dtype {compute_dtype!r}: expected bf16 or fp32') from None
+    return compute_dtype
+
+
 def load_sd15(pretrained_model_name_or_path, pretrained_vae_model_name_or_path, device, weight_dtype, revision=None,
-              variant=None, lora_config=None, enable_xformers=False, gradient_checkpointing=False, seed=0):
+              variant=None, lora_config=None, enable_xformers=False, gradient_checkpointing=False, seed=0, compute_dtype=None):
     """Same contract as the reference factory.  Sources, in order:
       * a local diffusers-layout directory (unet/diffusion_pytorch_model.safetensors, text_encoder/model.safetensors,
         tokenizer/{vocab.json,merges.txt}) -> real weights through `load_state_dict` (key names are diffusers');
       * 'random:<arch>' (arch in sd15 | sd21-base | tiny | tiny40), or any hub id when SIDLSG_ALLOW_RANDOM_INIT=1 ->
         seeded random weights of that architecture (no network here: benchmarks and parity tests use this).
-    `weight_dtype` is accepted for signature compatibility: masters are fp32, compute is bf16 (MFMA).
+    `weight_dtype` is accepted for signature compatibility (the reference passes its fp16/fp32 switch here): masters are
+    always fp32.  The COMPUTE dtype is `compute_dtype` (torch.bfloat16 = production MFMA path, torch.float32 = the
+    fp32-accurate mode of csrc/fp32.hip), default from $SIDLSG_COMPUTE_DTYPE ('bf16' | 'fp32'), else bf16.
     `enable_xformers` / `gradient_checkpointing` are accepted and ignored (attention is always the fused HIP kernel;
     the reference itself never forwards gradient_checkpointing, sid_training_loop.py:224-228)."""
     name = str(pretrained_model_name_or_path)
@@ -85,7 +98,7 @@ def load_sd15(pretrained_model_name_or_path, pretrained_vae_model_name_or_path, 
     if local:
         from safetensors.torch import load_file
         src = load_file(os.path.join(name, 'unet', 'diffusion_pytorch_model.safetensors'))
-    unet = HipUNet2DCondition(cfg)
+    unet = HipUNet2DCondition(cfg, compute_dtype=resolve_compute_dtype(compute_dtype))
     unet.materialize(device, seed=seed, source=src)
     tcfg = TEXT_CONFIGS.get(arch, dict(hidden=cfg.cross_attention_dim, layers=2, heads=2, dff=2 * cfg.cross_attention_dim,
                                        act='quick_gelu'))
@@ -136,24 +149,27 @@ def encode_contexts(contexts, text_encoder, tokenizer, device):
 def hip_generate(unet, z, ctx16, init_t, sched, x0=None):
     """x_t = s0*x0 + s1*z at t_init ; eps = G(x_t) ; x_hat = (x_t - s1*eps)/s0   (sid_sd_util.py:182-185)"""
     s0, s1 = sched.coefficients(init_t)
-    xin, xt = ops.noisy_input(x0, z, s0, s1, 1)
-    eps = _ddp_exchange(unet, _unwrap(unet).forward_nhwc(xin, init_t, ctx16))
-    return ops.cfg_x0(eps, xt, s0, s1, 1.0, True)
+    net = _unwrap(unet)
+    xin, xt = ops.noisy_input(x0, z, s0, s1, 1, net.compute_dtype)
+    eps = _ddp_exchange(unet, net.forward_nhwc(xin, init_t, ctx16))
+    return ops.cfg_x0(eps, xt, s0, s1, 1.0, True, net.compute_dtype)
 
 
-def hip_prepare_denoise(images, noise, t, cond16, uncond16, sched, guided):
-    """Shared by every network evaluated on the same (images, noise, t): the noisy CFG batch and its conditioning."""
+def hip_prepare_denoise(images, noise, t, cond16, uncond16, sched, guided, act_dtype=torch.bfloat16):
+    """Shared by every network evaluated on the same (images, noise, t): the noisy CFG batch and its conditioning
+    (`act_dtype` = the compute dtype of the networks that will consume it)."""
     s0, s1 = sched.coefficients(t)
     dup = 2 if guided else 1
-    xin, xt = ops.noisy_input(images, noise, s0, s1, dup)
+    xin, xt = ops.noisy_input(images, noise, s0, s1, dup, act_dtype)
     ctx = torch.cat([uncond16, cond16]) if guided else cond16          # (sid_sd_util.py:259-261)
     tt = torch.cat([t, t]) if guided else t
     return SimpleNamespace(xin=xin, xt=xt, s0=s0, s1=s1, ctx=ctx, tt=tt)
 
 
 def hip_denoise(unet, prep, guidance_scale, predict_x0):
-    eps = _ddp_exchange(unet, _unwrap(unet).forward_nhwc(prep.xin, prep.tt, prep.ctx))
-    return ops.cfg_x0(eps, prep.xt, prep.s0, prep.s1, guidance_scale, predict_x0)  # u + k(c-u), then x0 (:264-272)
+    net = _unwrap(unet)
+    eps = _ddp_exchange(unet, net.forward_nhwc(prep.xin, prep.tt, prep.ctx))
+    return ops.cfg_x0(eps, prep.xt, prep.s0, prep.s1, guidance_scale, predict_x0, net.compute_dtype)  # u + k(c-u), then x0 (:264-272)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -162,7 +178,7 @@ def sid_sd_sampler(unet, latents, contexts, init_timesteps, noise_scheduler, tex
                    num_steps_eval=1):
     steps = num_steps if train_sampler else num_steps_eval
     _require_hip(unet)
-    emb = encode_contexts(contexts, text_encoder, tokenizer, latents.device).to(torch.bfloat16).contiguous()
+    emb = encode_contexts(contexts, text_encoder, tokenizer, latents.device).to(_unwrap(unet).compute_dtype).contiguous()
     D_x = None
     ctxmgr = torch.enable_grad() if train_sampler else torch.no_grad()
     with ctxmgr:
@@ -188,8 +204,8 @@ def sid_sd_denoise(unet, images, noise, contexts, timesteps, noise_scheduler, te
     cond = encode_contexts(contexts, text_encoder, tokenizer, images.device)
     guided = guidance_scale != 1
     uncond = encode_contexts([''] * b, text_encoder, tokenizer, images.device) if guided else None
-    bf = torch.bfloat16
+    bf = _unwrap(unet).compute_dtype
     prep = hip_prepare_denoise(images.to(torch.float32).contiguous(), noise.to(torch.float32).contiguous(),
                                timesteps.contiguous(), cond.to(bf).contiguous(),
-                               uncond.to(bf).contiguous() if guided else None, noise_scheduler, guided)
+                               uncond.to(bf).contiguous() if guided else None, noise_scheduler, guided, act_dtype=bf)
     return hip_denoise(unet, prep, float(guidance_scale), predict_x0)

@@ -36,6 +36,8 @@ class SiDStep:
         opt_fake.grad_scale = opt_G.grad_scale = 1.0 / world_size     # DDP mean, folded into the optimizer kernel
         opt_fake.attach(ema=None, w16=fake_score.flat_w16)
         opt_G.attach(ema=(G_ema.flat_params if (G_ema is not None and G_ema is not G) else None), w16=G.flat_w16)
+        if not (G.compute_dtype == fake_score.compute_dtype == true_score.compute_dtype):
+            raise ValueError('G, fake_score and true_score must share one compute dtype (they share the noisy CFG batch)')
         self.phi.requires_grad_(False)
 
     def _init_t(self, n, device):
@@ -46,7 +48,8 @@ class SiDStep:
         """r: dict(z, noise, t, cond, uncond) (fp32 NCHW / int64 / bf16 text states)."""
         with torch.no_grad():                                                       # :406-411
             images = hip_generate(self.G, r['z'], r['cond'], self._init_t(len(r['z']), r['z'].device), self.sched)
-        prep = hip_prepare_denoise(images, r['noise'], r['t'], r['cond'], r.get('uncond'), self.sched, self.k1 != 1)
+        prep = hip_prepare_denoise(images, r['noise'], r['t'], r['cond'], r.get('uncond'), self.sched, self.k1 != 1,
+                                   act_dtype=self.psi.compute_dtype)
         eps = hip_denoise(self.psi, prep, self.k1, predict_x0=False)                # :418-421
         loss = ops.sid_fake_score_loss(eps, r['noise'], self.ls / self.bgt)         # :423-445
         loss.backward()                                                             # :449-450
@@ -71,7 +74,8 @@ class SiDStep:
     def generator_round(self, r, before_fake_eval=None):
         images = hip_generate(self.G, r['z'], r['cond'], self._init_t(len(r['z']), r['z'].device), self.sched)  # :488-491
         guided = (self.k2 != 1) or (self.k4 != 1)
-        prep = hip_prepare_denoise(images, r['noise'], r['t'], r['cond'], r.get('uncond'), self.sched, guided)
+        prep = hip_prepare_denoise(images, r['noise'], r['t'], r['cond'], r.get('uncond'), self.sched, guided,
+                                   act_dtype=self.psi.compute_dtype)
         k2 = self.k2 if guided else 1.0
         k4 = self.k4 if guided else 1.0
         # teacher first: neither G's forward nor phi's reads psi, so a pending psi gradient exchange / optimizer step

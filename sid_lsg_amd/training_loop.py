@@ -29,7 +29,7 @@ from . import distributed as dist
 from .data import InfiniteSampler, prompt_batches
 from .dnnlib_util import EasyDict, construct_class_by_name, format_time
 from .distributed import FlatGradReducer
-from .sd_util import load_sd15
+from .sd_util import load_sd15, resolve_compute_dtype
 from .sid_step import SiDStep
 from .text import TextConditioner
 
@@ -109,14 +109,16 @@ def training_loop(
         dist.print0('note: gradient_checkpointing is ignored (as in the reference loop, sid_training_loop.py:224-228)')
     dist.print0('Loading dataset...')
     dataset_obj = construct_class_by_name(**dataset_prompt_text_kwargs)
-    dtype = torch.bfloat16   # compute dtype of the HIP path (masters fp32); network_kwargs.use_fp16 is accepted and ignored
+    # compute dtype of the HIP path (masters are always fp32): network_kwargs.compute_dtype = 'bf16' (production, default) or
+    # 'fp32' (the reference's own default precision, :205; ~20x slower).  network_kwargs.use_fp16 is accepted and ignored.
+    dtype = resolve_compute_dtype(dict(network_kwargs).get('compute_dtype'))
     use_dropout = (cfg_train_fake != 1 or cfg_eval_fake != 1)
 
     if world > 1 and rank != 0:
         torch.distributed.barrier()
     unet, vae, noise_scheduler, text_encoder, tokenizer = load_sd15(
         pretrained_model_name_or_path=pretrained_model_name_or_path, pretrained_vae_model_name_or_path=None, device=device,
-        weight_dtype=dtype, enable_xformers=enable_xformers, lora_config=None)
+        weight_dtype=dtype, enable_xformers=enable_xformers, lora_config=None, compute_dtype=dtype)
     if world > 1 and rank == 0:
         torch.distributed.barrier()
     dist.print0('Loading network completed')
@@ -165,7 +167,7 @@ def training_loop(
             net.refresh_compute_weights()
     fake_score.eval().requires_grad_(False); G.eval().requires_grad_(False)
 
-    cond = TextConditioner(tokenizer, text_encoder)
+    cond = TextConditioner(tokenizer, text_encoder, out_dtype=true_score.compute_dtype)
     step = SiDStep(G, fake_score, true_score, G_ema, noise_scheduler, opt_f, opt_g, alpha=alpha, cfg_train_fake=cfg_train_fake,
                    cfg_eval_fake=cfg_eval_fake, cfg_eval_real=cfg_eval_real, loss_scaling=loss_scaling, loss_scaling_G=loss_scaling_G,
                    batch_gpu_total=batch_gpu_total, init_timestep=init_timestep, reducer=FlatGradReducer() if world > 1 else None,

@@ -10,7 +10,8 @@ optimizer kwargs (Adam, betas (0, 0.999), eps 1e-8 / 1e-6 under --fp16; AdamW + 
 ema_halflife_kimg = ema*1000, run-directory numbering and description string, `--resume training-state-<kimg>.pt`.
 Differences (documented, not silent):
   * `--sd_model` must be a local diffusers-layout directory or `random:<arch>` (no network in this environment);
-  * `--fp16` only selects the optimizer eps; compute is bf16 MFMA with fp32 masters;
+  * `--fp16` only selects the optimizer eps; masters are fp32 and compute is bf16 MFMA, or -- with the added option
+    `--precision fp32` -- the fp32-accurate mode (the reference's own default precision, ~20x slower);
   * `--metrics` other than none / `--train_mode 0` raise: FID/CLIP evaluation is outside the hot-path scope;
   * `--data` is optional (it is the COCO image set used only by the metrics).
 """
@@ -60,6 +61,7 @@ OPTIONS = [
     (('--resolution',), dict(type=int, default=512, show_default=True, metavar='INT', help='Image resolution')),
     (('--init_timestep',), dict(type=int, default=625, show_default=True, metavar='INT', help='t_init, in [0,999]')),
     (('--fp16',), dict(type=bool, default=False, show_default=True, metavar='BOOL', help='Reference fp16 recipe (optimizer eps 1e-6)')),
+    (('--precision',), dict(type=click.Choice(['bf16', 'fp32']), default='bf16', show_default=True, help='Compute dtype of the HIP path (not a reference option)')),
     (('--ls',), dict(type=click.FloatRange(min=0, min_open=True), default=1, show_default=True, help='Loss scaling')),
     (('--lsg',), dict(type=click.FloatRange(min=0, min_open=True), default=1, show_default=True, help='Loss scaling G')),
     (('--alpha',), dict(type=click.FloatRange(min=-1000, min_open=True), default=1, show_default=True, help='L2-alpha*L1')),
@@ -105,7 +107,7 @@ def build_config(o):
     extra = {} if o.optimizer == 'adam' else dict(weight_decay=0.01)
     c.fake_score_optimizer_kwargs = EasyDict(class_name=cls, lr=o.lr, betas=[0.0, 0.999], eps=eps, **extra)
     c.g_optimizer_kwargs = EasyDict(class_name=cls, lr=o.glr, betas=[0.0, 0.999], eps=eps, **extra)
-    c.network_kwargs = EasyDict(use_fp16=o.fp16)
+    c.network_kwargs = EasyDict(use_fp16=o.fp16, compute_dtype=o.get('precision', 'bf16'))
     c.loss_kwargs = EasyDict()
     c.init_timestep = o.init_timestep
     c.total_kimg = max(int(o.duration * 1000), 1)

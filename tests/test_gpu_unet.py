@@ -315,15 +315,18 @@ def test_product_loop_matches_reference_golden(dev, golden_dir, tmp_path, name):
     finally:
         tl.load_sd15 = saved
     got, ref = np.array(losses), g['loss_values']
-    rel = np.abs(got - ref) / np.maximum(np.abs(ref), 1e-3)
-    print(f'loop_{name}: product {got} reference {ref} rel {rel}')
     assert got.shape == ref.shape
-    # bf16 compute against the reference's fp32: the bound is 2x the worst error observed on MI355X over the three goldens
-    assert rel.max() < BF16_LOOP_TOL, f'loss curve differs from the reference by {rel.max():.3g}'
+    rel_f = np.abs(got[0::2] - ref[0::2]) / np.abs(ref[0::2])
+    # The golden runs start from G = psi = phi (as the reference does): y_real - y_fake is the effect of a few +-lr Adam
+    # steps, below the resolution of bf16 weights / activations, so in bf16 the generator loss of the first iterations is
+    # a small difference of large numbers.  Its error is therefore stated relative to the scale of what is subtracted (the
+    # fake-score loss has the same units: a sum over the same elements); tests/test_gpu_fp32.py asserts 1e-3 on BOTH
+    # losses in fp32 mode.  Observed on MI355X: fake-score loss <= 8e-4; generator loss <= 3.4e-3 of the scale (kappa 4.5).
+    abs_g = np.abs(got[1::2] - ref[1::2]) / np.abs(ref[0::2])
+    print(f'loop_{name}: product {got} reference {ref} fake-loss rel {rel_f} G-loss err / scale {abs_g}')
+    assert rel_f.max() < 2e-3, f'fake-score loss curve differs from the reference by {rel_f.max():.3g}'
+    assert abs_g.max() < 7e-3, f'generator loss differs from the reference by {abs_g.max():.3g} of the loss scale'
     assert float((out['G'].flat_params - out['G_ema'].flat_params).abs().max()) > 0
-
-
-BF16_LOOP_TOL = 5e-2
 
 
 def test_reference_loop_shape_with_foreign_optimizer(dev):
