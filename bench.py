@@ -84,35 +84,46 @@ def conv_flops(*a):
     return 2.0 * B * Ho * Wo * Cout * 9 * Cin
 
 
-def cpu_baseline(arch, threads):
-    """Bounded CPU sample of the same workload with the ORACLE (kind 'port'): fp32 forwards of the SD1.5-size oracle UNet
-    on one 64x64x4 latent; one distillation image = 18 forward-equivalents."""
+def cpu_baseline(arch, threads, kappa=1.5):
+    """The reference CPU loop timed on the host cores (kind 'port': oracle/sid_ref.py::sid_iteration_ref, the restatement of
+    sid_training_loop.py:383-571 that reproduces the reference's golden loss curves, on the oracle UNet): ONE complete
+    iteration at BASELINE.json configs[0] -- full-size architecture, batch 1, 64x64x4 latents, fp32, kappa on every branch:
+    generator forward, fake-score CFG forward + backward, Adam; generator forward + backward through the fake-score and
+    teacher CFG passes, Adam, EMA.  One iteration = one image at batch 1.  Bounded: a single iteration (~1-2 min)."""
+    import copy
+
+    from oracle import sid_ref
+    from oracle.scheduler_ref import DDPMSchedulerRef
     from oracle.unet_ref import CONFIGS, UNet2DConditionRef
     torch.set_num_threads(threads)
     cfg = CONFIGS[arch]
-    with torch.device('meta'):
-        net = UNet2DConditionRef(cfg)
-    net = net.to_empty(device='cpu')
+    t_setup = time.time()
+    torch.manual_seed(0)
+    phi = UNet2DConditionRef(cfg).eval().requires_grad_(False)
+    psi, G = copy.deepcopy(phi), copy.deepcopy(phi)
+    nets = dict(true_score=phi, fake_score=psi, G=G, G_ema=copy.deepcopy(G))
+    st = dict(fake_score=[{} for _ in psi.parameters()], G=[{} for _ in G.parameters()])
+    g = torch.Generator().manual_seed(1)
+    lat, b = 64, 1
+
+    def rnd_round():
+        return dict(z=torch.randn(b, 4, lat, lat, generator=g), noise=torch.randn(b, 4, lat, lat, generator=g),
+                    t=torch.randint(20, 980, (b,), generator=g), cond=torch.randn(b, cfg.text_len, cfg.cross_attention_dim, generator=g),
+                    uncond=torch.randn(b, cfg.text_len, cfg.cross_attention_dim, generator=g))
+    inputs = dict(A=[rnd_round()], B=[rnd_round()])
+    hp = dict(alpha=1.0, kappa1=kappa, kappa2=kappa, kappa4=kappa, ls=1.0, lsg=1.0, batch_gpu_total=b, lr=1e-6, glr=1e-6,
+              betas=(0.0, 0.999), eps=1e-8, init_t=625, batch_size=b, ema_halflife_kimg=50, ema_rampup_ratio=0.05, cur_nimg=0)
+    # page-in / oneDNN primitive creation outside the timed region: one small forward
     with torch.no_grad():
-        for p in net.parameters():
-            p.normal_(0, 0.02) if p.ndim > 1 else p.zero_()
-        for m in net.modules():
-            if isinstance(m, (torch.nn.GroupNorm, torch.nn.LayerNorm)):
-                m.weight.fill_(1.0)
-        x = torch.randn(1, 4, 64, 64)
-        t = torch.tensor([625])
-        e = torch.randn(1, cfg.text_len, cfg.cross_attention_dim)
-        # bounded sample (~10-30 s): a short warm-up on a 16x16 latent (page-in, oneDNN primitive creation), then timed
-        # full-size forwards until ~15 s have been spent (at least one)
-        net(x[:, :, :16, :16], t, encoder_hidden_states=e)
-        n, t0 = 0, time.time()
-        while n < 1 or (time.time() - t0 < 15 and n < 6):
-            net(x, t, encoder_hidden_states=e)
-            n += 1
-        dt = (time.time() - t0) / n
-    return dict(value=1.0 / (18.0 * dt), unit='images/s', cores=threads, kind='port',
-                sample=f'{n} fp32 forwards of the {arch} oracle UNet (oracle/unet_ref.py) on 1 sample at 64x64x4, {dt:.2f} s each; '
-                       f'1 image = 18 forward-equivalents (5 fwd + 4 bwd passes, CFG on every branch)')
+        phi(torch.randn(1, 4, 16, 16), torch.tensor([625]), encoder_hidden_states=inputs['A'][0]['cond'])
+    t_setup = time.time() - t_setup
+    t0 = time.time()
+    out = sid_ref.sid_iteration_ref(nets, st, DDPMSchedulerRef(), inputs, hp)
+    dt = time.time() - t0
+    return dict(value=b / dt, unit='images/s', cores=threads, kind='port',
+                sample=f'1 full SiD-LSG iteration (fake-score step + generator step + Adam + EMA) of the fp32 CPU restatement of the '
+                       f'reference loop (oracle/sid_ref.py on oracle/unet_ref.py), {arch} full size, batch 1, 64x64x4 latents, kappa={kappa}: '
+                       f'{dt:.1f} s on {threads} threads (setup {t_setup:.0f} s not timed); loss_fake {out["loss_fake"]:.1f}')
 
 
 def main():
@@ -263,7 +274,7 @@ def main():
     if not args.no_cpu_baseline and world == 1:
         # torch's CPU backend degrades badly when oversubscribed on many-core hosts (256 threads: 160 s per forward);
         # 32 threads is the measured sweet spot class for one fp32 conv-heavy forward -> cores = threads actually used
-        out['cpu_baseline'] = cpu_baseline(args.arch, min(os.cpu_count() or 1, 32))
+        out['cpu_baseline'] = cpu_baseline(args.arch, min(os.cpu_count() or 1, 32), kappa=args.kappa)
     print(json.dumps(out), flush=True)
 
 

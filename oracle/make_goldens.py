@@ -9,6 +9,11 @@ Every file records the weight checksum of the seeded random nets it was made wit
   loop_*.npz   the UNMODIFIED reference training_loop (training/sid_training_loop.py:148-672)
                run for a few iterations on CPU: per-step loss values and final parameter
                checksums: pins A1, A2, A7-A10, A13 (RNG order, accumulation, Adam, EMA).
+  networks_blocks.npz  the reference's own in-tree network primitives (training/networks.py: GroupNorm :96, AttentionOp
+               :113, UNetBlock :134, Conv2d :47, Linear :30) run forward + backward on seeded inputs: the only
+               reference-held arithmetic for GroupNorm+SiLU+conv3x3+time-embedding-add+1x1-shortcut (= the SD
+               ResnetBlock2D when adaptive_scale=False) and for softmax(QK^T/sqrt(d))V attention:
+               pins those pieces of row A5 for both the oracle UNet layers and the HIP ops.
   bias_act.npz reference torch_utils/ops/bias_act.py::_bias_act_ref (+ autograd grads).
   sampler.npz  reference torch_utils/misc.py::InfiniteSampler order.
 """
@@ -128,6 +133,46 @@ def gen_bias_act():
     print('bias_act done')
 
 
+def gen_blocks():
+    """training/networks.py::UNetBlock(adaptive_scale=False) forward/backward with every parameter seeded non-trivially
+    (the reference zero-initialises conv1 / proj).  Cases: channel change + 1x1 skip conv; identity skip; + attention with
+    head dim 40 (the SD1.5 64x64-stage head dim) and with head dim 64 (SD2.1)."""
+    ref_harness.import_reference()
+    import training.networks as N
+    out = {}
+    for tag, cin, cout, emb, attn, heads, hw in (('res_proj', 32, 64, 48, False, None, 12), ('res_id', 64, 64, 48, False, None, 8),
+                                                 ('attn40', 32, 80, 48, True, 2, 12), ('attn64', 32, 64, 32, True, 1, 10)):
+        g = torch.Generator().manual_seed({'res_proj': 1, 'res_id': 2, 'attn40': 3, 'attn64': 4}[tag])
+        blk = N.UNetBlock(in_channels=cin, out_channels=cout, emb_channels=emb, attention=attn, num_heads=heads, adaptive_scale=False)
+        with torch.no_grad():
+            for n, p in blk.named_parameters():
+                if n.startswith('norm'):
+                    p.copy_((1.0 if n.endswith('weight') else 0.0) + 0.3 * torch.randn(p.shape, generator=g))
+                elif n == 'qkv.bias':
+                    p.zero_()                                   # SD's to_q / to_k / to_v have no bias
+                elif n.endswith('bias'):
+                    p.copy_(0.2 * torch.randn(p.shape, generator=g))
+                else:
+                    fan_in = p[0].numel()
+                    p.copy_(torch.randn(p.shape, generator=g) * fan_in ** -0.5)
+        x = torch.randn(2, cin, hw, hw, generator=g).requires_grad_()
+        # the SD ResnetBlock2D feeds silu(temb) to its projection; UNetBlock takes the projection input directly
+        raw = torch.randn(2, emb, generator=g)
+        out[f'{tag}_emb_raw'] = raw.numpy()
+        e = torch.nn.functional.silu(raw).requires_grad_()
+        y = blk(x, e)
+        dy = torch.randn(y.shape, generator=g)
+        y.backward(dy)
+        out[f'{tag}_x'], out[f'{tag}_emb'], out[f'{tag}_y'], out[f'{tag}_dy'] = x.detach().numpy(), e.detach().numpy(), y.detach().numpy(), dy.numpy()
+        out[f'{tag}_dx'], out[f'{tag}_demb'] = x.grad.numpy(), e.grad.numpy()
+        out[f'{tag}_groups'] = np.array([blk.norm0.num_groups, blk.norm1.num_groups, blk.norm2.num_groups if attn else 0, heads or 0])
+        for n, p in blk.named_parameters():
+            out[f'{tag}_p_{n}'] = p.detach().numpy()
+            out[f'{tag}_g_{n}'] = p.grad.numpy()
+    np.savez_compressed(os.path.join(OUT, 'networks_blocks.npz'), **out)
+    print('blocks done', sorted(k for k in out if k.endswith('_y')))
+
+
 def gen_sampler():
     ref = ref_harness.import_reference()
     out = {}
@@ -141,7 +186,9 @@ def gen_sampler():
 if __name__ == '__main__':
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ['glue', 'loops', 'bias_act', 'sampler']
+    which = sys.argv[1:] or ['glue', 'loops', 'bias_act', 'sampler', 'blocks']
+    if 'blocks' in which:
+        gen_blocks()
     if 'glue' in which:
         gen_glue()
     if 'bias_act' in which:

@@ -276,7 +276,9 @@ def test_unet_forward_backward_f32(dev, cfg_name, lat):
     worst = 0.0
     for name, p in hip.named_parameters():
         gr = ref_p[name].grad
-        err = ((p.grad.detach().float().cpu() - gr).norm() / (gr.norm() + 1e-5)).item()
+        # + 1e-3: gradients that are exactly zero in exact arithmetic (q / k projections of a 1-token attention at the 1x1
+        # mid block of the lat=8 case) are ~1e-7 rounding noise on both sides
+        err = ((p.grad.detach().float().cpu() - gr).norm() / (gr.norm() + 1e-3)).item()
         worst = max(worst, err)
         assert err < 1e-3, f'param grad {name}: rel l2 {err:.3g}'
     print(f'{cfg_name} fp32: fwd {e:.2e}  dx {e2:.2e}  worst param-grad rel l2 {worst:.2e}')

@@ -216,7 +216,8 @@ def test_norm_fork_fuses_residual_gradient(dev, kind):
     else:
         nr = F.layer_norm(xr, (C,), gam, bet, 1e-5)
     (nr * 0.5 + xr * 2.0).backward(dy.float())
-    gm, bm = torch.nn.Parameter(gam.to(dev)), torch.nn.Parameter(bet.to(dev))
+    # (no gradient buffers bound: the affine parameters do not require grad here)
+    gm, bm = torch.nn.Parameter(gam.to(dev), requires_grad=False), torch.nn.Parameter(bet.to(dev), requires_grad=False)
     xd = x.to(dev).requires_grad_()
     if kind == 'gn':
         y, xk = ops.group_norm(xd, gm, bm, 32, 1e-5, True, fork=True)

@@ -79,3 +79,65 @@ def test_scheduler_constants():
     assert abs(float(ac[625]) - 0.13776892) < 2e-7
     assert abs(float(ac[20]) - 0.98131430) < 2e-7
     assert abs(float(ac[979]) - 0.00591277) < 2e-7
+
+
+def _load_ref_block(g, tag):
+    """Parameters / tensors of one reference UNetBlock case of networks_blocks.npz as torch tensors."""
+    t = {k[len(tag) + 1:]: torch.from_numpy(g[k]) for k in g.files if k.startswith(tag + '_')}
+    return t, [int(v) for v in g[f'{tag}_groups']]
+
+
+def qkv_rows_to_sd(w, heads):
+    """reference UNetBlock qkv rows are (head, channel, {q,k,v}) interleaved (networks.py:177); SD's to_q|to_k|to_v are
+    ({q,k,v}, head, channel)."""
+    c3 = w.shape[0]
+    d = c3 // (3 * heads)
+    return w.reshape(heads, d, 3, -1).permute(2, 0, 1, 3).reshape(c3, -1)
+
+
+@pytest.mark.parametrize('tag', ['res_proj', 'res_id', 'attn40', 'attn64'])
+def test_unet_layers_match_reference_networks_py(golden_dir, tag):
+    """Row A5 pieces that the reference DOES hold in-tree: training/networks.py UNetBlock (GroupNorm :96 + SiLU + Conv2d :47
+    + Linear :30 + 1x1 skip + AttentionOp :113), run by oracle/make_goldens.py::gen_blocks.  The oracle's ResnetBlock2D /
+    Attention layers (oracle/unet_ref.py, restating diffusers) must reproduce it with the same weights: forward,
+    input gradients and every parameter gradient."""
+    from oracle.unet_ref import Attention, ResnetBlock2D
+    import torch.nn as nn
+    import torch.nn.functional as F
+    g = _load(golden_dir, 'networks_blocks.npz')
+    t, (g0, g1, g2, heads) = _load_ref_block(g, tag)
+    cin, cout, emb = t['x'].shape[1], t['y'].shape[1], t['emb'].shape[1]
+    blk = ResnetBlock2D(cin, cout, emb, g0, 1e-5)
+    blk.norm2 = nn.GroupNorm(g1, cout, eps=1e-5)
+    names = {'norm1': 'norm0', 'conv1': 'conv0', 'time_emb_proj': 'affine', 'norm2': 'norm1', 'conv2': 'conv1', 'conv_shortcut': 'skip'}
+    with torch.no_grad():
+        for n, p in blk.named_parameters():
+            mod, leaf = n.rsplit('.', 1)
+            p.copy_(t[f'p_{names[mod]}.{leaf}'])
+    x, raw = t['x'].clone().requires_grad_(), t['emb_raw'].clone().requires_grad_()
+    y = blk(x, raw)
+    attn = None
+    if heads:
+        norm = nn.GroupNorm(g2, cout, eps=1e-5)
+        attn = Attention(cout, heads)
+        with torch.no_grad():
+            norm.weight.copy_(t['p_norm2.weight']); norm.bias.copy_(t['p_norm2.bias'])
+            w = qkv_rows_to_sd(t['p_qkv.weight'].flatten(1), heads)
+            attn.to_q.weight.copy_(w[:cout]); attn.to_k.weight.copy_(w[cout:2 * cout]); attn.to_v.weight.copy_(w[2 * cout:])
+            attn.to_out[0].weight.copy_(t['p_proj.weight'].flatten(1)); attn.to_out[0].bias.copy_(t['p_proj.bias'])
+        B, C, H, W = y.shape
+        tok = norm(y).flatten(2).transpose(1, 2)
+        y = y + attn(tok).transpose(1, 2).reshape(B, C, H, W)
+    np.testing.assert_allclose(y.detach().numpy(), g[f'{tag}_y'], rtol=2e-4, atol=2e-5)
+    y.backward(t['dy'])
+    np.testing.assert_allclose(x.grad.numpy(), g[f'{tag}_dx'], rtol=2e-4, atol=2e-5)
+    # d/d raw = d/d emb * silu'(raw)
+    s = torch.sigmoid(t['emb_raw'])
+    np.testing.assert_allclose(raw.grad.numpy(), (t['demb'] * s * (1 + t['emb_raw'] * (1 - s))).numpy(), rtol=2e-4, atol=2e-5)
+    for n, p in blk.named_parameters():
+        mod, leaf = n.rsplit('.', 1)
+        np.testing.assert_allclose(p.grad.numpy(), g[f'{tag}_g_{names[mod]}.{leaf}'].reshape(p.shape), rtol=5e-4, atol=5e-5, err_msg=n)
+    if heads:
+        gw = torch.cat([attn.to_q.weight.grad, attn.to_k.weight.grad, attn.to_v.weight.grad])
+        np.testing.assert_allclose(gw.numpy(), qkv_rows_to_sd(t['g_qkv.weight'].flatten(1), heads).numpy(), rtol=5e-4, atol=5e-5)
+        np.testing.assert_allclose(attn.to_out[0].weight.grad.numpy(), g[f'{tag}_g_proj.weight'].reshape(cout, cout), rtol=5e-4, atol=5e-5)
