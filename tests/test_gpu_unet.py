@@ -116,6 +116,13 @@ def test_glue_matches_reference_golden(dev, golden_dir):
                     assert e < 4e-2, f'denoise {cfg} b{b} k{kappa} x0{px0}: {e}'
 
 
+# Loss tolerances of the bf16 production path against the fp32 oracle: 2x the worst error observed on MI355X
+# (tiny: 5e-4 / 2e-3; SD1.5 full size: 4e-5 / 9e-4 at kappa 1.5, 3.5e-4 / 3e-3 at kappa 4.5 -- guidance multiplies the bf16
+# difference of the two CFG branches).  The fp32 mode is held to north_star's 1e-3 (observed ~1e-6).
+TOL_LOSS = {BF16: (2e-3, 6e-3), F32: (1e-3, 1e-3)}
+TOL_SIGN = {BF16: 0.97, F32: 0.999}
+
+
 @pytest.mark.parametrize('kappa,alpha', [(1.5, 1.0), (1.0, 1.2)])
 def test_sid_iteration_matches_oracle(dev, kappa, alpha):
     """Two full iterations (fake-score step + generator step, 2 accumulation rounds, Adam, EMA) vs oracle/sid_ref.py."""
@@ -127,13 +134,13 @@ def test_sid_iteration_matches_oracle(dev, kappa, alpha):
     os.environ.get('SIDLSG_FULLSIZE', '0') != '1', reason='a second ~2 min CPU oracle run: set SIDLSG_FULLSIZE=1'))])
 def test_sid_iteration_full_size_config1(dev, kappa):
     """BASELINE.json configs[0]: the reference's own CPU-runnable case -- full SD1.5 UNet (859.5 M parameters), kappa = 1.5,
-    batch 1, 64x64x4 latents; one complete iteration of the bf16 HIP path against the fp32 CPU oracle.  kappa = 4.5 is the
-    guidance scale of configs[2]."""
+    batch 1, 64x64x4 latents; one complete iteration against the fp32 CPU oracle (run once), in BOTH compute modes of the HIP
+    path: bf16 (production) and fp32 (north_star's 1e-3 bound).  kappa = 4.5 is the guidance scale of configs[2]."""
     _iteration_parity(dev, 'sd15', lat=64, b=1, rounds=1, lr=1e-6, kappa=kappa, alpha=1.0, iters=1,
-                      ema_names=('conv_in.weight', 'conv_out.bias'))
+                      ema_names=('conv_in.weight', 'conv_out.bias'), modes=(BF16, F32))
 
 
-def _iteration_parity(dev, cfg_name, lat, b, rounds, lr, kappa, alpha, iters, ema_names):
+def _iteration_parity(dev, cfg_name, lat, b, rounds, lr, kappa, alpha, iters, ema_names, modes=(BF16,)):
     from oracle import fixtures, sid_ref
     from oracle.scheduler_ref import DDPMSchedulerRef
     from oracle.unet_ref import CONFIGS as RC
@@ -147,15 +154,16 @@ def _iteration_parity(dev, cfg_name, lat, b, rounds, lr, kappa, alpha, iters, em
     G_r = copy.deepcopy(phi_r)
     Gema_r = copy.deepcopy(G_r)
     nets_r = dict(true_score=phi_r, fake_score=psi_r, G=G_r, G_ema=Gema_r)
-
-    def hipnet(r):
-        return HipUNet2DCondition(CONFIGS[cfg_name]).materialize(dev, source=r.state_dict())
-    phi, psi, G = hipnet(phi_r), hipnet(psi_r), hipnet(G_r)
-    G_ema = hipnet(G_r)
-    opt_f = FusedAdamEMA(psi.parameters(), lr=lr, betas=(0.0, 0.999), eps=1e-8)
-    opt_g = FusedAdamEMA(G.parameters(), lr=lr, betas=(0.0, 0.999), eps=1e-8)
-    step = SiDStep(G, psi, phi, G_ema, DDPMScheduler().to(dev), opt_f, opt_g, alpha=alpha, cfg_train_fake=kappa,
-                   cfg_eval_fake=kappa, cfg_eval_real=kappa, batch_gpu_total=b * rounds, init_timestep=625)
+    hip = {}
+    for cd in modes:
+        def hipnet(r):
+            return HipUNet2DCondition(CONFIGS[cfg_name], compute_dtype=cd).materialize(dev, source=r.state_dict())
+        phi, psi, G, G_ema = hipnet(phi_r), hipnet(psi_r), hipnet(G_r), hipnet(G_r)
+        opt_f = FusedAdamEMA(psi.parameters(), lr=lr, betas=(0.0, 0.999), eps=1e-8)
+        opt_g = FusedAdamEMA(G.parameters(), lr=lr, betas=(0.0, 0.999), eps=1e-8)
+        step = SiDStep(G, psi, phi, G_ema, DDPMScheduler().to(dev), opt_f, opt_g, alpha=alpha, cfg_train_fake=kappa,
+                       cfg_eval_fake=kappa, cfg_eval_real=kappa, batch_gpu_total=b * rounds, init_timestep=625)
+        hip[cd] = dict(step=step, psi=psi, G=G, G_ema=G_ema)
     st = dict(fake_score=[{} for _ in psi_r.parameters()], G=[{} for _ in G_r.parameters()])
     hp = dict(alpha=alpha, kappa1=kappa, kappa2=kappa, kappa4=kappa, ls=1.0, lsg=1.0, batch_gpu_total=b * rounds, lr=lr, glr=lr,
               betas=(0.0, 0.999), eps=1e-8, init_t=625, batch_size=b * rounds, ema_halflife_kimg=50, ema_rampup_ratio=0.05)
@@ -171,35 +179,40 @@ def _iteration_parity(dev, cfg_name, lat, b, rounds, lr, kappa, alpha, iters, em
                                        uncond=torch.randn(1, cfg.text_len, cfg.cross_attention_dim, generator=gen).to(BF16).float().expand(b, -1, -1).contiguous()))
         hp['cur_nimg'] = cur_nimg
         out_r = sid_ref.sid_iteration_ref(nets_r, st, DDPMSchedulerRef(), inputs, hp)
-        dinp = {ph: [{k: (v.to(dev).to(BF16).contiguous() if k in ('cond', 'uncond') else v.to(dev)) for k, v in r.items()}
-                     for r in inputs[ph]] for ph in inputs}
         beta = sid_ref.ema_beta_ref(b * rounds, cur_nimg, 50, 0.05)
-        lf, lg = step.iteration(dinp, ema_beta=beta)
-        print(f'iter {it}: loss_fake {float(lf):.5f} vs {out_r["loss_fake"]:.5f}; loss_G {float(lg):.5f} vs {out_r["loss_G"]:.5f}')
-        assert abs(float(lf) - out_r['loss_fake']) <= 2e-2 * abs(out_r['loss_fake'])
-        assert abs(float(lg) - out_r['loss_G']) <= 5e-2 * abs(out_r['loss_G']) + 1e-3
+        for cd in modes:
+            dinp = {ph: [{k: (v.to(dev).to(cd).contiguous() if k in ('cond', 'uncond') else v.to(dev)) for k, v in r.items()}
+                         for r in inputs[ph]] for ph in inputs}
+            lf, lg = hip[cd]['step'].iteration(dinp, ema_beta=beta)
+            rf = abs(float(lf) - out_r['loss_fake']) / abs(out_r['loss_fake'])
+            rg = abs(float(lg) - out_r['loss_G']) / abs(out_r['loss_G'])
+            print(f'{cfg_name} kappa {kappa} iter {it} [{cd}]: loss_fake {float(lf):.5f} vs {out_r["loss_fake"]:.5f} (rel {rf:.1e}); '
+                  f'loss_G {float(lg):.5f} vs {out_r["loss_G"]:.5f} (rel {rg:.1e})')
+            assert rf <= TOL_LOSS[cd][0], f'fake-score loss [{cd}]: rel {rf:.3g}'
+            assert rg <= TOL_LOSS[cd][1], f'generator loss [{cd}]: rel {rg:.3g}'
         cur_nimg += b * rounds
     # parameters: Adam(beta1=0) moves every weight by ~lr*sign(g); compare the UPDATE direction statistically
-    for net, net_r, name in ((psi, psi_r, 'fake_score'), (G, G_r, 'G')):
-        agree, total = 0, 0
-        init = fixtures.make_unet(cfg_name, seed=77 if name == 'fake_score' else 1234)
-        by_name_r, by_name_0 = dict(net_r.named_parameters()), dict(init.named_parameters())
-        for n, p in net.named_parameters():
-            pr, p0 = by_name_r[n], by_name_0[n]
-            du, dr = (p.detach().cpu() - p0).flatten(), (pr.detach() - p0).flatten()
-            big = dr.abs() > 0.5 * lr          # ignore entries whose reference gradient is ~0 (sign is noise there)
-            agree += int((torch.sign(du[big]) == torch.sign(dr[big])).sum())
-            total += int(big.sum())
-        frac = agree / max(total, 1)
-        print(f'{name}: update-sign agreement {frac:.4f} over {total} weights')
-        assert frac > 0.93
-    ema_r = dict(Gema_r.named_parameters())
-    for n, p in G_ema.named_parameters():
-        if n in ema_names:
-            e, _ = rel_err(p, ema_r[n])
-            # max-norm relative error; the only source of difference is the ~0.1 % of weights whose +-lr Adam step
-            # (beta1 = 0) has the opposite sign because their gradient is ~0
-            assert e < 2e-3, f'EMA weights {n}'
+    init = {name: dict(fixtures.make_unet(cfg_name, seed=seed).named_parameters()) for name, seed in (('fake_score', 77), ('G', 1234))}
+    for cd in modes:
+        for net, net_r, name in ((hip[cd]['psi'], psi_r, 'fake_score'), (hip[cd]['G'], G_r, 'G')):
+            agree, total = 0, 0
+            by_name_r, by_name_0 = dict(net_r.named_parameters()), init[name]
+            for n, p in net.named_parameters():
+                pr, p0 = by_name_r[n], by_name_0[n]
+                du, dr = (p.detach().cpu() - p0).flatten(), (pr.detach() - p0).flatten()
+                big = dr.abs() > 0.5 * lr          # ignore entries whose reference gradient is ~0 (sign is noise there)
+                agree += int((torch.sign(du[big]) == torch.sign(dr[big])).sum())
+                total += int(big.sum())
+            frac = agree / max(total, 1)
+            print(f'{name} [{cd}]: update-sign agreement {frac:.4f} over {total} weights')
+            assert frac > TOL_SIGN[cd]
+        ema_r = dict(Gema_r.named_parameters())
+        for n, p in hip[cd]['G_ema'].named_parameters():
+            if n in ema_names:
+                e, _ = rel_err(p, ema_r[n])
+                # max-norm relative error; the only source of difference is the ~0.1 % of weights whose +-lr Adam step
+                # (beta1 = 0) has the opposite sign because their gradient is ~0
+                assert e < 2e-3, f'EMA weights {n}'
 
 
 def test_training_loop_end_to_end(dev, tmp_path):
@@ -420,8 +433,8 @@ def test_reference_loop_shape_with_foreign_optimizer(dev):
             p_ema.copy_(p.detach().lerp(p_ema, beta))
         cur_nimg += b * rounds
         print(f'iter {it}: loss_fake {float(loss_f):.5f} vs {out_r["loss_fake"]:.5f}; loss_G {float(loss_g):.5f} vs {out_r["loss_G"]:.5f}')
-        assert abs(float(loss_f) - out_r['loss_fake']) <= 2e-2 * abs(out_r['loss_fake'])
-        assert abs(float(loss_g) - out_r['loss_G']) <= 5e-2 * abs(out_r['loss_G']) + 1e-3
+        assert abs(float(loss_f) - out_r['loss_fake']) <= TOL_LOSS[BF16][0] * abs(out_r['loss_fake'])
+        assert abs(float(loss_g) - out_r['loss_G']) <= TOL_LOSS[BF16][1] * abs(out_r['loss_G'])
     # the foreign optimizer moved the weights in the same direction as the oracle's Adam
     for net, net_r, seed in ((fake_score, psi_r, 77), (G, G_r, 1234)):
         init = dict(fixtures.make_unet(cfg_name, seed=seed).named_parameters())
