@@ -48,8 +48,12 @@ int sidlsg_conv3x3_bf16(const void* X, int ldx, const void* W, void* Y, int ldc,
 
 /* Optional fp32 scratch (device memory owned by the caller): per-split partial-sum slabs for split-K GEMMs/convs with few
  * output tiles and long K (8x8 / 16x16 stages) and for the pixel-split weight gradients (without it they fall back to
- * fp32 atomics, ~2-3x slower on MI355X).  Global per process; calls that use it must be on one stream.  NULL disables. */
+ * fp32 atomics, ~2-3x slower on MI355X).  Default for every stream without a private workspace (below): launches sharing
+ * it must be ordered on one stream.  NULL disables. */
 int sidlsg_set_workspace(void* ptr, long long bytes);
+/* A private workspace for launches on `stream` (ptr = NULL removes it; at most 4): needed when two streams run
+ * contractions concurrently -- the teacher beside the fake-score network in phase B of the step. */
+int sidlsg_set_stream_workspace(void* stream, void* ptr, long long bytes);
 
 /* weight gradients (autograd of the two ops above in the reference: loss.backward(),
  * sid_training_loop.py:450,533).  dW[N][K] += dY[M][N]^T A[M][K] in fp32 (pixel-split partial sums, reduced through the

@@ -113,6 +113,52 @@ def gen_loops():
               lr=1e-4, glr=1e-4, resolution=128)
 
 
+LOOP2_KW = dict(iterations=3, batch_size=4, batch_gpu=1, seed=7, alpha=1.0, kappa=(1.5, 1.5, 1.5), lr=1e-4, glr=1e-4, resolution=128)
+
+
+def _loop2_worker(prefix):
+    """One rank of the 2-rank reference run (launched by torch.distributed.run): the UNMODIFIED reference training_loop with
+    world_size 2 on gloo -- DistributedDataParallel gradient averaging, `misc.ddp_sync` no_sync rounds (2 accumulation
+    rounds per rank), rank-strided prompt stream, per-rank seeds (sid_training_loop.py:238, 274, 316-323, 416, 487)."""
+    torch.set_num_threads(4)
+    torch.distributed.init_process_group('gloo')
+    rank = torch.distributed.get_rank()
+    with tempfile.TemporaryDirectory() as tmp:
+        pdir = os.path.join(tmp, 'prompts')
+        os.makedirs(pdir)
+        with open(os.path.join(pdir, 'aesthetics_6_plus.txt'), 'wt') as f:
+            f.write('\n'.join(PROMPTS) + '\n')
+        run_dir = os.path.join(tmp, 'run')
+        os.makedirs(run_dir)
+        res = ref_harness.run_reference_training_loop(lambda: fixtures.factory('tiny'), pdir, run_dir, **LOOP2_KW)
+    np.savez(f'{prefix}.rank{rank}.npz', loss_names=np.array([n for n, _ in res['losses']]),
+             loss_values=np.array([v for _, v in res['losses']], dtype=np.float64),
+             G_conv_in_w=res['G_params'][0].numpy(), fake_conv_in_w=res['fake_score_params'][0].numpy(),
+             G_last_b=res['G_params'][-1].numpy(), G_checksum=np.array(fixtures.checksum(res['G_params'])),
+             fake_score_checksum=np.array(fixtures.checksum(res['fake_score_params'])))
+    torch.distributed.destroy_process_group()
+
+
+def gen_loop_2rank():
+    """tests/golden/loop2_k15_a1.npz: per-rank loss curves + final weights of a 2-rank run of the reference loop."""
+    import subprocess
+    with tempfile.TemporaryDirectory() as tmp:
+        prefix = os.path.join(tmp, 'loop2')
+        env = dict(os.environ, PYTHONPATH=ROOT)
+        subprocess.check_call([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+                               '--master-port', '29547', os.path.abspath(__file__), '_loop2_worker', prefix], env=env, cwd=ROOT)
+        r0, r1 = np.load(f'{prefix}.rank0.npz'), np.load(f'{prefix}.rank1.npz')
+        assert np.array_equal(r0['G_conv_in_w'], r1['G_conv_in_w']), 'ranks must end with identical weights'
+        out = dict(cfg='tiny', prompts=np.array(PROMPTS), loss_names=r0['loss_names'], loss_values_rank0=r0['loss_values'],
+                   loss_values_rank1=r1['loss_values'], G_conv_in_w=r0['G_conv_in_w'], fake_conv_in_w=r0['fake_conv_in_w'],
+                   G_last_b=r0['G_last_b'], G_checksum=r0['G_checksum'], fake_score_checksum=r0['fake_score_checksum'],
+                   weight_checksum=np.array(fixtures.checksum(fixtures.make_unet('tiny'))))
+        for k, v in LOOP2_KW.items():
+            out['kw_' + k] = np.array(v)
+        np.savez_compressed(os.path.join(OUT, 'loop2_k15_a1.npz'), **out)
+        print('loop2', out['loss_values_rank0'], out['loss_values_rank1'])
+
+
 def gen_bias_act():
     ref = ref_harness.import_reference()
     g = torch.Generator().manual_seed(3)
@@ -186,7 +232,12 @@ def gen_sampler():
 if __name__ == '__main__':
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ['glue', 'loops', 'bias_act', 'sampler', 'blocks']
+    if len(sys.argv) > 2 and sys.argv[1] == '_loop2_worker':
+        _loop2_worker(sys.argv[2])
+        sys.exit(0)
+    which = sys.argv[1:] or ['glue', 'loops', 'bias_act', 'sampler', 'blocks', 'loop2']
+    if 'loop2' in which:
+        gen_loop_2rank()
     if 'blocks' in which:
         gen_blocks()
     if 'glue' in which:

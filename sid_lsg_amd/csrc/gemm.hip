@@ -388,8 +388,20 @@ __global__ void gemm_finish_kernel(GemmParams p) {
     }
 }
 
-static float* g_ws = nullptr;          // set by sidlsg_set_workspace (host-allocated device memory, zero-initialised)
-static long long g_ws_bytes = 0;
+// Split-K / pixel-split scratch.  The default workspace (sidlsg_set_workspace) serves every stream that has no workspace
+// of its own; a stream that runs contractions CONCURRENTLY with another one (the teacher evaluated beside the fake-score
+// network, sid_step.py) registers a private one with sidlsg_set_stream_workspace, so the two never share slabs.
+struct WsSlot { hipStream_t stream; float* ptr; long long bytes; };
+static float* g_ws_default = nullptr;
+static long long g_ws_default_bytes = 0;
+static WsSlot g_ws_slots[4] = {};
+static int g_ws_nslots = 0;
+struct Ws { float* ptr; long long bytes; };
+static Ws ws_for(hipStream_t s) {
+    for (int i = 0; i < g_ws_nslots; i++)
+        if (g_ws_slots[i].stream == s) return {g_ws_slots[i].ptr, g_ws_slots[i].bytes};
+    return {g_ws_default, g_ws_default_bytes};
+}
 
 // ---------------------------------------------------------------------------------------------
 // Direct-to-LDS (buffer_load ... lds) kernels.  (A 256 x 160 / 8-wave / 3-stage-ring variant "v2" and a
@@ -682,6 +694,9 @@ static int dispatch_gemm(const GemmParams& p, hipStream_t s) {
     {
         const long long t = tiles(128, n160 ? 160 : 128);
         const int nk = (p.K + BK - 1) / BK;
+        const Ws w = ws_for(s);
+        float* const g_ws = w.ptr;
+        const long long g_ws_bytes = w.bytes;
         if (t < 384 && nk >= 32 && (p.N & 3) == 0 && g_ws && (long long)p.M * p.N * 8 <= g_ws_bytes) {
             int splits = (int)((512 + t - 1) / t);
             const long long cap = g_ws_bytes / ((long long)p.M * p.N * 4);
@@ -1172,6 +1187,9 @@ static int launch_wgrad(WgradParams p, hipStream_t s) {
     mps = (mps + WG_MB - 1) / WG_MB * WG_MB;
     splits = (p.M + mps - 1) / mps;
     const long long nk = (long long)p.N * p.K;
+    const Ws wsl = ws_for(s);
+    float* const g_ws = wsl.ptr;
+    const long long g_ws_bytes = wsl.bytes;
     if (splits > 1 && g_ws) {                       // cap the split count by the slab space
         const long long cap = g_ws_bytes / (nk * 4);
         if (cap < 2) { p.ws = nullptr; }
@@ -1212,7 +1230,22 @@ extern "C" {
 // caller, used by every later sidlsg_gemm_bf16 / sidlsg_conv3x3_bf16 call of this process (one stream at a time).
 // Pass NULL/0 to disable split-K.
 int sidlsg_set_workspace(void* ptr, long long bytes) {
-    g_ws = (float*)ptr; g_ws_bytes = ptr ? bytes : 0;
+    g_ws_default = (float*)ptr; g_ws_default_bytes = ptr ? bytes : 0;
+    return SIDLSG_OK;
+}
+
+// Private scratch for one stream (see WsSlot).  ptr = NULL removes the entry.  At most 4 streams.
+int sidlsg_set_stream_workspace(void* stream, void* ptr, long long bytes) {
+    hipStream_t s = (hipStream_t)stream;
+    for (int i = 0; i < g_ws_nslots; i++)
+        if (g_ws_slots[i].stream == s) {
+            if (ptr) { g_ws_slots[i].ptr = (float*)ptr; g_ws_slots[i].bytes = bytes; }
+            else { g_ws_slots[i] = g_ws_slots[--g_ws_nslots]; }
+            return SIDLSG_OK;
+        }
+    if (!ptr) return SIDLSG_OK;
+    if (g_ws_nslots >= 4) return SIDLSG_EINVAL;
+    g_ws_slots[g_ws_nslots++] = {s, (float*)ptr, bytes};
     return SIDLSG_OK;
 }
 

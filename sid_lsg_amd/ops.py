@@ -75,6 +75,19 @@ def ensure_workspace(device, nbytes=512 << 20):
     return _workspace[key]
 
 
+_stream_ws = {}
+
+
+def ensure_stream_workspace(stream, nbytes=256 << 20):
+    """Private split-K scratch for a side stream that runs contractions concurrently with the main one."""
+    key = stream.cuda_stream
+    if key not in _stream_ws:
+        ws = torch.empty(nbytes // 4, device=stream.device, dtype=F32)
+        lib.sidlsg_set_stream_workspace(key, ws.data_ptr(), ws.numel() * 4)
+        _stream_ws[key] = ws
+    return _stream_ws[key]
+
+
 # raw launches
 def gemm(a, w16, out=None, bias=None, res=None, rowvec=None, rows_per_batch=1, alpha=1.0, out_f32=False, lda=None):
     """C[M,N] = alpha*A[M,K] W[N,K]^T + bias + rowvec[m//rpb] + res"""

@@ -33,6 +33,13 @@ class SiDStep:
         self.init_timestep = int(init_timestep)
         self.reducer, self.world = reducer, world_size
         self.overlap_g = os.environ.get('SIDLSG_OVERLAP_G', '1') != '0'    # A/B switch; results are identical either way
+        # Phase B evaluates the teacher and the fake-score network on the SAME noisy CFG batch (identical layer shapes): the
+        # teacher runs on a second HIP stream (forward, and through autograd its data-gradient backward), so the two
+        # networks' kernels share the chip wherever one of them cannot fill 256 CUs (16x16 / 8x8 stages, split-K tails).
+        self.side = None
+        if os.environ.get('SIDLSG_TEACHER_STREAM', '0') == '1' and torch.cuda.is_available():
+            self.side = torch.cuda.Stream()
+            ops.ensure_stream_workspace(self.side)
         opt_fake.grad_scale = opt_G.grad_scale = 1.0 / world_size     # DDP mean, folded into the optimizer kernel
         opt_fake.attach(ema=None, w16=fake_score.flat_w16)
         opt_G.attach(ema=(G_ema.flat_params if (G_ema is not None and G_ema is not G) else None), w16=G.flat_w16)
@@ -80,10 +87,21 @@ class SiDStep:
         k4 = self.k4 if guided else 1.0
         # teacher first: neither G's forward nor phi's reads psi, so a pending psi gradient exchange / optimizer step
         # (before_fake_eval) overlaps with them.  y_real and y_fake are independent: the order does not change the math.
-        y_real = hip_denoise(self.phi, prep, k4, predict_x0=True)                   # :503-506
+        if self.side is None:
+            y_real = hip_denoise(self.phi, prep, k4, predict_x0=True)               # :503-506
+        else:
+            cur = torch.cuda.current_stream()
+            self.side.wait_stream(cur)
+            for t in (prep.xin, prep.xt, prep.s0, prep.s1, prep.ctx, prep.tt):
+                t.record_stream(self.side)
+            with torch.cuda.stream(self.side):
+                y_real = hip_denoise(self.phi, prep, k4, predict_x0=True)
+            y_real.record_stream(cur)
         if before_fake_eval is not None:
             before_fake_eval()
         y_fake = hip_denoise(self.psi, prep, k2, predict_x0=True)                   # :496-499
+        if self.side is not None:
+            torch.cuda.current_stream().wait_stream(self.side)
         loss = ops.sid_generator_loss(images, y_real, y_fake, self.alpha, self.lsg / self.bgt)   # :508-530
         loss.backward()                                                             # :532-533
         return loss.detach()

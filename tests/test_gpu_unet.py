@@ -446,3 +446,42 @@ def test_reference_loop_shape_with_foreign_optimizer(dev):
             agree += int((torch.sign(du[big]) == torch.sign(dr[big])).sum())
             total += int(big.sum())
         assert agree / max(total, 1) > 0.93, f'update-sign agreement {agree / max(total, 1):.4f}'
+
+
+@pytest.mark.parametrize('precision', ['fp32', 'bf16'])
+def test_two_rank_loop_matches_reference_ddp_golden(dev, golden_dir, tmp_path, precision):
+    """the data-parallel path against a 2-RANK run of the UNMODIFIED reference loop
+    (DistributedDataParallel + misc.ddp_sync on gloo, oracle/make_goldens.py::gen_loop_2rank -> loop2_k15_a1.npz): each
+    rank's own loss curve and the (rank-identical) final weights.  Two processes share this GPU and exchange over gloo
+    (tests/mp_loop_worker.py); the exchange logic (FlatGradReducer, overlapped psi / segment-wise G exchange, mean in the
+    optimizer kernel) is the production one.  fp32 mode: 1e-3 (north_star); bf16: the bounds of the 1-rank golden test."""
+    import subprocess
+    import sys
+    golden = os.path.join(golden_dir, 'loop2_k15_a1.npz')
+    out = str(tmp_path / 'loop2')
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', '29561', os.path.join(os.path.dirname(os.path.abspath(__file__)), 'mp_loop_worker.py'), golden, out, precision]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
+    g = np.load(golden)
+    lr = float(g['kw_lr'])
+    finals = []
+    for rank in (0, 1):
+        r = np.load(f'{out}.rank{rank}.npz')
+        got, ref = r['losses'], g[f'loss_values_rank{rank}']
+        assert got.shape == ref.shape
+        rel_f = np.abs(got[0::2] - ref[0::2]) / np.abs(ref[0::2])
+        rel_g = np.abs(got[1::2] - ref[1::2]) / np.abs(ref[1::2])
+        abs_g = np.abs(got[1::2] - ref[1::2]) / np.abs(ref[0::2])
+        print(f'rank {rank} [{precision}]: product {got} reference {ref} fake rel {rel_f} G rel {rel_g}')
+        if precision == 'fp32':
+            assert rel_f.max() < 1e-3 and rel_g.max() < 1e-3
+        else:
+            assert rel_f.max() < 2e-3 and abs_g.max() < 7e-3
+        finals.append(r)
+    for key in ('G_conv_in_w', 'fake_conv_in_w', 'G_last_b'):
+        assert np.array_equal(finals[0][key], finals[1][key]), f'{key}: ranks diverged'
+        if precision == 'fp32':
+            d = np.abs(finals[0][key] - g[key])
+            assert (d < 0.05 * lr).mean() > 0.98, f'{key}: {(d < 0.05 * lr).mean():.4f} of the weights match the reference DDP run'
