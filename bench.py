@@ -84,6 +84,16 @@ def conv_flops(*a):
     return 2.0 * B * Ho * Wo * Cout * 9 * Cin
 
 
+def gn_bytes(*a):
+    # sidlsg_groupnorm_fwd(x, gamma, beta, y, stats, ws, B, HW, C, G, eps, silu, stream): algorithmic bytes = read x + write y (bf16)
+    return 2.0 * 2.0 * a[6] * a[7] * a[8]
+
+
+def attn_flops(*a):
+    # sidlsg_attn_fwd(Q, K, V, O, LSE, B, H, Nq, Nk, D, ...): QK^T + PV
+    return 4.0 * a[5] * a[6] * a[7] * a[8] * a[9]
+
+
 def cpu_baseline(arch, threads, kappa=1.5):
     """The reference CPU loop timed on the host cores (kind 'port': oracle/sid_ref.py::sid_iteration_ref, the restatement of
     sid_training_loop.py:383-571 that reproduces the reference's golden loss curves, on the oracle UNet): ONE complete
@@ -202,17 +212,23 @@ def main():
     for it in range(args.warmup):
         one_iteration(it)
     sync()
-    timer = None
+    timer = timer_gn = timer_attn = None
     if not args.no_kernel_timing and rank == 0:      # roofline of the dominant kernel, sampled live over the timed region
         timer = KernelTimer(lib, 'sidlsg_conv3x3_bf16', conv_flops)
         timer.__enter__()
+        # north_star's two other pieces of evidence: HBM GB/s on GroupNorm, MFMA utilisation on attention (forward entry points)
+        timer_gn = KernelTimer(lib, 'sidlsg_groupnorm_fwd', gn_bytes, stride=5)
+        timer_gn.__enter__()
+        timer_attn = KernelTimer(lib, 'sidlsg_attn_fwd', attn_flops, stride=3)
+        timer_attn.__enter__()
     t0 = time.time()
     for it in range(args.warmup, args.warmup + args.steps):
         lf, lg = one_iteration(it)
     sync()
     dt = time.time() - t0
-    if timer is not None:
-        timer.__exit__()
+    for tm in (timer, timer_gn, timer_attn):
+        if tm is not None:
+            tm.__exit__()
     # north_star's second figure: MFMA utilisation of the CFG teacher pass alone (phi forward on the [uncond; cond] batch of
     # 2b samples + guidance + x0), timed with events on a few extra passes after the timed region (rank 0)
     teacher = None
@@ -263,14 +279,33 @@ def main():
     if timer is not None:
         r = timer.result()
         ach = r['flops'] / (r['ms'] * 1e-3) / 1e12 if r['ms'] > 0 else 0.0
-        traffic = None   # HBM-side bytes per launch from the committed PMC summary (separate rocprofv3 --pmc passes, gfx950-corrected)
-        pmc = os.path.join(ROOT, 'profiles', 'r01_conv_pmc.json')
-        if os.path.isfile(pmc):
-            traffic = json.load(open(pmc)).get('avg_hbm_side_bytes_per_launch')
+        # HBM-side bytes per launch: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, gfx950-corrected) of the SAME
+        # entry point on the SAME layer shapes, collected with the kernel micro-benchmark (tools/bench_kernels.py conv, batch
+        # 16) -- not inside this timed step (PMC passes serialise kernels); the committed summary says so itself
+        traffic, traffic_src = None, None
+        for name in ('r02_conv_pmc.json', 'r01_conv_pmc.json'):
+            pmc = os.path.join(ROOT, 'profiles', name)
+            if os.path.isfile(pmc):
+                traffic, traffic_src = json.load(open(pmc)).get('avg_hbm_side_bytes_per_launch'), f'profiles/{name} (micro-benchmark of the step\'s conv shapes)'
+                break
         out['roofline'] = {'bound': 'mfma', 'kernel': 'implicit-GEMM conv3x3 fwd + dgrad (gemm_v3_kernel<1>, gemm_bf16_kernel<*,*,1|2>)',
                            'achieved': ach, 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / PEAK_BF16_TFLOPS,
-                           'traffic': traffic, 'launches': r['launches'], 'launches_total': r['calls'], 'avg_launch_ms': r['ms'] / max(r['launches'], 1),
+                           'traffic': traffic, 'traffic_source': traffic_src, 'launches': r['launches'], 'launches_total': r['calls'], 'avg_launch_ms': r['ms'] / max(r['launches'], 1),
                            'algorithmic_tflop_per_launch': r['flops'] / max(r['launches'], 1) / 1e12}
+    if timer_gn is not None:
+        r = timer_gn.result()
+        ach = r['flops'] / (r['ms'] * 1e-3) / 1e9 if r['ms'] > 0 else 0.0
+        out['roofline_gn'] = {'bound': 'hbm', 'kernel': 'GroupNorm(32)+SiLU forward (gn_stats_kernel + gn_apply_kernel, one entry point)',
+                              'achieved': ach, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': ach / PEAK_HBM_GBS, 'traffic': None,
+                              'launches': r['launches'], 'launches_total': r['calls'], 'avg_launch_ms': r['ms'] / max(r['launches'], 1),
+                              'algorithmic_bytes_per_launch': r['flops'] / max(r['launches'], 1)}
+    if timer_attn is not None:
+        r = timer_attn.result()
+        ach = r['flops'] / (r['ms'] * 1e-3) / 1e12 if r['ms'] > 0 else 0.0
+        out['roofline_attn'] = {'bound': 'mfma', 'kernel': 'flash attention forward, self + cross (attn_q_kernel<*,*,0,*>)', 'achieved': ach,
+                                'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / PEAK_BF16_TFLOPS, 'traffic': None,
+                                'launches': r['launches'], 'launches_total': r['calls'], 'avg_launch_ms': r['ms'] / max(r['launches'], 1),
+                                'algorithmic_tflop_per_launch': r['flops'] / max(r['launches'], 1) / 1e12}
     if not args.no_cpu_baseline and world == 1:
         # torch's CPU backend degrades badly when oversubscribed on many-core hosts (256 threads: 160 s per forward);
         # 32 threads is the measured sweet spot class for one fp32 conv-heavy forward -> cores = threads actually used

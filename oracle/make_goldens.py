@@ -166,15 +166,21 @@ def gen_bias_act():
     x = torch.randn(2, 40, 3, 5, generator=g)
     b = torch.randn(40, generator=g)
     dy = torch.randn(2, 40, 3, 5, generator=g)
-    out['x'], out['b'], out['dy'] = x.numpy(), b.numpy(), dy.numpy()
+    seed2 = torch.randn(2, 40, 3, 5, generator=g)
+    out['x'], out['b'], out['dy'], out['seed2'] = x.numpy(), b.numpy(), dy.numpy(), seed2.numpy()
     for act in ref.bias_act.activation_funcs.keys():
         for gain, clamp in ((None, None), (1.0, None), (1.5, 0.7)):
             xx = x.clone().requires_grad_(True)
             bb = b.clone().requires_grad_(True)
             y = ref.bias_act._bias_act_ref(xx, bb, dim=1, act=act, gain=gain, clamp=clamp)
-            dx, db = torch.autograd.grad(y, [xx, bb], dy)
+            dyy = dy.clone().requires_grad_(True)
+            dx, db = torch.autograd.grad(y, [xx, bb], dyy, create_graph=True)
             key = f'{act}_g{gain}_c{clamp}'
-            out[key + '_y'], out[key + '_dx'], out[key + '_db'] = y.detach().numpy(), dx.numpy(), db.numpy()
+            out[key + '_y'], out[key + '_dx'], out[key + '_db'] = y.detach().numpy(), dx.detach().numpy(), db.detach().numpy()
+            # second order (reference plugin grad=2, bias_act.py:190-212): seed on dx -> gradients w.r.t. x and dy
+            d2x, d2dy = torch.autograd.grad(dx, [xx, dyy], seed2, allow_unused=True)
+            out[key + '_d2x'] = (d2x if d2x is not None else torch.zeros_like(x)).numpy()
+            out[key + '_d2dy'] = d2dy.numpy()
     np.savez_compressed(os.path.join(OUT, 'bias_act.npz'), **out)
     print('bias_act done')
 

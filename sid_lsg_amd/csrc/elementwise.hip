@@ -395,55 +395,7 @@ __global__ void sum_small_kernel(const float* __restrict__ part, float* __restri
     if (threadIdx.x == 0) out[0] = t;
 }
 
-// ---- bias_act (reference plugin op: torch_utils/ops/bias_act.cu) -----------------------------
-// y = clamp(act(x + b[(i/stepB)%sizeB]) * gain); grad=1: dx from dy using saved x (+b) or y.
-DEVFN float act_fwd(int a, float x, float alpha) {
-    switch (a) {
-        case 1: return x;
-        case 2: return x > 0.f ? x : 0.f;
-        case 3: return x > 0.f ? x : x * alpha;
-        case 4: return tanhf(x);
-        case 5: return 1.f / (1.f + expf(-x));
-        case 6: return x > 0.f ? x : expm1f(x);
-        case 7: return 1.0507009873554805f * (x > 0.f ? x : 1.6732632423543772f * expm1f(x));
-        case 8: return x > 20.f ? x : log1pf(expf(x));
-        case 9: return x / (1.f + expf(-x));
-    }
-    return x;
-}
-// derivative of act at pre-activation x (y = act(x))
-DEVFN float act_grad(int a, float x, float y, float alpha) {
-    switch (a) {
-        case 1: return 1.f;
-        case 2: return x > 0.f ? 1.f : 0.f;
-        case 3: return x > 0.f ? 1.f : alpha;
-        case 4: return 1.f - y * y;
-        case 5: return y * (1.f - y);
-        case 6: return x > 0.f ? 1.f : y + 1.f;
-        case 7: return x > 0.f ? 1.0507009873554805f : y + 1.0507009873554805f * 1.6732632423543772f;
-        case 8: return 1.f / (1.f + expf(-x));
-        case 9: { const float s = 1.f / (1.f + expf(-x)); return s * (1.f + x * (1.f - s)); }
-    }
-    return 1.f;
-}
-template <typename T>
-__global__ void bias_act_kernel(const T* __restrict__ x, const T* __restrict__ b, const T* __restrict__ dy, T* __restrict__ out,
-                                size_t n, int stepB, int sizeB, int act, float alpha, float gain, float clamp, int grad) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    float v = (float)x[i];
-    if (b) v += (float)b[(i / stepB) % sizeB];
-    const float y = act_fwd(act, v, alpha);
-    if (grad == 0) {
-        float o = y * gain;
-        if (clamp >= 0.f) o = fminf(fmaxf(o, -clamp), clamp);
-        out[i] = (T)o;
-    } else {
-        float o = (float)dy[i] * gain * act_grad(act, v, y, alpha);
-        if (clamp >= 0.f) { const float yy = y * gain; if (yy > clamp || yy < -clamp) o = 0.f; }
-        out[i] = (T)o;
-    }
-}
+#include "bias_act_kernel.h"
 
 // ---- typed host launchers (T = activation storage type) + the two C entry-point families ----------------------------
 template <typename T>
@@ -635,14 +587,8 @@ int sidlsg_fake_loss(const float* e, const float* noise, float* de, float* loss,
 // bias_act: dtype 0 = fp32, 1 = bf16.  grad 0: out = clamp(act(x+b)*gain); grad 1: out = dL/dx given dy (x,b = saved inputs)
 int sidlsg_bias_act(const void* x, const void* b, const void* dy, void* out, long long n, int stepB, int sizeB, int act,
                     float alpha, float gain, float clamp, int grad, int dtype, void* stream) {
-    if (act < 1 || act > 9 || (grad != 0 && grad != 1) || (grad == 1 && !dy)) return SIDLSG_EINVAL;
-    if (dtype == 0)
-        hipLaunchKernelGGL(bias_act_kernel<float>, GRID1D(n, 256), dim3(256), 0, (hipStream_t)stream, (const float*)x,
-                           (const float*)b, (const float*)dy, (float*)out, (size_t)n, stepB, sizeB, act, alpha, gain, clamp, grad);
-    else
-        hipLaunchKernelGGL(bias_act_kernel<bf16>, GRID1D(n, 256), dim3(256), 0, (hipStream_t)stream, (const bf16*)x,
-                           (const bf16*)b, (const bf16*)dy, (bf16*)out, (size_t)n, stepB, sizeB, act, alpha, gain, clamp, grad);
-    return sidlsg_last_error();
+    if (grad != 0 && grad != 1) return SIDLSG_EINVAL;       // second order: the plugin entry point (plugins/bias_act_plugin.hip)
+    return bias_act_launch(x, b, dy, nullptr, out, n, stepB, sizeB, act, alpha, gain, clamp, grad, dtype, stream);
 }
 
 }  // extern "C"

@@ -691,17 +691,23 @@ static int dispatch_gemm(const GemmParams& p, hipStream_t s) {
     const bool n160 = p.N % 160 == 0;
     static const bool v3_on = !(getenv("SIDLSG_GEMM_V3") && atoi(getenv("SIDLSG_GEMM_V3")) == 0);   // A/B switch
     const bool v3 = n160 && v3_on && MODE != 2;
+    // A/B knobs (defaults = the measured best): launches with fewer than MIN_TILES 128-row tiles split K when the
+    // contraction has at least MIN_NK k-tiles, keeping at least MIN_KT k-tiles per split
+    static const int MIN_TILES = getenv("SIDLSG_GEMM_MIN_TILES") ? atoi(getenv("SIDLSG_GEMM_MIN_TILES")) : 384;
+    static const int MIN_NK = getenv("SIDLSG_SPLITK_MIN_NK") ? atoi(getenv("SIDLSG_SPLITK_MIN_NK")) : 32;
+    static const int MIN_KT = getenv("SIDLSG_SPLITK_MIN_KT") ? atoi(getenv("SIDLSG_SPLITK_MIN_KT")) : 8;
+    static const int V3_DIRECT_TILES = getenv("SIDLSG_V3_DIRECT_TILES") ? atoi(getenv("SIDLSG_V3_DIRECT_TILES")) : 384;
     {
         const long long t = tiles(128, n160 ? 160 : 128);
         const int nk = (p.K + BK - 1) / BK;
         const Ws w = ws_for(s);
         float* const g_ws = w.ptr;
         const long long g_ws_bytes = w.bytes;
-        if (t < 384 && nk >= 32 && (p.N & 3) == 0 && g_ws && (long long)p.M * p.N * 8 <= g_ws_bytes) {
+        if (t < MIN_TILES && nk >= MIN_NK && (p.N & 3) == 0 && g_ws && (long long)p.M * p.N * 8 <= g_ws_bytes) {
             int splits = (int)((512 + t - 1) / t);
             const long long cap = g_ws_bytes / ((long long)p.M * p.N * 4);
             if (splits > cap) splits = (int)cap;
-            if (splits > nk / 8) splits = nk / 8;
+            if (splits > nk / MIN_KT) splits = nk / MIN_KT;
             if (splits > 16) splits = 16;
             if (splits >= 2) {
                 GemmParams q = p;
@@ -712,7 +718,7 @@ static int dispatch_gemm(const GemmParams& p, hipStream_t s) {
             }
         }
     }
-    if (tiles(128, n160 ? 160 : 128) >= 384) {
+    if (tiles(128, n160 ? 160 : 128) >= (v3 ? V3_DIRECT_TILES : 384)) {
         if (v3) return launch_gemm_v3<MODE == 2 ? 0 : MODE>(p, s);
         return n160 ? launch_gemm<128, 160, MODE>(p, s) : launch_gemm<128, 128, MODE>(p, s);
     }

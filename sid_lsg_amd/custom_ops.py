@@ -1,7 +1,9 @@
 """`get_plugin(module_name, sources, **build_kwargs)` -- the reference's plugin loader seam
 (torch_utils/custom_ops.py:46-124, boundary B3) re-designed for ROCm: sources are .hip files with
-`extern "C"` entry points, compiled in-tree by hipcc for gfx950 into `<module_name>.so` and returned
-as a ctypes library handle.
+`extern "C"` entry points, compiled in-tree by hipcc for gfx950 into `<module_name>.so`.  As in the reference the
+caller gets back a python MODULE whose attributes are tensor-level functions (`_plugin.bias_act(x, b, ...)`): the glue
+pybind provides there is a small `<module_name>_binding.py` next to the sources (`bind(dll) -> {name: callable}`, ctypes on
+the C ABI); without one the module exposes the raw `extern "C"` symbols of the library (`module.dll`).
 
 Kept from the reference contract: process-global cache keyed by module name; rebuild only when the
 md5 digest of the sources changes; a cross-process lock so N ranks build once (reference: FileBaton,
@@ -11,8 +13,10 @@ Not kept: pybind/torch::Tensor signatures -- the boundary here is a C ABI (plain
 import ctypes
 import fcntl
 import hashlib
+import importlib.util
 import os
 import subprocess
+import types
 
 verbosity = 'brief'
 _cached_plugins = dict()
@@ -29,7 +33,8 @@ def get_plugin(module_name, sources, build_directory=None, extra_cflags=(), head
         sources = [os.path.abspath(s) for s in sources]
         build_directory = build_directory or os.path.dirname(sources[0])
         h = hashlib.md5()
-        for f in list(sources) + [os.path.abspath(x) for x in headers]:
+        binding_src = os.path.join(os.path.dirname(sources[0]), f'{module_name}_binding.py')
+        for f in list(sources) + [os.path.abspath(x) for x in headers] + ([binding_src] if os.path.isfile(binding_src) else []):
             with open(f, 'rb') as fh:
                 h.update(fh.read())
         h.update(' '.join(list(_DEFAULT_FLAGS) + list(extra_cflags)).encode())
@@ -48,7 +53,17 @@ def get_plugin(module_name, sources, build_directory=None, extra_cflags=(), head
                         f.write(h.hexdigest())
             finally:
                 fcntl.flock(lock, fcntl.LOCK_UN)
-        module = ctypes.CDLL(so)
+        import torch  # noqa: F401  (torch first: it brings the HIP runtime our library must share, see _lib.py)
+        dll = ctypes.CDLL(so)
+        module = types.ModuleType(module_name)
+        module.dll, module.__file__ = dll, so
+        binding = os.path.join(os.path.dirname(sources[0]), f'{module_name}_binding.py')
+        if os.path.isfile(binding):
+            spec = importlib.util.spec_from_file_location(f'{module_name}_binding', binding)
+            mod = importlib.util.module_from_spec(spec)
+            spec.loader.exec_module(mod)
+            for name, fn in mod.bind(dll).items():
+                setattr(module, name, fn)
     except Exception:
         if verbosity == 'brief':
             print('Failed!')

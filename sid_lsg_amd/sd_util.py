@@ -54,8 +54,27 @@ def _require_hip(net):
         raise TypeError(f'sid_lsg_amd.sd_util works on HipUNet2DCondition networks only, got {type(_unwrap(net)).__name__}')
 
 
+def _arch_from_dir(path):
+    """Architecture of a local diffusers-layout directory from its unet/config.json (block_out_channels,
+    cross_attention_dim, use_linear_projection -- the fields that distinguish the supported configurations)."""
+    import json
+    cj = os.path.join(path, 'unet', 'config.json')
+    if not os.path.isfile(cj):
+        return None
+    c = json.load(open(cj))
+    for name, cfg in CONFIGS.items():
+        if (tuple(c.get('block_out_channels', ())) == tuple(cfg.block_out_channels) and c.get('cross_attention_dim') == cfg.cross_attention_dim
+                and bool(c.get('use_linear_projection', False)) == cfg.use_linear_projection):
+            return name
+    raise ValueError(f'{cj}: not one of the supported UNet configurations {sorted(CONFIGS)}')
+
+
 def _arch_of(name):
-    n = name.lower()
+    if os.path.isdir(name):
+        arch = _arch_from_dir(name)
+        if arch is not None:
+            return arch
+    n = os.path.basename(os.path.normpath(name)).lower() if os.path.isdir(name) else name.lower()
     if n.startswith('random:'):
         return n.split(':', 1)[1]
     if '2-1-base' in n or 'sd21' in n or 'stable-diffusion-2' in n:

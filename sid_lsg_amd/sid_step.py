@@ -37,7 +37,7 @@ class SiDStep:
         # teacher runs on a second HIP stream (forward, and through autograd its data-gradient backward), so the two
         # networks' kernels share the chip wherever one of them cannot fill 256 CUs (16x16 / 8x8 stages, split-K tails).
         self.side = None
-        if os.environ.get('SIDLSG_TEACHER_STREAM', '0') == '1' and torch.cuda.is_available():
+        if os.environ.get('SIDLSG_TEACHER_STREAM', '1') != '0' and torch.cuda.is_available():     # A/B switch (+2 % images/s on MI355X)
             self.side = torch.cuda.Stream()
             ops.ensure_stream_workspace(self.side)
         opt_fake.grad_scale = opt_G.grad_scale = 1.0 / world_size     # DDP mean, folded into the optimizer kernel

@@ -405,16 +405,32 @@ def test_adam_ema(dev):
 
 
 def test_bias_act_matches_reference_golden(dev, golden_dir):
+    """Reference plugin op through the reference's own seams: `custom_ops.get_plugin('bias_act_plugin', sources=...)` builds /
+    loads the HIP plugin and returns a module; `bias_act(...)` calls `_plugin.bias_act(x, b, xref, yref, dy, grad, ...)` for
+    the forward, first-order and second-order passes (torch_utils/ops/bias_act.py:130-212).  Goldens: the reference's
+    `_bias_act_ref` + autograd (incl. double backward), 9 activations x (gain, clamp)."""
     import os
-    from sid_lsg_amd.bias_act import activation_funcs, bias_act
+    from sid_lsg_amd import bias_act as ba
+    from sid_lsg_amd import custom_ops
     g = np.load(os.path.join(golden_dir, 'bias_act.npz'))
-    x, b, dy = (torch.from_numpy(g[k]).to(dev) for k in ('x', 'b', 'dy'))
-    for act in activation_funcs:
+    x, b, dy, seed2 = (torch.from_numpy(g[k]).to(dev) for k in ('x', 'b', 'dy', 'seed2'))
+    for act in ba.activation_funcs:
         for gain, clamp in ((None, None), (1.0, None), (1.5, 0.7)):
-            xx, bb = x.clone().requires_grad_(), b.clone().requires_grad_()
-            y = bias_act(xx, bb, dim=1, act=act, gain=gain, clamp=clamp)
-            y.backward(dy)
+            xx, bb, dyy = x.clone().requires_grad_(), b.clone().requires_grad_(), dy.clone().requires_grad_()
+            y = ba.bias_act(xx, bb, dim=1, act=act, gain=gain, clamp=clamp)
+            dx, db = torch.autograd.grad(y, [xx, bb], dyy, create_graph=True)
             key = f'{act}_g{gain}_c{clamp}'
             close(y, torch.from_numpy(g[key + '_y']), 1e-5, key)
-            close(xx.grad, torch.from_numpy(g[key + '_dx']), 1e-5, key + ' dx')
-            close(bb.grad, torch.from_numpy(g[key + '_db']), 1e-5, key + ' db')
+            close(dx, torch.from_numpy(g[key + '_dx']), 1e-5, key + ' dx')
+            close(db, torch.from_numpy(g[key + '_db']), 1e-5, key + ' db')
+            d2x, d2dy = torch.autograd.grad(dx, [xx, dyy], seed2, allow_unused=True)
+            ref2 = torch.from_numpy(g[key + '_d2x'])
+            if float(ref2.abs().max()) > 0:
+                close(d2x, ref2, 2e-5, key + ' second-order d/dx')
+            else:
+                assert d2x is None or float(d2x.abs().max()) == 0.0
+            close(d2dy, torch.from_numpy(g[key + '_d2dy']), 1e-5, key + ' second-order d/d(dy)')
+    assert custom_ops._cached_plugins['bias_act_plugin'] is ba._plugin and callable(ba._plugin.bias_act)
+    # bf16 tensors go through the same plugin
+    yb = ba.bias_act(x.to(BF16), b.to(BF16), dim=1, act='swish')
+    close(yb, torch.from_numpy(g['swish_gNone_cNone_y']), 1.2e-2, 'bf16 swish')

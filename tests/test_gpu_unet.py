@@ -485,3 +485,66 @@ def test_two_rank_loop_matches_reference_ddp_golden(dev, golden_dir, tmp_path, p
         if precision == 'fp32':
             d = np.abs(finals[0][key] - g[key])
             assert (d < 0.05 * lr).mean() > 0.98, f'{key}: {(d < 0.05 * lr).mean():.4f} of the weights match the reference DDP run'
+
+
+def test_load_sd15_from_diffusers_layout_directory(dev, tmp_path):
+    """Real-weight import path (reference: `from_pretrained(..., subfolder=...)`, sid_sd_util.py:58-79):
+    a local diffusers-layout directory -- unet/diffusion_pytorch_model.safetensors, text_encoder/model.safetensors,
+    vae/diffusion_pytorch_model.safetensors, tokenizer/{vocab.json, merges.txt} -- goes through `load_sd15`; every tensor must
+    arrive (diffusers key names / shapes incl. the conv [Cout,Cin,3,3] -> physical [Cout,3,3,Cin] relayout and the fused q|k|v
+    views), and a mismatching text-encoder checkpoint must raise instead of silently keeping random weights."""
+    import json
+    from safetensors.torch import save_file
+    from oracle import fixtures
+    from sid_lsg_amd import sd_util
+    from sid_lsg_amd.text import TEXT_CONFIGS, CLIPTextModel
+    from sid_lsg_amd.vae import HipAutoencoderKLDecoder
+    root = tmp_path / 'tiny-sd'                                    # the architecture comes from unet/config.json
+    for sub in ('unet', 'text_encoder', 'vae', 'tokenizer'):
+        (root / sub).mkdir(parents=True)
+    c = sd_util.CONFIGS['tiny']
+    (root / 'unet' / 'config.json').write_text(json.dumps(dict(
+        _class_name='UNet2DConditionModel', block_out_channels=list(c.block_out_channels), cross_attention_dim=c.cross_attention_dim,
+        attention_head_dim=list(c.num_heads), use_linear_projection=c.use_linear_projection, norm_num_groups=c.norm_num_groups)))
+    ref = fixtures.make_unet('tiny', seed=4242)
+    save_file({k: v.contiguous() for k, v in ref.state_dict().items()}, str(root / 'unet' / 'diffusion_pytorch_model.safetensors'))
+    cfg = sd_util.CONFIGS['tiny']
+    torch.manual_seed(9)
+    te = CLIPTextModel(max_pos=cfg.text_len, **TEXT_CONFIGS.get('tiny', dict(hidden=cfg.cross_attention_dim, layers=2, heads=2,
+                                                                         dff=2 * cfg.cross_attention_dim, act='quick_gelu')))
+    te_sd = {k: v.contiguous() for k, v in te.state_dict().items()}
+    te_sd['text_model.embeddings.position_ids'] = torch.arange(cfg.text_len).unsqueeze(0)        # transformers < 4.31 checkpoints carry it
+    save_file(te_sd, str(root / 'text_encoder' / 'model.safetensors'))
+    vae = HipAutoencoderKLDecoder('tiny')
+    vae.init_parameters(5)
+    save_file({k: v.contiguous() for k, v in vae.state_dict().items()}, str(root / 'vae' / 'diffusion_pytorch_model.safetensors'))
+    vocab = {'<|startoftext|>': 49406, '<|endoftext|>': 49407, 'a</w>': 320, 'cat</w>': 2368, 'c': 66, 'a': 64, 't</w>': 4000}
+    (root / 'tokenizer' / 'vocab.json').write_text(json.dumps(vocab))
+    (root / 'tokenizer' / 'merges.txt').write_text('#version: 0.2\nc a\nca t</w>\n')
+    unet, vae2, sched, te2, tok = sd_util.load_sd15(str(root), None, dev, torch.float32)
+    got = unet.state_dict()
+    for k, v in ref.state_dict().items():
+        assert torch.equal(got[k].cpu(), v), k
+    # the fused projection views see the loaded weights, and the compute copies were refreshed
+    blk = unet.down_blocks[0].attentions[0].transformer_blocks[0].attn1
+    assert torch.equal(blk.fused['w'][:blk.to_q.weight.shape[0]].cpu(), ref.state_dict()['down_blocks.0.attentions.0.transformer_blocks.0.attn1.to_q.weight'])
+    assert torch.equal(blk.fused['w16'].float().cpu(), blk.fused['w'].to(BF16).float().cpu())
+    for k, v in te.state_dict().items():
+        assert torch.equal(te2.state_dict()[k].cpu(), v), k
+    for k, v in vae.state_dict().items():
+        assert torch.equal(vae2.state_dict()[k].cpu(), v), k
+    assert tok('a cat').input_ids[0, :4].tolist() == [49406, 320, 2368, 49407]
+    # forward equals the oracle with the same weights (bf16 tolerance)
+    g = torch.Generator().manual_seed(0)
+    x, ctx = torch.randn(1, 4, 8, 8, generator=g), torch.randn(1, cfg.text_len, cfg.cross_attention_dim, generator=g)
+    with torch.no_grad():
+        yr = ref(x, torch.tensor([500]), encoder_hidden_states=ctx).sample
+        y = unet(x.to(dev), torch.tensor([500], device=dev), encoder_hidden_states=ctx.to(dev)).sample
+    e, _ = rel_err(y, yr)
+    assert e < 4e-2
+    # a checkpoint of another architecture must not load silently
+    bad = dict(te_sd)
+    bad.pop('text_model.final_layer_norm.weight')
+    save_file(bad, str(root / 'text_encoder' / 'model.safetensors'))
+    with pytest.raises(RuntimeError, match='text-encoder checkpoint'):
+        sd_util.load_sd15(str(root), None, dev, torch.float32)

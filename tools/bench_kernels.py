@@ -59,7 +59,8 @@ def bench_gemm(B):
     for hw, c in ((4096, 320), (1024, 640), (256, 1280)):
         M = B * hw
         cases += [(M, 3 * c, c), (M, c, c), (M, 8 * c, c), (M, c, 4 * c)]
-    cases += [(B * 77, 640, 768), (B * 4096, 320, 640), (B * 64, 1280, 1280)]
+    cases += [(B * 77, 640, 768), (B * 4096, 320, 640), (B * 64, 1280, 1280), (B * 128, 1280, 1280), (B * 128, 5120, 1280),
+              (B * 256, 1280, 5120), (B * 128, 1280, 5120), (B * 512, 640, 640)]
     tot_f = tot_t = 0
     for M, N, K in cases:
         a, w = r(M, K), r(N, K, scale=0.02)
