@@ -256,10 +256,13 @@ __global__ __launch_bounds__(256) void attn_q_kernel(AttnParams p) {
                 mx = fmax3(mx, s[2][qt][3], s[3][qt][0]);
                 mx = fmax3(mx, s[3][qt][1], s[3][qt][2]);
                 mx = fmax2(mx, s[3][qt][3]);
-                mx = fmax2(mx, __shfl_xor(mx, 16, 64));
-                mx = fmax2(mx, __shfl_xor(mx, 32, 64));
                 mx *= p.scale2;                                    // scale2 > 0: max commutes with the scaling
-                if (__any(mx > m[qt] + 8.0f)) {                    // wave-uniform: rescale everything held at the old max
+                // wave-uniform test on the lanes' LOCAL maxima (this lane group's 16 keys): the common path needs no
+                // cross-lane reduction (2 ds_bpermute round trips per query tile); only when the running max must move is
+                // the row maximum reduced over the 4 lane groups and everything held at the old max rescaled
+                if (__any(mx > m[qt] + 8.0f)) {
+                    mx = fmax2(mx, __shfl_xor(mx, 16, 64));
+                    mx = fmax2(mx, __shfl_xor(mx, 32, 64));
                     const float mn = fmax2(m[qt], mx);
                     const float alpha = __builtin_amdgcn_exp2f(m[qt] - mn);   // m = -inf on the first tile -> 0
                     l[qt] *= alpha;

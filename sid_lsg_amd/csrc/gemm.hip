@@ -26,6 +26,7 @@
 #include "common.h"
 #include <stdlib.h>
 #include <algorithm>
+#include <type_traits>
 
 struct GemmParams {
     const bf16* A;        // dense: [M][lda]; conv: NHWC image [B][Hs][Ws][ldx]
@@ -431,9 +432,13 @@ DEVFN int wsw(int r) {
     return rr < 64 ? ((q & 1) | (((q >> 2) & 3) << 1)) : (q & 7);
 }
 
+#ifndef SIDLSG_V3_SCHED_FENCE
+#define SIDLSG_V3_SCHED_FENCE 1
+#endif
 template <int MODE>   // 0 dense, 1 conv3x3 with Cin % 64 == 0
 __global__ __launch_bounds__(NTHREADS, 2) void gemm_v3_kernel(GemmParams p) {
     constexpr int BM = 128, BN = 160, MT = 4, NT = 5;
+    constexpr bool SCHED_FENCE = SIDLSG_V3_SCHED_FENCE;
     constexpr int STAGE = (BM + BN) * BK;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16* ring = reinterpret_cast<bf16*>(smem);
@@ -602,19 +607,33 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_v3_kernel(GemmParams p) {
     asm volatile("" ::: "memory");
     read_frags(0, 0, fa0, fw0);
     if (kt_begin + 1 < nk) issue(kt_begin + 1, 1);
-    for (int kt = kt_begin; kt < nk; kt++) {
+    // One K-tile.  The steady state, the last-but-one tile (nothing left to fetch) and the last tile are separate
+    // STRAIGHT-LINE instantiations: with `if (more)` / `if (kt + 2 < nk)` inside one loop body the waitcnt pass has to merge
+    // the paths and makes the kk=1 MFMAs of E wait for the fragment reads D has just issued (lgkmcnt(4..0) in the ISA instead
+    // of ~9), i.e. the prefetch of the next tile's fragments was serialised in front of the MFMAs meant to cover it.
+    auto ktile = [&](const int kt, auto has_next, auto fetch) {
         const int buf = (kt - kt_begin) & 1;
-        const bool more = kt + 1 < nk;
         read_frags(buf, 1, fa1, fw1);                          // A
         mfma_block(fa0, fw0);
+        // The MFMAs are register-only, so neither the "memory" clobber nor the barrier orders them: without this fence the
+        // scheduler hoists the wait + barrier to right behind the FIRST kk=0 MFMA (seen in the ISA), which halves the MFMA
+        // time covering the DMA of tile kt+1 (issued in the previous D) and serialises the wait in front of 19 MFMAs.
+        if (SCHED_FENCE) __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // C: my share of tile kt+1 is in LDS
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (more) {                                            // D
+        if (SCHED_FENCE) __builtin_amdgcn_sched_barrier(0);
+        if constexpr (decltype(has_next)::value) {             // D
             read_frags(buf ^ 1, 0, fa0, fw0);
-            if (kt + 2 < nk) issue(kt + 2, buf);
+            if constexpr (decltype(fetch)::value) issue(kt + 2, buf);
         }
         mfma_block(fa1, fw1);                                  // E
+    };
+    {
+        int kt = kt_begin;
+        for (; kt + 2 < nk; kt++) ktile(kt, std::true_type{}, std::true_type{});
+        if (kt + 1 < nk) { ktile(kt, std::true_type{}, std::false_type{}); kt++; }
+        ktile(kt, std::false_type{}, std::false_type{});
     }
 
     if (p.kt_per_split) {
@@ -1096,18 +1115,26 @@ DEVFN void wgrad_v2_body(const WgradParams& p) {
     asm volatile("" ::: "memory");
     read_frags(0, 0, fy0, fx0);
     if (nsteps > 1) issue(mbeg + WG_MB, 1);
-    for (int st = 0; st < nsteps; st++) {
+    auto stage = [&](const int st, auto has_next, auto fetch) {           // straight-line instantiations: see gemm_v3_kernel
         const int buf = st & 1;
         read_frags(buf, 1, fy1, fx1);                                     // A
         mfma_block(fy0, fx0);
+        if (SIDLSG_V3_SCHED_FENCE) __builtin_amdgcn_sched_barrier(0);    // keep the kk=0 MFMAs in front of the wait
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // C: my DMA share of stage st+1 landed; my reads of buf done
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (st + 1 < nsteps) {                                            // D
+        if (SIDLSG_V3_SCHED_FENCE) __builtin_amdgcn_sched_barrier(0);
+        if constexpr (decltype(has_next)::value) {                        // D
             read_frags(buf ^ 1, 0, fy0, fx0);
-            if (st + 2 < nsteps) issue(mbeg + (st + 2) * WG_MB, buf);
+            if constexpr (decltype(fetch)::value) issue(mbeg + (st + 2) * WG_MB, buf);
         }
         mfma_block(fy1, fx1);                                             // E
+    };
+    {
+        int st = 0;
+        for (; st + 2 < nsteps; st++) stage(st, std::true_type{}, std::true_type{});
+        if (st + 1 < nsteps) { stage(st, std::true_type{}, std::false_type{}); st++; }
+        stage(st, std::false_type{}, std::false_type{});
     }
     if (do_bias && li == 0) {
 #pragma unroll

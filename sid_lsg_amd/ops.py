@@ -76,6 +76,17 @@ def ensure_workspace(device, nbytes=512 << 20):
 
 
 _stream_ws = {}
+_side_streams = {}
+
+
+def side_stream(device):
+    """The process-wide second compute stream of `device` (with its private split-K workspace): created once, shared by
+    every SiDStep -- the C library keeps at most 4 stream workspaces."""
+    key = torch.device(device).index or 0
+    if key not in _side_streams:
+        _side_streams[key] = torch.cuda.Stream(device=device)
+        ensure_stream_workspace(_side_streams[key])
+    return _side_streams[key]
 
 
 def ensure_stream_workspace(stream, nbytes=256 << 20):

@@ -38,8 +38,7 @@ class SiDStep:
         # networks' kernels share the chip wherever one of them cannot fill 256 CUs (16x16 / 8x8 stages, split-K tails).
         self.side = None
         if os.environ.get('SIDLSG_TEACHER_STREAM', '1') != '0' and torch.cuda.is_available():     # A/B switch (+2 % images/s on MI355X)
-            self.side = torch.cuda.Stream()
-            ops.ensure_stream_workspace(self.side)
+            self.side = ops.side_stream(G.flat_params.device)
         opt_fake.grad_scale = opt_G.grad_scale = 1.0 / world_size     # DDP mean, folded into the optimizer kernel
         opt_fake.attach(ema=None, w16=fake_score.flat_w16)
         opt_G.attach(ema=(G_ema.flat_params if (G_ema is not None and G_ema is not G) else None), w16=G.flat_w16)
