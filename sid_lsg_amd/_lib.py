@@ -9,7 +9,8 @@ import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 HEADER = os.path.join(os.path.dirname(_HERE), 'include', 'sidlsg_hip.h')
-LIB_PATH = os.path.join(_HERE, 'libsidlsg_hip.so')
+# SIDLSG_LIB: an alternative build of the same C ABI (A/B measurements of kernel variants inside one GPU session)
+LIB_PATH = os.environ.get('SIDLSG_LIB') or os.path.join(_HERE, 'libsidlsg_hip.so')
 
 _CT = {'int': ctypes.c_int, 'float': ctypes.c_float, 'long long': ctypes.c_longlong}
 

@@ -155,8 +155,9 @@ constexpr int AT_KT = 64;   // keys per LDS tile
 // ONES (forward, D == DP - 8 only): V's first pad column holds 1.0, so O^T row D accumulates the softmax
 // denominator inside the P.V MFMAs (and is rescaled with O); the 16 VALU adds per query tile disappear.
 // K/V tiles are double buffered in LDS: one barrier per key tile.
+// (the d = 40 forward is VALU-bound and lives on 4 resident waves per SIMD: cap its registers at 128)
 template <int DP, int QT, int MODE, bool ONES>
-__global__ __launch_bounds__(256) void attn_q_kernel(AttnParams p) {
+__global__ __launch_bounds__(256, (DP <= 48 && MODE == 0) ? 4 : 1) void attn_q_kernel(AttnParams p) {
     static_assert(!ONES || (MODE == 0 && DP % 16 == 0), "ones column: forward only");
     constexpr int LD = DP + 8;
     constexpr int DT = DP / 16;
@@ -219,8 +220,11 @@ __global__ __launch_bounds__(256) void attn_q_kernel(AttnParams p) {
     int buf = 0;
     // The tile body is instantiated twice: full tiles (no masking code at all; the compiler otherwise if-converts
     // the ragged-tile test into ~90 predicated VALU ops per tile in a VALU-bound loop) and the ragged last tile.
-    auto tile = [&](const int k0, auto ragged) {
-        const bool more = k0 + AT_KT < p.Nk;
+    // Forward: `has_next` is a compile-time flag like `ragged` -- a run-time `if (more)` around the prefetch / commit makes
+    // the waitcnt pass merge two paths (same finding as in gemm_v3_kernel; A/B on one MI355X: forward +1.4 % at d=40, +3 %
+    // at d=64/80).  The dQ pass measured 1-8 % SLOWER that way (register allocation), so it keeps the run-time test.
+    auto tile = [&](const int k0, auto ragged, auto has_next) {
+        const bool more = MODE == 0 ? decltype(has_next)::value : (k0 + AT_KT < p.Nk);
         if (more) { tk.load(rk, p.ldk, k0 + AT_KT, p.Nk, p.D); tv.load(rv, p.ldv, k0 + AT_KT, p.Nk, p.D); }
         const bf16* Kt = Ks[buf];
         const bf16* Vt = Vs[buf];
@@ -325,8 +329,12 @@ __global__ __launch_bounds__(256) void attn_q_kernel(AttnParams p) {
         }
     };
     int k0 = 0;
-    for (; k0 + AT_KT <= p.Nk; k0 += AT_KT) tile(k0, std::false_type{});
-    if (k0 < p.Nk) tile(k0, std::true_type{});
+    for (; k0 + 2 * AT_KT <= p.Nk; k0 += AT_KT) tile(k0, std::false_type{}, std::true_type{});       // full tile, a full tile follows
+    if (k0 + AT_KT <= p.Nk) {                                                                       // last full tile
+        if (k0 + AT_KT < p.Nk) tile(k0, std::false_type{}, std::true_type{}); else tile(k0, std::false_type{}, std::false_type{});
+        k0 += AT_KT;
+    }
+    if (k0 < p.Nk) tile(k0, std::true_type{}, std::false_type{});                                    // ragged tail
     // epilogue: lane holds, for query li of tile qt, d = dt*16 + lg*4 + r
 #pragma unroll
     for (int qt = 0; qt < QT; qt++) {
@@ -406,7 +414,7 @@ __global__ __launch_bounds__(256) void attn_dkdv_kernel(AttnParams p) {
     if (threadIdx.x < AK_QT) { lse_s[0][threadIdx.x] = lse_r; dl_s[0][threadIdx.x] = dl_r; }
     __syncthreads();
     int pb_ = 0;
-    for (int q0 = 0; q0 < p.Nq; q0 += AK_QT) {
+    auto qtile = [&](const int q0, auto has_next) {       // (run-time `more`: the compile-time split measured slower here)
         const bool more = q0 + AK_QT < p.Nq;
         if (more) prefetch(q0 + AK_QT);
         f32x4 pp[KT][4], ds[KT][4];
@@ -451,6 +459,10 @@ __global__ __launch_bounds__(256) void attn_dkdv_kernel(AttnParams p) {
             if (threadIdx.x < AK_QT) { lse_s[pb_][threadIdx.x] = lse_r; dl_s[pb_][threadIdx.x] = dl_r; }
             __syncthreads();
         }
+    };
+    {
+        int q0 = 0;
+        for (; q0 < p.Nq; q0 += AK_QT) qtile(q0, std::true_type{});
     }
 #pragma unroll
     for (int kt = 0; kt < KT; kt++) {

@@ -324,18 +324,23 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_kernel(GemmParams p) { 
     __syncthreads();
     read_frags(0, 0, fa0, fw0);
     if (kt_begin + 1 < nk) load_tile(kt_begin + 1);
-    for (int kt = kt_begin; kt < nk; kt++) {
+    auto ktile = [&](const int kt, auto has_next, auto fetch) {     // straight-line instantiations: see gemm_v3_kernel
         const int buf = (kt - kt_begin) & 1;
-        const bool more = kt + 1 < nk;
         read_frags(buf, 1, fa1, fw1);          // A
         mfma_block(fa0, fw0);
-        if (more) store_tile(buf ^ 1);         // B
+        if constexpr (decltype(has_next)::value) store_tile(buf ^ 1);         // B
         __syncthreads();                       // C
-        if (more) {                            // D
+        if constexpr (decltype(has_next)::value) {                            // D
             read_frags(buf ^ 1, 0, fa0, fw0);
-            if (kt + 2 < nk) load_tile(kt + 2);
+            if constexpr (decltype(fetch)::value) load_tile(kt + 2);
         }
         mfma_block(fa1, fw1);                  // E
+    };
+    {
+        int kt = kt_begin;
+        for (; kt + 2 < nk; kt++) ktile(kt, std::true_type{}, std::true_type{});
+        if (kt + 1 < nk) { ktile(kt, std::true_type{}, std::false_type{}); kt++; }
+        ktile(kt, std::false_type{}, std::false_type{});
     }
 
     if (p.kt_per_split) {
@@ -435,8 +440,11 @@ DEVFN int wsw(int r) {
 #ifndef SIDLSG_V3_SCHED_FENCE
 #define SIDLSG_V3_SCHED_FENCE 1
 #endif
-template <int MODE>   // 0 dense, 1 conv3x3 with Cin % 64 == 0
-__global__ __launch_bounds__(NTHREADS, 2) void gemm_v3_kernel(GemmParams p) {
+// (A 3-buffer ring with counted vmcnt(9) -- every DMA gets two K-tiles of MFMA time, but 108 KiB of LDS = ONE block per CU
+// -- was measured in the same session: 30-50 % SLOWER on every SD shape (e.g. conv 64x64 320->320 124 -> 195 us, FF-in 239 ->
+// 355 us).  Two co-resident blocks per CU hide more than a deeper pipeline in one; the variant is not in the build.)
+template <int MODE, int STAGES>   // MODE 0 dense, 1 conv3x3 with Cin % 64 == 0
+DEVFN void gemm_v3_body(const GemmParams& p) {
     constexpr int BM = 128, BN = 160, MT = 4, NT = 5;
     constexpr bool SCHED_FENCE = SIDLSG_V3_SCHED_FENCE;
     constexpr int STAGE = (BM + BN) * BK;
@@ -601,6 +609,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_v3_kernel(GemmParams p) {
     };
 
     bf16x8 fa0[MT], fw0[NT], fa1[MT], fw1[NT];
+    if constexpr (STAGES == 2) {
     issue(kt_begin, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -636,6 +645,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_v3_kernel(GemmParams p) {
         ktile(kt, std::false_type{}, std::false_type{});
     }
 
+    }
+
     if (p.kt_per_split) {
 #pragma unroll
         for (int mi = 0; mi < MT; mi++) {
@@ -657,13 +668,17 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_v3_kernel(GemmParams p) {
     gemm_epilogue<MT, NT>(p, acc, m0 + wm0, n0 + wn0, li, lg);
 }
 
+// (plain kernels over one body: a kernel template with a second non-type parameter got no host stub from hipcc 7.2)
+template <int MODE>
+__global__ __launch_bounds__(NTHREADS, 2) void gemm_v3_kernel(GemmParams p) { gemm_v3_body<MODE, 2>(p); }
+
 template <int MODE>
 static int launch_gemm_v3(const GemmParams& p, hipStream_t s) {
     const int tiles = ((p.M + 127) / 128) * ((p.N + 159) / 160);
     const size_t lds = (size_t)2 * (128 + 160) * BK * sizeof(bf16);
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_v3_kernel<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_v3_kernel<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (128 + 160) * BK * 2);
         attr_done = true;
     }
     const int nk = (p.K + BK - 1) / BK;
