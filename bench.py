@@ -145,6 +145,9 @@ def main():
     ap.add_argument('--arch', default='sd15')
     ap.add_argument('--kappa', type=float, default=1.5)
     ap.add_argument('--resolution', type=int, default=512, help='image resolution (latents are resolution/8); 768 for BASELINE config #4')
+    ap.add_argument('--teacher-weights', default='bf16', choices=['bf16', 'fp8'],
+                    help="fp8: the frozen teacher's forward weights as e4m3 + per-channel scales (BASELINE configs[4] precision; "
+                         "not the headline configuration)")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true')
     args = ap.parse_args()
@@ -181,6 +184,8 @@ def main():
     psi = phi.clone_network()
     G = phi.clone_network()
     G_ema = phi.clone_network(with_grad_buffers=False)
+    if args.teacher_weights == 'fp8':
+        phi.enable_fp8_weights()
     text_encoder.to(torch.bfloat16)
     cond = TextConditioner(tokenizer, text_encoder)
     opt_f = FusedAdamEMA(psi.parameters(), lr=1e-6, betas=(0.0, 0.999), eps=1e-8)
@@ -285,7 +290,7 @@ def main():
         'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
         'config': {'workload': f'{args.arch} SiD-LSG inner step, kappa={args.kappa} on all branches, {args.resolution}x{args.resolution} ({lat}x{lat}x4 latents), '
                                f'batch_gpu={b}, fp32 masters + bf16 MFMA compute, Adam(beta1=0)+EMA, random-init weights',
-                   'global_batch': batch_size, 'parallelism': f'dp{world}'},
+                   'global_batch': batch_size, 'parallelism': f'dp{world}', 'teacher_weights': args.teacher_weights},
         'step_tflops': value * img_tflop, 'step_mfma_frac': value * img_tflop / (PEAK_BF16_TFLOPS * world),
         'loss_fake': float(lf), 'loss_G': float(lg),
     }

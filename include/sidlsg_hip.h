@@ -151,6 +151,20 @@ int sidlsg_transpose_w_batched(const void* jobs, int njobs, int nblocks, void* s
 int sidlsg_bias_act(const void* x, const void* b, const void* dy, void* out, long long n, int stepB, int sizeB, int act,
                     float alpha, float gain, float clamp, int grad, int dtype, void* stream);
 
+/* ---- fp8-weight contractions (BASELINE.json configs[4] "fp8 MFMA weights"; no counterpart in the reference, which only
+ * knows fp32 / fp16: training/sid_training_loop.py:205) ----------------------------------------------------------------
+ * For FROZEN networks: W8 = OCP e4m3 bytes [N][K] with one fp32 scale per output channel (sidlsg_quantize_fp8_rows from
+ * the bf16 compute copy); A / X stay bf16 in HBM and are converted to e4m3 in the kernel's loader (static unit scale,
+ * saturating); v_mfma_f32_16x16x32_fp8_fp8, fp32 accumulation, C = act(alpha * wscale[n] * acc + bias + rowvec + res).
+ * Same remaining arguments as sidlsg_gemm_bf16 / sidlsg_conv3x3_bf16; K (Cin) multiple of 16. */
+int sidlsg_quantize_fp8_rows(const void* src_bf16, void* dst_fp8, float* scale, int rows, int cols, void* stream);
+int sidlsg_gemm_fp8w(const void* A, int lda, const void* W8, const float* wscale, void* C, int ldc, const float* bias, const void* res,
+                     int ldres, const float* rowvec, int ld_rowvec, int rows_per_batch, int M, int N, int K, float alpha,
+                     int flags, void* stream);
+int sidlsg_conv3x3_fp8w(const void* X, int ldx, const void* W8, const float* wscale, void* Y, int ldc, const float* bias,
+                        const void* res, int ldres, const float* rowvec, int ld_rowvec, int B, int H, int Wd, int Cin, int Cout,
+                        int stride, int ups, float alpha, int flags, void* stream);
+
 /* ---- fp32-accurate compute mode ------------------------------------------------------------------------------
  * The reference's default precision is fp32 (training/sid_training_loop.py:205 `dtype = float16 if use_fp16 else float32`,
  * run_sid.sh:63-88) and BASELINE.json configs[0] is fp32.  Every entry point above that touches bf16 activations also

@@ -47,6 +47,7 @@ struct GemmParams {
     int kt_per_split;            // split-K: K-tiles per split (0 = no split)
     int group_m;                 // v3: m-tiles per group of the logical tile order (see gemm_v3_kernel)
     float* ws;                   // split-K: fp32 [splits][M][N] partial-sum slabs
+    const float* wscale;         // fp8-weight path: per-output-channel dequantisation scale [N] (else null)
 };
 
 enum { F_OUT_F32 = 1, F_SILU = 2, F_ACCUM = 4 };
@@ -107,7 +108,7 @@ DEVFN void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[NT][MT], int mbase, i
                 }
 #pragma unroll
                 for (int e = 0; e < 8; e++) {
-                    float x = v[e] * p.alpha + bb[e] + rr[e];
+                    float x = v[e] * p.alpha * ((p.wscale && e < cnt) ? p.wscale[n + e] : 1.f) + bb[e] + rr[e];
                     if (p.flags & F_SILU) x = silu_f(x);
                     v[e] = x;
                 }
@@ -138,7 +139,7 @@ DEVFN void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[NT][MT], int mbase, i
                 for (int e = 0; e < cnt; e++) {
                     const int nn = n + e;
                     if (nn >= p.N) break;
-                    float x = v[e] * p.alpha;
+                    float x = v[e] * p.alpha * (p.wscale ? p.wscale[nn] : 1.f);
                     if (p.bias) x += p.bias[nn];
                     if (rv) x += rv[nn];
                     if (p.res) x += bf2f(p.res[(size_t)m * p.ldres + nn]);
@@ -363,6 +364,160 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_kernel(GemmParams p) { 
         return;
     }
     gemm_epilogue<MT, NT>(p, acc, m0 + wm0, n0 + wn0, li, lg);
+}
+
+// ---------------------------------------------------------------------------------------------
+// fp8-weight path (BASELINE.json configs[4]: "fp8 MFMA weights + bf16 accum"; no reference behaviour exists for it --
+// SURVEY.md Appendix C -- so the contract is this file's): frozen networks (teacher, fake score under evaluation) keep
+// their GEMM / conv weights as OCP e4m3 bytes with one fp32 scale per output channel (sidlsg_quantize_fp8_rows); the
+// activations arrive as bf16, are converted to e4m3 in the loader (static unit scale, saturating: normalised
+// activations sit well inside +-448) and the contraction runs on v_mfma_f32_16x16x32_fp8_fp8 with fp32 accumulation;
+// the epilogue multiplies by the channel scale.  Half the operand bytes through L2 / LDS; the non-scaled fp8 MFMA has
+// the bf16 rate on gfx950 (only the MX block-scaled K=128 forms are faster), so this is a bandwidth, not a FLOP, lever.
+// 128 x 128 x 64 tile, 4 waves (64 x 64 each), register-staged loads (the bf16 -> fp8 conversion needs registers), LDS
+// rows of 64 bytes padded to 80 so the 8-byte fragment reads of a half-wave fall on distinct banks.
+typedef long i64_t;
+constexpr int F8_T = 128, F8_LD = 80;     // tile edge; LDS row stride in bytes
+
+DEVFN unsigned cvt4_fp8(float a, float b, float c, float d) {
+    int r = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
+    r = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, r, true);
+    return (unsigned)r;
+}
+
+template <int MODE>   // 0 dense rows, 2 conv3x3 (any Cin % 8 == 0)
+__global__ __launch_bounds__(NTHREADS, 2) void gemm_fp8w_kernel(GemmParams p) {
+    __shared__ __attribute__((aligned(16))) unsigned char As[2][F8_T * F8_LD];
+    __shared__ __attribute__((aligned(16))) unsigned char Ws[2][F8_T * F8_LD];
+    const int tiles_n = (p.N + F8_T - 1) / F8_T;
+    const int nblk = tiles_n * ((p.M + F8_T - 1) / F8_T);
+    int bid = blockIdx.x;
+    {
+        const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int m0 = (bid / tiles_n) * F8_T, n0 = (bid % tiles_n) * F8_T;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lg = lane >> 4;
+    const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 64;
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(p.A), 0, (int)p.a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(p.W), 0, (int)p.w_bytes, 0x00020000);
+    const unsigned char* W8 = reinterpret_cast<const unsigned char*>(p.W);
+    (void)W8;
+    // A loader: 4 chunks of 8 bf16 per thread: chunk c = tid & 7 (k = c*8), rows r = (tid >> 3) + 32 i
+    const int kc = tid & 7, r0 = tid >> 3;
+    const int Hs = p.ups ? (p.H >> 1) : p.H, Wsrc = p.ups ? (p.Wd >> 1) : p.Wd;
+    unsigned abase[4];
+    int ahi[4], awi[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int m = m0 + r0 + 32 * i;
+        const bool ok = m < p.M;
+        if (MODE == 0) { abase[i] = ok ? (unsigned)m * (unsigned)p.lda * 2u : OOB; ahi[i] = awi[i] = 0; }
+        else {
+            const int mm = ok ? m : 0, hw = p.Ho * p.Wo;
+            const int b = mm / hw, rem = mm - b * hw, ho = rem / p.Wo, wo = rem - ho * p.Wo;
+            abase[i] = (unsigned)b * (unsigned)(Hs * Wsrc) * (unsigned)p.lda * 2u;
+            ahi[i] = ok ? ho * p.stride - 1 : -100000;
+            awi[i] = wo * p.stride - 1;
+        }
+    }
+    // W loader: fp8 rows of K bytes: 2 chunks of 16 bytes per thread: chunk c = tid & 3 (k = c*16), rows (tid >> 2) + 64 i
+    const int wc = tid & 3, wr0 = tid >> 2;
+    bf16x8 areg[4];
+    u32x4 wreg[2];
+    auto load_tile = [&](int kt) {
+        const int k = kt * BK + kc * 8;
+        const bool kok = k < p.K;
+        int dh = 0, dw = 0, c = k;
+        if (MODE != 0) { const int tap = k / p.Cin; c = k - tap * p.Cin; dh = tap / 3; dw = tap - dh * 3; }
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            unsigned off = OOB;
+            if (kok && abase[i] != OOB) {
+                if (MODE == 0) off = abase[i] + (unsigned)k * 2u;
+                else {
+                    int hi = ahi[i] + dh, wi = awi[i] + dw;
+                    const bool ok = hi >= 0 && hi < p.H && wi >= 0 && wi < p.Wd;
+                    if (p.ups) { hi >>= 1; wi >>= 1; }
+                    if (ok) off = abase[i] + ((unsigned)(hi * Wsrc + wi) * (unsigned)p.lda + (unsigned)c) * 2u;
+                }
+            }
+            areg[i] = buf_ld8(ra, off);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            const int n = n0 + wr0 + 64 * i, kb = kt * BK + wc * 16;
+            wreg[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, (n < p.N && kb < p.K) ? (unsigned)n * (unsigned)p.K + (unsigned)kb : OOB, 0, 0));
+        }
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const bf16x8 v = areg[i];
+            u32x2 q = {cvt4_fp8(bf2f(v[0]), bf2f(v[1]), bf2f(v[2]), bf2f(v[3])), cvt4_fp8(bf2f(v[4]), bf2f(v[5]), bf2f(v[6]), bf2f(v[7]))};
+            *reinterpret_cast<u32x2*>(&As[buf][(r0 + 32 * i) * F8_LD + kc * 8]) = q;
+        }
+#pragma unroll
+        for (int i = 0; i < 2; i++) *reinterpret_cast<u32x4*>(&Ws[buf][(wr0 + 64 * i) * F8_LD + wc * 16]) = wreg[i];
+    };
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    int wrow[4];
+#pragma unroll
+    for (int ni = 0; ni < 4; ni++) wrow[ni] = wn0 + 32 * (ni >> 1) + (li >> 2) * 8 + (ni & 1) * 4 + (li & 3);
+    const int nk = (p.K + BK - 1) / BK;
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; kt++) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) load_tile(kt + 1);
+#pragma unroll
+        for (int kk = 0; kk < 2; kk++) {
+            i64_t fa[4], fw[4];
+#pragma unroll
+            for (int mi = 0; mi < 4; mi++) fa[mi] = *reinterpret_cast<const i64_t*>(&As[buf][(wm0 + mi * 16 + li) * F8_LD + kk * 32 + lg * 8]);
+#pragma unroll
+            for (int ni = 0; ni < 4; ni++) fw[ni] = *reinterpret_cast<const i64_t*>(&Ws[buf][wrow[ni] * F8_LD + kk * 32 + lg * 8]);
+#pragma unroll
+            for (int ni = 0; ni < 4; ni++)
+#pragma unroll
+                for (int mi = 0; mi < 4; mi++)
+                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(fw[ni], fa[mi], acc[ni][mi], 0, 0, 0);
+        }
+        if (kt + 1 < nk) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+    gemm_epilogue<4, 4>(p, acc, m0 + wm0, n0 + wn0, li, lg);
+}
+
+// per-row e4m3 quantisation of a bf16 matrix [rows][cols] (cols % 8 == 0): scale[r] = max|x| / 448 (1 if the row is zero),
+// q = cvt_fp8(x / scale).  One wave per row.
+__global__ __launch_bounds__(256) void quantize_fp8_rows_kernel(const bf16* __restrict__ src, unsigned char* __restrict__ dst,
+                                                                float* __restrict__ scale, int rows, int cols) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const bf16* s = src + (size_t)row * cols;
+    float amax = 0.f;
+    for (int c = lane * 8; c < cols; c += 512) {
+        const bf16x8 v = ld8(s + c);
+#pragma unroll
+        for (int e = 0; e < 8; e++) amax = fmaxf(amax, fabsf(bf2f(v[e])));
+    }
+    amax = wave_max(amax);
+    const float sc = amax > 0.f ? amax / 448.f : 1.f;
+    const float inv = 1.f / sc;
+    if (lane == 0) scale[row] = sc;
+    for (int c = lane * 8; c < cols; c += 512) {
+        const bf16x8 v = ld8(s + c);
+        u32x2 q = {cvt4_fp8(bf2f(v[0]) * inv, bf2f(v[1]) * inv, bf2f(v[2]) * inv, bf2f(v[3]) * inv),
+                   cvt4_fp8(bf2f(v[4]) * inv, bf2f(v[5]) * inv, bf2f(v[6]) * inv, bf2f(v[7]) * inv)};
+        *reinterpret_cast<u32x2*>(dst + (size_t)row * cols + c) = q;
+    }
 }
 
 // epilogue of a split-K GEMM: C = act(alpha * sum_s slab_s + bias + rowvec + res)
@@ -1363,6 +1518,54 @@ int sidlsg_conv3x3_wgrad_bf16(const void* dY, int ldy, const void* X, int ldx, f
     if (!fits31(ab) || !fits31(yb)) return SIDLSG_EINVAL;
     p.a_bytes = (unsigned)ab; p.y_bytes = (unsigned)yb;
     return launch_wgrad<1>(p, (hipStream_t)stream);
+}
+
+// ---- fp8-weight contractions (see gemm_fp8w_kernel).  W8: e4m3 bytes [N][K]; wscale: fp32 [N].  K % 16 == 0.
+int sidlsg_quantize_fp8_rows(const void* src_bf16, void* dst_fp8, float* scale, int rows, int cols, void* stream) {
+    if (rows <= 0 || cols <= 0 || (cols & 7) || !src_bf16 || !dst_fp8 || !scale) return SIDLSG_EINVAL;
+    hipLaunchKernelGGL(quantize_fp8_rows_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const bf16*)src_bf16,
+                       (unsigned char*)dst_fp8, scale, rows, cols);
+    return sidlsg_last_error();
+}
+
+int sidlsg_gemm_fp8w(const void* A, int lda, const void* W8, const float* wscale, void* C, int ldc, const float* bias, const void* res,
+                     int ldres, const float* rowvec, int ld_rowvec, int rows_per_batch, int M, int N, int K, float alpha,
+                     int flags, void* stream) {
+    GemmParams p{};
+    p.A = (const bf16*)A; p.W = (const bf16*)W8; p.wscale = wscale; p.C = C; p.bias = bias; p.res = (const bf16*)res; p.rowvec = rowvec;
+    p.ldrv = ld_rowvec > 0 ? ld_rowvec : N;
+    p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldc = ldc; p.ldres = ldres; p.rows_per_batch = rows_per_batch;
+    p.alpha = alpha; p.flags = flags;
+    if (int e = check_common(p)) return e;
+    if ((K & 15) || !wscale) return SIDLSG_EINVAL;
+    const unsigned long long ab = ((unsigned long long)(M - 1) * lda + K) * 2ull, wb = (unsigned long long)N * K;
+    if (!fits31(ab) || !fits31(wb)) return SIDLSG_EINVAL;
+    p.a_bytes = (unsigned)ab; p.w_bytes = (unsigned)wb;
+    const int tiles = ((M + F8_T - 1) / F8_T) * ((N + F8_T - 1) / F8_T);
+    hipLaunchKernelGGL((gemm_fp8w_kernel<0>), dim3(tiles), dim3(NTHREADS), 0, (hipStream_t)stream, p);
+    return sidlsg_last_error();
+}
+
+int sidlsg_conv3x3_fp8w(const void* X, int ldx, const void* W8, const float* wscale, void* Y, int ldc, const float* bias,
+                        const void* res, int ldres, const float* rowvec, int ld_rowvec, int B, int H, int Wd, int Cin, int Cout,
+                        int stride, int ups, float alpha, int flags, void* stream) {
+    if ((stride != 1 && stride != 2) || (Cin & 15) || !wscale) return SIDLSG_EINVAL;
+    if (ups && ((H | Wd) & 1)) return SIDLSG_EINVAL;
+    GemmParams p{};
+    p.A = (const bf16*)X; p.W = (const bf16*)W8; p.wscale = wscale; p.C = Y; p.bias = bias; p.res = (const bf16*)res; p.rowvec = rowvec;
+    p.ldrv = ld_rowvec > 0 ? ld_rowvec : Cout;
+    p.H = H; p.Wd = Wd; p.Cin = Cin; p.stride = stride; p.ups = ups;
+    p.Ho = (H + 2 - 3) / stride + 1; p.Wo = (Wd + 2 - 3) / stride + 1;
+    p.M = B * p.Ho * p.Wo; p.N = Cout; p.K = 9 * Cin; p.lda = ldx; p.ldc = ldc; p.ldres = ldres;
+    p.rows_per_batch = p.Ho * p.Wo; p.alpha = alpha; p.flags = flags;
+    if (int e = check_common(p)) return e;
+    const int Hs = ups ? H / 2 : H, Wss = ups ? Wd / 2 : Wd;
+    const unsigned long long ab = (((unsigned long long)B * Hs * Wss - 1) * ldx + Cin) * 2ull, wb = (unsigned long long)Cout * 9 * Cin;
+    if (!fits31(ab) || !fits31(wb)) return SIDLSG_EINVAL;
+    p.a_bytes = (unsigned)ab; p.w_bytes = (unsigned)wb;
+    const int tiles = ((p.M + F8_T - 1) / F8_T) * ((p.N + F8_T - 1) / F8_T);
+    hipLaunchKernelGGL((gemm_fp8w_kernel<2>), dim3(tiles), dim3(NTHREADS), 0, (hipStream_t)stream, p);
+    return sidlsg_last_error();
 }
 
 }  // extern "C"

@@ -99,6 +99,28 @@ def ensure_stream_workspace(stream, nbytes=256 << 20):
     return _stream_ws[key]
 
 
+class Fp8Weight:
+    """A frozen GEMM / conv weight in the fp8-weight format of include/sidlsg_hip.h: e4m3 bytes [N][K] + one fp32 scale per
+    output channel.  Stands where the bf16 compute copy stands in gemm() / conv3x3() (forward only: the backward-data
+    operand of a layer stays bf16)."""
+    dtype = 'fp8_e4m3'
+
+    def __init__(self, w_bf16):
+        w = w_bf16.detach()
+        if w.dtype != BF16 or w.ndim != 2 or not w.is_contiguous() or w.shape[1] % 16:
+            raise RuntimeError('Fp8Weight: needs a contiguous bf16 [N, K] matrix with K % 16 == 0')
+        self.shape = w.shape
+        self.q = torch.empty(w.shape, device=w.device, dtype=torch.uint8)
+        self.scale = torch.empty(w.shape[0], device=w.device, dtype=F32)
+        self.requantize(w)
+
+    def requantize(self, w_bf16):
+        lib.sidlsg_quantize_fp8_rows(_p(w_bf16), _p(self.q), _p(self.scale), self.shape[0], self.shape[1], _s())
+
+    def dequantize(self):
+        return self.q.view(torch.float8_e4m3fn).float() * self.scale[:, None]
+
+
 # raw launches
 def gemm(a, w16, out=None, bias=None, res=None, rowvec=None, rows_per_batch=1, alpha=1.0, out_f32=False, lda=None):
     """C[M,N] = alpha*A[M,K] W[N,K]^T + bias + rowvec[m//rpb] + res"""
@@ -112,6 +134,13 @@ def gemm(a, w16, out=None, bias=None, res=None, rowvec=None, rows_per_batch=1, a
     ensure_workspace(a.device)
     if out is None:
         out = torch.empty((M, N), device=a.device, dtype=F32 if (out_f32 or f32) else BF16)
+    if isinstance(w16, Fp8Weight):
+        if a.dtype != BF16:
+            raise RuntimeError('fp8 weights take bf16 activations')
+        lib.sidlsg_gemm_fp8w(_p(a), lda, _p(w16.q), _p(w16.scale), _p(out), out.stride(0), _p(bias), _p(res),
+                             res.stride(0) if res is not None else 0, _p(rowvec), rowvec.stride(0) if rowvec is not None else 0,
+                             rows_per_batch, M, N, K, float(alpha), 1 if out_f32 else 0, _s())
+        return out
     _fn('gemm', a.dtype, '_bf16')(_p(a), lda, _p(w16), _p(out), out.stride(0), _p(bias), _p(res), res.stride(0) if res is not None else 0,
                                   _p(rowvec), rowvec.stride(0) if rowvec is not None else 0, rows_per_batch, M, N, K, float(alpha),
                                   0 if f32 else (1 if out_f32 else 0), _s())
@@ -129,6 +158,13 @@ def conv3x3(x, w16, bias=None, res=None, rowvec=None, stride=1, ups=0, out_f32=F
         raise RuntimeError('fp32 activations need the fp32 compute copy of the weights')
     ensure_workspace(x.device)
     out = torch.empty((B, Ho, Wo, Cout), device=x.device, dtype=F32 if (out_f32 or f32) else BF16)
+    if isinstance(w16, Fp8Weight):
+        if x.dtype != BF16:
+            raise RuntimeError('fp8 weights take bf16 activations')
+        lib.sidlsg_conv3x3_fp8w(_p(x), Cin, _p(w16.q), _p(w16.scale), _p(out), Cout, _p(bias), _p(res), Cout if res is not None else 0,
+                                _p(rowvec), rowvec.stride(0) if rowvec is not None else 0, B, H, W, Cin, Cout, stride, ups, 1.0,
+                                1 if out_f32 else 0, _s())
+        return out
     _fn('conv3x3', x.dtype, '_bf16')(_p(x), Cin, _p(w16), _p(out), Cout, _p(bias), _p(res), Cout if res is not None else 0, _p(rowvec),
                                      rowvec.stride(0) if rowvec is not None else 0, B, H, W, Cin, Cout, stride, ups, 1.0,
                                      0 if f32 else (1 if out_f32 else 0), _s())

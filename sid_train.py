@@ -62,6 +62,7 @@ OPTIONS = [
     (('--init_timestep',), dict(type=int, default=625, show_default=True, metavar='INT', help='t_init, in [0,999]')),
     (('--fp16',), dict(type=bool, default=False, show_default=True, metavar='BOOL', help='Reference fp16 recipe (optimizer eps 1e-6)')),
     (('--precision',), dict(type=click.Choice(['bf16', 'fp32']), default='bf16', show_default=True, help='Compute dtype of the HIP path (not a reference option)')),
+    (('--teacher-weights', 'teacher_weights'), dict(type=click.Choice(['bf16', 'fp8']), default='bf16', show_default=True, help='fp8: frozen teacher forward weights as e4m3 + per-channel scales (not a reference option)')),
     (('--ls',), dict(type=click.FloatRange(min=0, min_open=True), default=1, show_default=True, help='Loss scaling')),
     (('--lsg',), dict(type=click.FloatRange(min=0, min_open=True), default=1, show_default=True, help='Loss scaling G')),
     (('--alpha',), dict(type=click.FloatRange(min=-1000, min_open=True), default=1, show_default=True, help='L2-alpha*L1')),
@@ -107,7 +108,7 @@ def build_config(o):
     extra = {} if o.optimizer == 'adam' else dict(weight_decay=0.01)
     c.fake_score_optimizer_kwargs = EasyDict(class_name=cls, lr=o.lr, betas=[0.0, 0.999], eps=eps, **extra)
     c.g_optimizer_kwargs = EasyDict(class_name=cls, lr=o.glr, betas=[0.0, 0.999], eps=eps, **extra)
-    c.network_kwargs = EasyDict(use_fp16=o.fp16, compute_dtype=o.get('precision', 'bf16'))
+    c.network_kwargs = EasyDict(use_fp16=o.fp16, compute_dtype=o.get('precision', 'bf16'), teacher_weights=o.get('teacher_weights', 'bf16'))
     c.loss_kwargs = EasyDict()
     c.init_timestep = o.init_timestep
     c.total_kimg = max(int(o.duration * 1000), 1)

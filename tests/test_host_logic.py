@@ -256,7 +256,7 @@ def test_cli_dry_run_builds_reference_config(tmp_path):
     assert c.g_optimizer_kwargs == dict(class_name='torch.optim.AdamW', lr=2e-6, betas=[0.0, 0.999], eps=1e-6, weight_decay=0.01)
     assert c.fake_score_optimizer_kwargs['lr'] == 1e-6
     assert c.dataset_prompt_text_kwargs['class_name'] == 'sid_lsg_amd.data.PromptDataset'
-    assert c.network_kwargs == dict(use_fp16=True, compute_dtype='bf16')
+    assert c.network_kwargs == dict(use_fp16=True, compute_dtype='bf16', teacher_weights='bf16')
     # errors the reference raises as ClickException
     bad = CliRunner().invoke(sid_train.main, ['--outdir', 'x', '--data_prompt_text', str(tmp_path), '--resume', 'nope.pt', '--seed', '0', '-n'])
     assert bad.exit_code != 0 and 'training-state' in bad.output

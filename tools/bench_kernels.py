@@ -2,7 +2,7 @@
 """Per-shape kernel micro-benchmarks on the SD1.5 work list -- the optimisation harness.
 Prints achieved TFLOP/s (contractions) or GB/s (HBM-bound kernels) per shape.  GPU only.
 
-    python tools/bench_kernels.py [conv] [gemm] [wgrad] [attn] [norm] [--batch 16]
+    python tools/bench_kernels.py [conv] [gemm] [wgrad] [attn] [norm] [fp8] [--batch 16]
 """
 import os
 import sys
@@ -70,6 +70,24 @@ def bench_gemm(B):
         tot_f += fl; tot_t += t
         print(f'  {M}x{N}x{K}: {t * 1e6:8.1f} us  {fl / t / 1e12:7.1f} TF/s')
     print(f'  aggregate {tot_f / tot_t / 1e12:.1f} TF/s')
+
+
+def bench_fp8(B):
+    """fp8-weight forward contractions next to the bf16 kernels on the same shapes."""
+    print('--- fp8-weight vs bf16 forward: TFLOP/s')
+    for M, N, K in ((B * 4096, 320, 320), (B * 4096, 2560, 320), (B * 4096, 320, 1280), (B * 1024, 640, 640), (B * 1024, 5120, 640),
+                    (B * 256, 1280, 1280), (B * 256, 10240, 1280), (B * 256, 1280, 5120)):
+        a, w = r(M, K), r(N, K, scale=0.02)
+        q = ops.Fp8Weight(w)
+        t16, t8 = timeit(lambda: ops.gemm(a, w)), timeit(lambda: ops.gemm(a, q))
+        fl = 2.0 * M * N * K
+        print(f'  gemm {M}x{N}x{K}: bf16 {t16 * 1e6:8.1f} us {fl / t16 / 1e12:6.1f} | fp8w {t8 * 1e6:8.1f} us {fl / t8 / 1e12:6.1f} TF/s')
+    for H, cin, cout in ((64, 320, 320), (64, 640, 320), (32, 640, 640), (32, 1280, 640), (16, 1280, 1280), (16, 2560, 1280), (8, 2560, 1280)):
+        x, w = r(B, H, H, cin), r(cout, 9 * cin, scale=0.02)
+        q = ops.Fp8Weight(w)
+        t16, t8 = timeit(lambda: ops.conv3x3(x, w)), timeit(lambda: ops.conv3x3(x, q))
+        fl = 2.0 * B * H * H * cout * 9 * cin
+        print(f'  conv {H}x{H} {cin}->{cout}: bf16 {t16 * 1e6:8.1f} us {fl / t16 / 1e12:6.1f} | fp8w {t8 * 1e6:8.1f} us {fl / t8 / 1e12:6.1f} TF/s')
 
 
 def bench_wgrad(B):
