@@ -62,100 +62,227 @@ DEVFN bf16x8 buf_ld8(__amdgpu_buffer_rsrc_t r, unsigned off) {
 
 // MODE 0: dense rows.  MODE 1: conv3x3 with Cin % 64 == 0 (a K-tile lies inside one tap).  MODE 2: conv3x3, any Cin % 8 == 0.
 // Shared epilogue: lane (lg, li) holds, for pixel row m = mbase + mi*16 + li, 8 (or 4) consecutive channels per tile pair.
-template <int MT, int NT>
-DEVFN void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[NT][MT], int mbase, int nbase, int li, int lg) {
-    const int m0 = mbase, wm0 = 0, n0 = nbase, wn0 = 0;
-    // ---- epilogue: lane (lg, li) holds, for pixel row m = .. + li, 8 (or 4) consecutive channels
-    const bool vec_ok = (p.N & 7) == 0;
+//
+// Every global load of the epilogue is issued BEFORE the first store.  C is not __restrict__, so a load that follows a store
+// in program order stays behind it: the earlier form (load bias / rowvec / residual, add, store, per 16-row block) made
+// MT = 4 dependent round trips through a memory system that the co-resident blocks' tile DMAs keep saturated -- 5.5 us per
+// 128 x 160 tile in the phase trace of tools/ab/gemm_trace.py, as long as the whole K loop of a K = 320 GEMM.  The bias
+// (a function of the column only) can be fetched before the K loop (epilogue_prefetch) and costs nothing at all.
+template <int NT>
+struct EpiPre {
+    float b[(NT + 1) / 2][8];
+};
+
+template <int NT>
+DEVFN void epilogue_prefetch(const GemmParams& p, EpiPre<NT>& pre, int nbase, int lg) {
+#pragma unroll
+    for (int pr = 0; pr < (NT + 1) / 2; pr++) {
+        const bool paired = (2 * pr + 1) < NT;
+        const int cnt = paired ? 8 : 4;
+        const int n = nbase + 32 * pr + lg * cnt;
+#pragma unroll
+        for (int e = 0; e < 8; e++) pre.b[pr][e] = 0.f;
+        if (p.bias && (p.N & 7) == 0 && n < p.N) {
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.bias + n);
+            pre.b[pr][0] = b0[0]; pre.b[pr][1] = b0[1]; pre.b[pr][2] = b0[2]; pre.b[pr][3] = b0[3];
+            if (paired) {
+                const f32x4 b1 = *reinterpret_cast<const f32x4*>(p.bias + n + 4);
+                pre.b[pr][4] = b1[0]; pre.b[pr][5] = b1[1]; pre.b[pr][6] = b1[2]; pre.b[pr][7] = b1[3];
+            }
+        }
+    }
+}
+
+// stage != nullptr (bf16 outputs, N % 8 == 0): the finished values go to an LDS image of the block's output tile
+// (row stride ldr elements, origin (tm0, tn0)) instead of global memory; gemm_store_rows then writes it out row-major.
+//
+// CODE SIZE is a first-order cost here.  One fully unrolled epilogue that tests every flag per 8-channel group (SiLU with its
+// exp, fp32 / accumulate outputs, ragged N, residual, row vector) made gemm_v3_kernel 113 KB of code -- 97 KB of it epilogue --
+// against a 64 KB instruction cache shared by two CUs whose four resident blocks are all in different phases.  The phase
+// trace (tools/ab/gemm_trace.py) showed the epilogue of one 128 x 160 tile taking 5.5 - 7.3 us, as long as the whole K loop
+// of a K = 320 GEMM, and 1.5 us with a bias-only build: the time was instruction fetch through a memory system that the
+// tile DMAs keep saturated.  Hence: the feature set is decided ONCE per call (FEAT, uniform branch) and each hot
+// combination (bf16 output, N % 8 == 0, no activation: bias only / + residual / + row vector) is its own compact
+// straight-line instantiation; everything else takes the generic instantiation (FEAT 4, flags read at run time).
+template <int MT, int NT, int FEAT>      // FEAT: 0 bias only, 1 + residual, 2 + row vector, 4 generic
+DEVFN void epilogue_rows8(const GemmParams& p, f32x4 (&acc)[NT][MT], int mbase, int nbase, int li, int lg,
+                          const EpiPre<NT>& pre, bf16* stage, int tm0, int tn0, int ldr) {
+    constexpr int PR = (NT + 1) / 2;
+    constexpr bool GENERIC = (FEAT & 4) != 0;
+    const bool has_res = GENERIC ? p.res != nullptr : (FEAT & 1) != 0;
+    const bool has_rv = GENERIC ? p.rowvec != nullptr : (FEAT & 2) != 0;
+    const int flags = GENERIC ? p.flags : 0;
+    // rowvec (one vector per batch image): the 16*MT <= 64 rows of this wave lie in at most two images when an image has
+    // >= 64 rows (always on the SD path: 8 x 8 latents at the coarsest level) -> two vectors, selected per row
+    f32x4 rvv[2][PR][2];
+    bf16x8 rsv[MT][PR];
+    const int img0 = (mbase < p.M ? mbase : 0) / p.rows_per_batch;
+    const bool rv_two = has_rv && (!GENERIC || p.rows_per_batch >= 16 * MT);
+    if (rv_two) {
+        const int last = (min(mbase + 16 * MT, p.M) - 1) / p.rows_per_batch;
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const float* rv = p.rowvec + (size_t)(h ? max(last, img0) : img0) * p.ldrv;
+#pragma unroll
+            for (int pr = 0; pr < PR; pr++) {
+                const bool paired = (2 * pr + 1) < NT;
+                const int n = nbase + 32 * pr + lg * (paired ? 8 : 4);
+                rvv[h][pr][0] = rvv[h][pr][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (mbase < p.M && n < p.N) {
+                    rvv[h][pr][0] = *reinterpret_cast<const f32x4*>(rv + n);
+                    if (paired) rvv[h][pr][1] = *reinterpret_cast<const f32x4*>(rv + n + 4);
+                }
+            }
+        }
+    }
+    if (has_res) {
+#pragma unroll
+        for (int mi = 0; mi < MT; mi++) {
+            const int m = mbase + mi * 16 + li;
+#pragma unroll
+            for (int pr = 0; pr < PR; pr++) {
+                const bool paired = (2 * pr + 1) < NT;
+                const int n = nbase + 32 * pr + lg * (paired ? 8 : 4);
+                rsv[mi][pr] = zero8();
+                if (m < p.M && n < p.N) {
+                    const bf16* rp = p.res + (size_t)m * p.ldres + n;
+                    if (paired) rsv[mi][pr] = ld8(rp);
+                    else {
+                        const bf16x4 t = *reinterpret_cast<const bf16x4*>(rp);
+                        rsv[mi][pr][0] = t[0]; rsv[mi][pr][1] = t[1]; rsv[mi][pr][2] = t[2]; rsv[mi][pr][3] = t[3];
+                    }
+                }
+            }
+        }
+    }
 #pragma unroll
     for (int mi = 0; mi < MT; mi++) {
-        const int m = m0 + wm0 + mi * 16 + li;
+        const int m = mbase + mi * 16 + li;
         if (m >= p.M) continue;
-        const float* rv = p.rowvec ? p.rowvec + (size_t)(m / p.rows_per_batch) * p.ldrv : nullptr;
+        const bool first_img = rv_two && (m / p.rows_per_batch == img0);
 #pragma unroll
-        for (int pr = 0; pr < (NT + 1) / 2; pr++) {
+        for (int pr = 0; pr < PR; pr++) {
             const bool paired = (2 * pr + 1) < NT;
             const int cnt = paired ? 8 : 4;
-            const int n = n0 + wn0 + 32 * pr + lg * cnt;
+            const int n = nbase + 32 * pr + lg * cnt;
+            if (n >= p.N) continue;
             float v[8];
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 v[r] = acc[2 * pr][mi][r];
                 v[4 + r] = paired ? acc[(2 * pr + 1) < NT ? 2 * pr + 1 : 2 * pr][mi][r] : 0.f;
             }
-            if (n >= p.N) continue;
-            if (vec_ok && n + cnt <= p.N) {
-                // vector path: 8 (4) consecutive channels, all in range
-                float bb[8] = {0, 0, 0, 0, 0, 0, 0, 0}, rr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-                if (p.bias) {
-                    const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.bias + n);
-                    bb[0] = b0[0]; bb[1] = b0[1]; bb[2] = b0[2]; bb[3] = b0[3];
-                    if (cnt == 8) { const f32x4 b1 = *reinterpret_cast<const f32x4*>(p.bias + n + 4); bb[4] = b1[0]; bb[5] = b1[1]; bb[6] = b1[2]; bb[7] = b1[3]; }
-                }
-                if (rv) {
-                    const f32x4 b0 = *reinterpret_cast<const f32x4*>(rv + n);
-                    bb[0] += b0[0]; bb[1] += b0[1]; bb[2] += b0[2]; bb[3] += b0[3];
-                    if (cnt == 8) { const f32x4 b1 = *reinterpret_cast<const f32x4*>(rv + n + 4); bb[4] += b1[0]; bb[5] += b1[1]; bb[6] += b1[2]; bb[7] += b1[3]; }
-                }
-                if (p.res) {
-                    const bf16* rp = p.res + (size_t)m * p.ldres + n;
-                    if (cnt == 8) { const bf16x8 t = ld8(rp);
 #pragma unroll
-                        for (int e = 0; e < 8; e++) rr[e] = bf2f(t[e]); }
-                    else { const bf16x4 t = *reinterpret_cast<const bf16x4*>(rp);
-#pragma unroll
-                        for (int e = 0; e < 4; e++) rr[e] = bf2f(t[e]); }
-                }
-#pragma unroll
-                for (int e = 0; e < 8; e++) {
-                    float x = v[e] * p.alpha * ((p.wscale && e < cnt) ? p.wscale[n + e] : 1.f) + bb[e] + rr[e];
-                    if (p.flags & F_SILU) x = silu_f(x);
-                    v[e] = x;
-                }
-                if (p.flags & F_OUT_F32) {
-                    float* c = reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n;
-                    if (p.flags & F_ACCUM) {
-                        for (int e = 0; e < cnt; e++) c[e] += v[e];
-                    } else {
-                        *reinterpret_cast<f32x4*>(c) = (f32x4){v[0], v[1], v[2], v[3]};
-                        if (cnt == 8) *reinterpret_cast<f32x4*>(c + 4) = (f32x4){v[4], v[5], v[6], v[7]};
-                    }
+            for (int e = 0; e < 8; e++) {
+                float x = v[e] * p.alpha + pre.b[pr][e];
+                if (rv_two) x += first_img ? rvv[0][pr][e >> 2][e & 3] : rvv[1][pr][e >> 2][e & 3];
+                else if (GENERIC && has_rv) x += p.rowvec[(size_t)(m / p.rows_per_batch) * p.ldrv + n + e];
+                if (has_res) x += bf2f(rsv[mi][pr][e]);
+                if (GENERIC && (flags & F_SILU)) x = silu_f(x);
+                v[e] = x;
+            }
+#ifdef SIDLSG_EXP_NOSTORE      // measurement build: everything but the global stores
+            if (v[0] != 123456.75f) continue;
+#endif
+            if (GENERIC && (flags & F_OUT_F32)) {
+                float* c = reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n;
+                if (flags & F_ACCUM) {
+                    for (int e = 0; e < cnt; e++) c[e] += v[e];
                 } else {
-                    bf16* c = reinterpret_cast<bf16*>(p.C) + (size_t)m * p.ldc + n;
-                    if (cnt == 8) {
-                        bf16x8 o;
-#pragma unroll
-                        for (int e = 0; e < 8; e++) o[e] = f2bf(v[e]);
-                        st8(c, o);
-                    } else {
-                        bf16x4 o;
-#pragma unroll
-                        for (int e = 0; e < 4; e++) o[e] = f2bf(v[e]);
-                        *reinterpret_cast<bf16x4*>(c) = o;
-                    }
+                    *reinterpret_cast<f32x4*>(c) = (f32x4){v[0], v[1], v[2], v[3]};
+                    if (cnt == 8) *reinterpret_cast<f32x4*>(c + 4) = (f32x4){v[4], v[5], v[6], v[7]};
                 }
             } else {
-                // ragged N: element-wise, guarded
-                for (int e = 0; e < cnt; e++) {
-                    const int nn = n + e;
-                    if (nn >= p.N) break;
-                    float x = v[e] * p.alpha * (p.wscale ? p.wscale[nn] : 1.f);
-                    if (p.bias) x += p.bias[nn];
-                    if (rv) x += rv[nn];
-                    if (p.res) x += bf2f(p.res[(size_t)m * p.ldres + nn]);
-                    if (p.flags & F_SILU) x = silu_f(x);
-                    if (p.flags & F_OUT_F32) {
-                        float* c = reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + nn;
-                        *c = (p.flags & F_ACCUM) ? *c + x : x;
-                    } else {
-                        reinterpret_cast<bf16*>(p.C)[(size_t)m * p.ldc + nn] = f2bf(x);
-                    }
+                bf16* c = stage ? stage + (m - tm0) * ldr + (n - tn0) : reinterpret_cast<bf16*>(p.C) + (size_t)m * p.ldc + n;
+                if (cnt == 8) {
+                    bf16x8 o;
+#pragma unroll
+                    for (int e = 0; e < 8; e++) o[e] = f2bf(v[e]);
+                    st8(c, o);
+                } else {
+                    bf16x4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; e++) o[e] = f2bf(v[e]);
+                    *reinterpret_cast<bf16x4*>(c) = o;
                 }
             }
         }
     }
 }
 
+template <int MT, int NT, bool HOT = true>       // HOT = false: the caller has already peeled the hot combinations off
+DEVFN void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[NT][MT], int mbase, int nbase, int li, int lg,
+                         const EpiPre<NT>& pre, bf16* stage = nullptr, int tm0 = 0, int tn0 = 0, int ldr = 0) {
+    constexpr int PR = (NT + 1) / 2;
+    if ((p.N & 7) == 0) {
+        // ---- N % 8 == 0: every lane's 8 (4) channels are all in range or all out of range
+        const bool plain = HOT && !(p.flags & (F_SILU | F_OUT_F32 | F_ACCUM));
+#ifndef SIDLSG_EXP_GENERIC_EPILOGUE
+        if (plain && !p.rowvec) {
+            if (!p.res) epilogue_rows8<MT, NT, 0>(p, acc, mbase, nbase, li, lg, pre, stage, tm0, tn0, ldr);
+            else epilogue_rows8<MT, NT, 1>(p, acc, mbase, nbase, li, lg, pre, stage, tm0, tn0, ldr);
+        } else if (plain && !p.res && p.rows_per_batch >= 16 * MT) {
+            epilogue_rows8<MT, NT, 2>(p, acc, mbase, nbase, li, lg, pre, stage, tm0, tn0, ldr);
+        } else
+#endif
+        {
+            (void)plain;
+            epilogue_rows8<MT, NT, 4>(p, acc, mbase, nbase, li, lg, pre, stage, tm0, tn0, ldr);
+        }
+        return;
+    }
+    // ---- ragged N: element-wise, guarded
+#pragma unroll
+    for (int mi = 0; mi < MT; mi++) {
+        const int m = mbase + mi * 16 + li;
+        if (m >= p.M) continue;
+        const float* rv = p.rowvec ? p.rowvec + (size_t)(m / p.rows_per_batch) * p.ldrv : nullptr;
+#pragma unroll
+        for (int pr = 0; pr < PR; pr++) {
+            const bool paired = (2 * pr + 1) < NT;
+            const int cnt = paired ? 8 : 4;
+            const int n = nbase + 32 * pr + lg * cnt;
+            float v[8];
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                v[r] = acc[2 * pr][mi][r];
+                v[4 + r] = paired ? acc[(2 * pr + 1) < NT ? 2 * pr + 1 : 2 * pr][mi][r] : 0.f;
+            }
+            for (int e = 0; e < cnt; e++) {
+                const int nn = n + e;
+                if (nn >= p.N) break;
+                float x = v[e] * p.alpha;
+                if (p.bias) x += p.bias[nn];
+                if (rv) x += rv[nn];
+                if (p.res) x += bf2f(p.res[(size_t)m * p.ldres + nn]);
+                if (p.flags & F_SILU) x = silu_f(x);
+                if (p.flags & F_OUT_F32) {
+                    float* c = reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + nn;
+                    *c = (p.flags & F_ACCUM) ? *c + x : x;
+                } else {
+                    reinterpret_cast<bf16*>(p.C)[(size_t)m * p.ldc + nn] = f2bf(x);
+                }
+            }
+        }
+    }
+}
+
+// Row-major write-out of a BM x BN bf16 output tile staged in LDS by gemm_epilogue(stage=...).  In the MFMA accumulator
+// layout one store instruction covers 16 rows x 64 bytes: half cache lines, which the L2 takes at half its write rate
+// (FF-in 65536 x 2560 x 320: 335 MB of output left at 2.2 TB/s and were 58 % of the kernel -- the one-K-tile build of
+// tools/ab/ffin.py).  From LDS, consecutive lanes write consecutive 16-byte chunks of a row: BN*2-byte contiguous runs.
+template <int BM, int BN>
+DEVFN void gemm_store_rows(const GemmParams& p, const bf16* stage, int m0, int n0, int ldr, int tid) {
+    constexpr int CPR = BN / 8;                 // 16-byte chunks per row
+#pragma unroll
+    for (int i = 0; i < (BM * CPR + NTHREADS - 1) / NTHREADS; i++) {
+        const int c = tid + i * NTHREADS;
+        const int row = c / CPR, col = (c - row * CPR) * 8;
+        if ((BM * CPR) % NTHREADS != 0 && row >= BM) break;
+        const int m = m0 + row, n = n0 + col;
+        if (m < p.M && n < p.N) st8(reinterpret_cast<bf16*>(p.C) + (size_t)m * p.ldc + n, *reinterpret_cast<const bf16x8*>(stage + row * ldr + col));
+    }
+}
 
 template <int BM, int BN, int MODE>
 __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_kernel(GemmParams p) {   // 2 blocks/CU: <= 256 registers
@@ -363,7 +490,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_kernel(GemmParams p) { 
         }
         return;
     }
-    gemm_epilogue<MT, NT>(p, acc, m0 + wm0, n0 + wn0, li, lg);
+    EpiPre<NT> pre;
+    epilogue_prefetch<NT>(p, pre, n0 + wn0, lg);
+    gemm_epilogue<MT, NT>(p, acc, m0 + wm0, n0 + wn0, li, lg, pre);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -492,7 +621,24 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_fp8w_kernel(GemmParams p) {
         if (kt + 1 < nk) store_tile(buf ^ 1);
         __syncthreads();
     }
-    gemm_epilogue<4, 4>(p, acc, m0 + wm0, n0 + wn0, li, lg);
+    // per-output-channel dequantisation scales, applied in place (lane (lg, li): channels n .. n+7 of each tile pair)
+#pragma unroll
+    for (int pr = 0; pr < 2; pr++) {
+        const int n = n0 + wn0 + 32 * pr + lg * 8;
+        float sc[8];
+#pragma unroll
+        for (int e = 0; e < 8; e++) sc[e] = (n + e < p.N) ? p.wscale[n + e] : 0.f;
+#pragma unroll
+        for (int mi = 0; mi < 4; mi++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                acc[2 * pr][mi][r] *= sc[r];
+                acc[2 * pr + 1][mi][r] *= sc[4 + r];
+            }
+    }
+    EpiPre<4> pre;
+    epilogue_prefetch<4>(p, pre, n0 + wn0, lg);
+    gemm_epilogue<4, 4>(p, acc, m0 + wm0, n0 + wn0, li, lg, pre);
 }
 
 // per-row e4m3 quantisation of a bf16 matrix [rows][cols] (cols % 8 == 0): scale[r] = max|x| / 448 (1 if the row is zero),
@@ -592,6 +738,15 @@ DEVFN int wsw(int r) {
     return rr < 64 ? ((q & 1) | (((q >> 2) & 3) << 1)) : (q & 7);
 }
 
+#ifdef SIDLSG_EXP_TRACE           // measurement build (tools/ab/gemm_trace.py): per-block phase timestamps, 100 MHz wall clock
+__device__ unsigned long long* g_trace = nullptr;
+extern "C" int sidlsg_exp_set_trace(void* ptr) { return hipMemcpyToSymbol(HIP_SYMBOL(g_trace), &ptr, sizeof(ptr)) == hipSuccess ? 0 : -1; }
+#define TRACE(i) do { if (g_trace && threadIdx.x == 0) g_trace[(size_t)blockIdx.x * 8 + (i)] = wall_clock64(); } while (0)
+#define TRACE_HWID() do { if (g_trace && threadIdx.x == 0) { unsigned h, x; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(h)); asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x)); g_trace[(size_t)blockIdx.x * 8 + 7] = ((unsigned long long)x << 32) | h; } } while (0)
+#else
+#define TRACE(i)
+#define TRACE_HWID()
+#endif
 #ifndef SIDLSG_V3_SCHED_FENCE
 #define SIDLSG_V3_SCHED_FENCE 1
 #endif
@@ -614,7 +769,11 @@ DEVFN void gemm_v3_body(const GemmParams& p) {
     // us on the 8x8 2560->1280 conv.)
     const int tiles_n = (p.N + BN - 1) / BN;
     const int tiles_m = (p.M + BM - 1) / BM;
+#ifdef SIDLSG_EXP_K1             // measurement build: one K-tile per output tile (prologue + epilogue cost)
+    const int nk_all = 1;
+#else
     const int nk_all = (p.K + BK - 1) / BK;
+#endif
     const int nsplit = p.kt_per_split ? (nk_all + p.kt_per_split - 1) / p.kt_per_split : 1;
     const int ntile = tiles_n * tiles_m;
     int bid = blockIdx.x;
@@ -764,11 +923,15 @@ DEVFN void gemm_v3_body(const GemmParams& p) {
     };
 
     bf16x8 fa0[MT], fw0[NT], fa1[MT], fw1[NT];
+    EpiPre<NT> pre;
     if constexpr (STAGES == 2) {
+    TRACE(0); TRACE_HWID();
     issue(kt_begin, 0);
+    if (!p.kt_per_split) epilogue_prefetch<NT>(p, pre, n0 + wn0, lg);     // behind the first tile's DMA, used after the loop
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+    TRACE(1);
     read_frags(0, 0, fa0, fw0);
     if (kt_begin + 1 < nk) issue(kt_begin + 1, 1);
     // One K-tile.  The steady state, the last-but-one tile (nothing left to fetch) and the last tile are separate
@@ -820,7 +983,26 @@ DEVFN void gemm_v3_body(const GemmParams& p) {
         }
         return;
     }
-    gemm_epilogue<MT, NT>(p, acc, m0 + wm0, n0 + wn0, li, lg);
+#ifndef SIDLSG_EXP_DIRECT_STORE
+    if (!(p.flags & (F_OUT_F32 | F_ACCUM)) && (p.N & 7) == 0) {
+        constexpr int LDR = BN + 8;             // 336-byte rows: the 16 rows of a b128 write phase fall on distinct banks
+        __syncthreads();                        // every wave is done with the last K-tile: the ring becomes the tile image
+        TRACE(2);
+        gemm_epilogue<MT, NT>(p, acc, m0 + wm0, n0 + wn0, li, lg, pre, ring, m0, n0, LDR);
+        __syncthreads();
+        TRACE(3);
+        gemm_store_rows<BM, BN>(p, ring, m0, n0, LDR, tid);
+        TRACE(4);
+#ifdef SIDLSG_EXP_TRACE
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        TRACE(5);
+#endif
+        return;
+    }
+    gemm_epilogue<MT, NT, false>(p, acc, m0 + wm0, n0 + wn0, li, lg, pre);
+#else
+    gemm_epilogue<MT, NT>(p, acc, m0 + wm0, n0 + wn0, li, lg, pre);
+#endif
 }
 
 // (plain kernels over one body: a kernel template with a second non-type parameter got no host stub from hipcc 7.2)
