@@ -143,6 +143,9 @@ int sidlsg_transpose_w(const float* src, void* dst, int N, int K, int T, void* s
  *   struct sidlsg_tw_job { const float* src; void* dst; int N, K, T, blk0; };   (32 bytes, no padding)
  * sorted by blk0 = index of the job's first 32x32 tile (job i covers T*ceil(N/32)*ceil(K/32) tiles); nblocks = total. */
 int sidlsg_transpose_w_batched(const void* jobs, int njobs, int nblocks, void* stream);
+/* Same, from the bf16 COMPUTE copies (src of a record points at bf16 [N][T][K]; 4 instead of 6 bytes per parameter):
+ * 64x64 tiles -> blk0 / nblocks count ceil(N/64)*ceil(K/64) tiles per tap; N and K multiples of 8. */
+int sidlsg_transpose_w16_batched(const void* jobs, int njobs, int nblocks, void* stream);
 
 /* ---- reference plugin op: torch_utils/ops/bias_act.cpp:32 `bias_act(x,b,xref,yref,dy,grad,dim,act,alpha,gain,clamp)`
  * act: 1 linear 2 relu 3 lrelu 4 tanh 5 sigmoid 6 elu 7 selu 8 softplus 9 swish (bias_act.py:23-33).

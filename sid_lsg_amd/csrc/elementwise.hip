@@ -319,6 +319,48 @@ __global__ void transpose_w_batched_kernel(const TwJob* __restrict__ jobs, int n
     }
 }
 
+// bf16 -> bf16 variant: reads the bf16 COMPUTE copies (which the optimizer kernel has just written) instead of the fp32
+// masters -- 4 instead of 6 bytes per parameter -- in 64 x 64 tiles with 16-byte global accesses on both sides.  Same job
+// record (src then points at bf16 data); blk0 counts 64 x 64 tiles; N and K multiples of 8.
+__global__ __launch_bounds__(256) void transpose_w16_batched_kernel(const TwJob* __restrict__ jobs, int njobs) {
+    __shared__ unsigned tile[64][33];        // [n][k / 2]: two bf16 per dword, 33-dword rows -> column reads hit distinct banks
+    int lo = 0, hi = njobs - 1;
+    const int bid = blockIdx.x;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (jobs[mid].blk0 <= bid) lo = mid; else hi = mid - 1;
+    }
+    const TwJob j = jobs[lo];
+    const bf16* src = reinterpret_cast<const bf16*>(j.src);
+    bf16* dst = reinterpret_cast<bf16*>(j.dst);
+    const int tk = (j.K + 63) / 64, tn = (j.N + 63) / 64;
+    int t = bid - j.blk0;
+    const int tap = t / (tk * tn); t -= tap * tk * tn;
+    const int n0 = (t / tk) * 64, k0 = (t % tk) * 64;
+    const int c8 = (threadIdx.x & 7) * 8, r0 = threadIdx.x >> 3;
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        const int n = n0 + r0 + 32 * i, k = k0 + c8;
+        u32x4 q = {0u, 0u, 0u, 0u};         // 8 consecutive k of row n = 4 dwords, already (k even | k odd << 16)
+        if (n < j.N && k < j.K) q = *reinterpret_cast<const u32x4*>(src + ((size_t)n * j.T + tap) * j.K + k);
+#pragma unroll
+        for (int d = 0; d < 4; d++) tile[r0 + 32 * i][(c8 >> 1) + d] = q[d];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        const int kl = r0 + 32 * i, k = k0 + kl, n = n0 + c8;
+        if (n < j.N && k < j.K) {
+            const int sh = (kl & 1) * 16;
+            u32x4 o;
+#pragma unroll
+            for (int d = 0; d < 4; d++)
+                o[d] = ((tile[c8 + 2 * d][kl >> 1] >> sh) & 0xffffu) | (((tile[c8 + 2 * d + 1][kl >> 1] >> sh) & 0xffffu) << 16);
+            *reinterpret_cast<u32x4*>(dst + ((size_t)k * j.T + (j.T - 1 - tap)) * j.N + n) = o;
+        }
+    }
+}
+
 // ---- SiD losses: loss value + closed-form gradients -------------------
 // per-sample prepass: nan flag over the inputs, and sum |x - y_r|
 __global__ void sid_sample_stats_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ c,
@@ -510,6 +552,12 @@ static int transpose_w_batched_t(const void* jobs, int njobs, int nblocks, void*
 }
 
 extern "C" {
+
+int sidlsg_transpose_w16_batched(const void* jobs, int njobs, int nblocks, void* stream) {
+    if (!jobs || njobs <= 0 || nblocks <= 0) return SIDLSG_EINVAL;
+    hipLaunchKernelGGL(transpose_w16_batched_kernel, dim3(nblocks), dim3(256), 0, (hipStream_t)stream, (const TwJob*)jobs, njobs);
+    return sidlsg_last_error();
+}
 
 #define SIDLSG_BOTH(name, tmpl, params, args) \
     int name params { return tmpl<bf16> args; }  \

@@ -700,9 +700,13 @@ def after_backward(x, cb):
     return _AfterBackward.apply(x, cb) if x.requires_grad else x
 
 
-def transpose_w_batched(jobs, njobs, nblocks, dtype=BF16):
-    """jobs: device uint8 tensor holding njobs sidlsg_tw_job records (see include/sidlsg_hip.h); dtype: of the destinations."""
-    _fn('transpose_w_batched', dtype)(_p(jobs), njobs, nblocks, _s())
+def transpose_w_batched(jobs, njobs, nblocks, dtype=BF16, src16=False):
+    """jobs: device uint8 tensor holding njobs sidlsg_tw_job records (see include/sidlsg_hip.h); dtype: of the destinations;
+    src16: the records' sources are the bf16 compute copies (64x64-tile job table)."""
+    if src16:
+        lib.sidlsg_transpose_w16_batched(_p(jobs), njobs, nblocks, _s())
+    else:
+        _fn('transpose_w_batched', dtype)(_p(jobs), njobs, nblocks, _s())
 
 
 def cast_bf16(src_f32, out=None):

@@ -549,3 +549,30 @@ def test_load_sd15_from_diffusers_layout_directory(dev, tmp_path):
     save_file(bad, str(root / 'text_encoder' / 'model.safetensors'))
     with pytest.raises(RuntimeError, match='text-encoder checkpoint'):
         sd_util.load_sd15(str(root), None, dev, torch.float32)
+
+
+@pytest.mark.parametrize('cfg_name', ['tiny', 'tiny40', 'tiny21'])
+def test_batched_backward_operands_from_bf16_copies(dev, cfg_name):
+    """The one-launch refresh of all backward-data operands (bf16 mode: 64x64-tile transposes of the bf16 compute copies,
+    sidlsg_transpose_w16_batched) equals the per-layer single-op path from the fp32 masters, bit for bit."""
+    from sid_lsg_amd import ops
+    from sid_lsg_amd.unet import CONFIGS, HConv3x3, HipUNet2DCondition, HLinear
+    net = HipUNet2DCondition(CONFIGS[cfg_name]).materialize(dev, seed=5)
+    assert net._flat['tw']['src16']
+    checked = 0
+    for mod in net.modules():
+        if isinstance(mod, HConv3x3) and mod.cin % 8 == 0 and mod.cout % 8 == 0:
+            ref = ops.transpose_w(mod.weight.permute(0, 2, 3, 1), mod.cout, mod.cin, 9, dtype=BF16)
+        elif isinstance(mod, HLinear) and not isinstance(mod, HConv3x3) and not getattr(mod, '_fused_member', False):
+            ref = ops.transpose_w(mod.weight, mod.weight.shape[0], mod.weight[0].numel(), 1, dtype=BF16)
+        else:
+            continue
+        assert torch.equal(mod.w16t.reshape(-1), ref.reshape(-1)), (type(mod).__name__, tuple(mod.weight.shape), float((mod.w16t.reshape(-1).float() - ref.reshape(-1).float()).abs().max()))
+        checked += 1
+    for mod in net.modules():
+        f = mod.__dict__.get('fused')
+        if f is not None:
+            ref = ops.transpose_w(f['w'], f['w'].shape[0], f['w'].shape[1], 1, dtype=BF16)
+            assert torch.equal(f['w16t'].reshape(-1), ref.reshape(-1))
+            checked += 1
+    assert checked > 40
