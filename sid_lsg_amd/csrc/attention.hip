@@ -371,11 +371,14 @@ template <int DP, int KT>
 __global__ __launch_bounds__(256) void attn_dkdv_kernel(AttnParams p) {
     constexpr int LD = DP + 8;
     constexpr int DT = DP / 16;
-    __shared__ __attribute__((aligned(16))) bf16 Qs[lds_tile_elems<DP, AK_QT>()];
-    __shared__ __attribute__((aligned(16))) bf16 dOs[lds_tile_elems<DP, AK_QT>()];
+    // Q / dO tiles double-buffered (2 x 2 x 7 KiB at d = 40): the next tile is written while other waves still read the
+    // current one -> ONE barrier per 64-query stage
+    constexpr int TE = lds_tile_elems<DP, AK_QT>();
+    __shared__ __attribute__((aligned(16))) bf16 Qs2[2][TE];
+    __shared__ __attribute__((aligned(16))) bf16 dOs2[2][TE];
     __shared__ float lse_s[2][AK_QT], dl_s[2][AK_QT];
-    lds_tile_init<DP, AK_QT>(Qs);
-    lds_tile_init<DP, AK_QT>(dOs);
+#pragma unroll
+    for (int i = 0; i < 2; i++) { lds_tile_init<DP, AK_QT>(Qs2[i]); lds_tile_init<DP, AK_QT>(dOs2[i]); }
     const int b = blockIdx.z, h = blockIdx.y;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lg = lane >> 4;
     const int key0 = (blockIdx.x * 4 + wave) * (KT * 16);
@@ -410,13 +413,15 @@ __global__ __launch_bounds__(256) void attn_dkdv_kernel(AttnParams p) {
         }
     };
     prefetch(0);
-    tq.store(Qs, LD); tdo.store(dOs, LD);
+    tq.store(Qs2[0], LD); tdo.store(dOs2[0], LD);
     if (threadIdx.x < AK_QT) { lse_s[0][threadIdx.x] = lse_r; dl_s[0][threadIdx.x] = dl_r; }
     __syncthreads();
     int pb_ = 0;
     auto qtile = [&](const int q0, auto has_next) {       // (run-time `more`: the compile-time split measured slower here)
         const bool more = q0 + AK_QT < p.Nq;
         if (more) prefetch(q0 + AK_QT);
+        const bf16* Qs = Qs2[pb_];
+        const bf16* dOs = dOs2[pb_];
         f32x4 pp[KT][4], ds[KT][4];
 #pragma unroll
         for (int qt = 0; qt < 4; qt++) {
@@ -452,10 +457,9 @@ __global__ __launch_bounds__(256) void attn_dkdv_kernel(AttnParams p) {
                     dk[kt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb, dsb, dk[kt][dt], 0, 0, 0);
                 }
             }
-        __syncthreads();
-        if (more) {
-            tq.store(Qs, LD); tdo.store(dOs, LD);
+        if (more) {          // the other buffer was last read in the previous stage, i.e. before the previous barrier
             pb_ ^= 1;
+            tq.store(Qs2[pb_], LD); tdo.store(dOs2[pb_], LD);
             if (threadIdx.x < AK_QT) { lse_s[pb_][threadIdx.x] = lse_r; dl_s[pb_][threadIdx.x] = dl_r; }
             __syncthreads();
         }

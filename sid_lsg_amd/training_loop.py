@@ -84,6 +84,9 @@ class PromptStream:
         return prompts, z.to(self.device), noise.to(self.device), t.to(self.device)
 
 
+SNAPSHOT_EXTRA_TICKS = (2, 4, 10, 20, 30, 40, 50, 60, 70, 80, 90, 100)
+
+
 def training_loop(
     run_dir='.', dataset_kwargs={}, data_loader_kwargs={}, network_kwargs={}, loss_kwargs={},
     fake_score_optimizer_kwargs={}, g_optimizer_kwargs={}, augment_kwargs=None, seed=0, batch_size=512, batch_gpu=None,
@@ -227,7 +230,8 @@ def training_loop(
             torch.cuda.reset_peak_memory_stats()
         if (not done) and dist.should_stop():
             done = True
-        if snapshot_ticks is not None and (done or cur_tick % snapshot_ticks == 0) and cur_tick > 0 and rank == 0 and run_dir:
+        # reference cadence (sid_training_loop.py:597): tick 0, every snapshot_ticks, a fixed early schedule, and the last tick
+        if snapshot_ticks is not None and (done or cur_tick % snapshot_ticks == 0 or cur_tick in SNAPSHOT_EXTRA_TICKS) and rank == 0 and run_dir:
             with open(os.path.join(run_dir, f'network-snapshot-{alpha:03f}-{cur_nimg // 1000:06d}.pkl'), 'wb') as f:
                 pickle.dump(dict(ema=G_ema), f)
         if state_dump_ticks is not None and (done or cur_tick % state_dump_ticks == 0) and cur_tick != 0 and rank == 0 and run_dir:

@@ -434,3 +434,21 @@ def test_bias_act_matches_reference_golden(dev, golden_dir):
     # bf16 tensors go through the same plugin
     yb = ba.bias_act(x.to(BF16), b.to(BF16), dim=1, act='swish')
     close(yb, torch.from_numpy(g['swish_gNone_cNone_y']), 1.2e-2, 'bf16 swish')
+
+
+@pytest.mark.parametrize('heads,d', [(2, 40), (2, 64)])
+def test_attention_propagates_nan(dev, heads, d):
+    """attention.hip is built with -fno-honor-nans (fmax without canonicalisation), while the step relies on a NaN sample staying
+    NaN up to the per-sample filter of the loss kernels (sid_training_loop.py:443-445, 522-530): a NaN anywhere in a sample's
+    q/k/v must surface in that sample's output and leave the other samples untouched."""
+    from sid_lsg_amd import ops
+    torch.manual_seed(0)
+    B, N, C = 3, 200, heads * d
+    qkv = torch.randn(B, N, 3 * C, device=dev).to(BF16)
+    clean = ops.self_attention(qkv, heads).float()
+    for where in (0, C, 2 * C):                      # a NaN in q, in k, in v of sample 1
+        bad = qkv.clone()
+        bad[1, 17, where + 3] = float('nan')
+        out = ops.self_attention(bad, heads).float()
+        assert torch.isnan(out[1]).any(), where
+        assert torch.equal(out[0], clean[0]) and torch.equal(out[2], clean[2])
