@@ -743,9 +743,11 @@ __device__ unsigned long long* g_trace = nullptr;
 extern "C" int sidlsg_exp_set_trace(void* ptr) { return hipMemcpyToSymbol(HIP_SYMBOL(g_trace), &ptr, sizeof(ptr)) == hipSuccess ? 0 : -1; }
 #define TRACE(i) do { if (g_trace && threadIdx.x == 0) g_trace[(size_t)blockIdx.x * 8 + (i)] = wall_clock64(); } while (0)
 #define TRACE_HWID() do { if (g_trace && threadIdx.x == 0) { unsigned h, x; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(h)); asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x)); g_trace[(size_t)blockIdx.x * 8 + 7] = ((unsigned long long)x << 32) | h; } } while (0)
+#define WTRACE(i) do { if (g_trace && threadIdx.x == 0) g_trace[(size_t)blockIdx.x * 8 + (i)] = wall_clock64(); } while (0)
 #else
 #define TRACE(i)
 #define TRACE_HWID()
+#define WTRACE(i)
 #endif
 #ifndef SIDLSG_V3_SCHED_FENCE
 #define SIDLSG_V3_SCHED_FENCE 1
@@ -1461,10 +1463,12 @@ DEVFN void wgrad_v2_body(const WgradParams& p) {
     const int nsteps = (mend - mbeg + WG_MB - 1) / WG_MB;
     if (nsteps <= 0) return;
     bf16x8 fy0[NI], fx0[4], fy1[NI], fx1[4];
+    WTRACE(0);
     issue(mbeg, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+    WTRACE(1);
     read_frags(0, 0, fy0, fx0);
     if (nsteps > 1) issue(mbeg + WG_MB, 1);
     auto stage = [&](const int st, auto has_next, auto fetch) {           // straight-line instantiations: see gemm_v3_kernel
@@ -1488,6 +1492,7 @@ DEVFN void wgrad_v2_body(const WgradParams& p) {
         if (st + 1 < nsteps) { stage(st, std::true_type{}, std::false_type{}); st++; }
         stage(st, std::false_type{}, std::false_type{});
     }
+    WTRACE(2);
     if (do_bias && li == 0) {
 #pragma unroll
         for (int i = 0; i < NI; i++)
@@ -1497,22 +1502,60 @@ DEVFN void wgrad_v2_body(const WgradParams& p) {
                 if (n < p.N) unsafeAtomicAdd(p.dB + n, accb[i][r]);
             }
     }
+    // Result write-out.  In the accumulator layout a lane holds single floats of 16-float row segments: 64-80 scalar stores
+    // per lane behind three run-time branches each -- the phase trace (tools/ab/wgrad_trace.py) showed 7.5-18 us per block in
+    // this epilogue, a third to a half of a dense weight-gradient block.  Instead the tile goes through LDS (the stage ring is
+    // free now; fp32 [TN/2][128 + 4], one half of the n rows at a time) and leaves as 16-byte stores along k: 512-byte runs
+    // (11.5 -> 9.3 us dense, 9.6 -> 5.9 us conv; code 19.8 -> 11.2 KB).  What remains is a chip-wide write burst: all blocks of
+    // a launch have equal work, reach this point together and write tiles x splits x 64 KB of slabs (31 MB for 65536x320x320)
+    // with nothing left to overlap it.
+    if (p.nsplits == 1 || p.ws) {
+        constexpr int LDW = WG_T + 4;
+        float* img = reinterpret_cast<float*>(smem);
+        float* dst = p.nsplits == 1 ? p.dW : p.ws + (size_t)split * p.N * p.K;
+        const bool accum = p.nsplits == 1;
 #pragma unroll
-    for (int i = 0; i < NI; i++)
+        for (int h = 0; h < 2; h++) {
+            __syncthreads();                             // the ring (or the previous half image) is no longer read
+            if ((wave >> 1) == h) {
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const int k = k0 + wk0 + 16 * j + li;
-            if (k >= p.K) continue;
+                for (int i = 0; i < NI; i++)
 #pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const int n = n0 + wn0 + 16 * i + lg * 4 + r;
-                if (n >= p.N) continue;
-                const size_t e = (size_t)n * p.K + k;
-                if (p.nsplits == 1) p.dW[e] += acc[i][j][r];
-                else if (p.ws) p.ws[(size_t)split * p.N * p.K + e] = acc[i][j][r];
-                else unsafeAtomicAdd(p.dW + e, acc[i][j][r]);
+                    for (int j = 0; j < 4; j++)
+#pragma unroll
+                        for (int r = 0; r < 4; r++) img[(16 * i + lg * 4 + r) * LDW + wk0 + 16 * j + li] = acc[i][j][r];
+            }
+            __syncthreads();
+            for (int c = tid; c < (TN / 2) * 32; c += NTHREADS) {
+                const int row = c >> 5, k4 = (c & 31) * 4;
+                const int n = n0 + h * (TN / 2) + row, k = k0 + k4;
+                if (n < p.N && k < p.K) {
+                    f32x4 v = *reinterpret_cast<const f32x4*>(img + row * LDW + k4);
+                    float* d = dst + (size_t)n * p.K + k;
+                    if (accum) v += *reinterpret_cast<const f32x4*>(d);
+                    *reinterpret_cast<f32x4*>(d) = v;
+                }
             }
         }
+    } else {
+#pragma unroll
+        for (int i = 0; i < NI; i++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int k = k0 + wk0 + 16 * j + li;
+                if (k >= p.K) continue;
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int n = n0 + wn0 + 16 * i + lg * 4 + r;
+                    if (n < p.N) unsafeAtomicAdd(p.dW + (size_t)n * p.K + k, acc[i][j][r]);
+                }
+            }
+    }
+    WTRACE(3);
+#ifdef SIDLSG_EXP_TRACE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    WTRACE(4);
+#endif
 }
 
 // (two plain kernels over one body: a kernel template with the second non-type parameter did not get a host stub from
