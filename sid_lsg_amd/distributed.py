@@ -47,6 +47,13 @@ def print0(*args, **kwargs):
         print(*args, **kwargs)
 
 
+def _grad_side_streams(t):
+    if not t.is_cuda:
+        return []
+    from . import ops
+    return ops.grad_streams(t.device)
+
+
 class FlatGradReducer:
     """Data-parallel gradient exchange on a network's flat fp32 gradient buffer.
 
@@ -71,6 +78,8 @@ class FlatGradReducer:
             return
         if self.stream is not None:
             self.stream.wait_stream(torch.cuda.current_stream())
+            for side in _grad_side_streams(flat_grad):      # weight gradients are produced on their own stream (ops.py)
+                self.stream.wait_stream(side)
             with torch.cuda.stream(self.stream):
                 for o in range(lo, hi, max_elems):
                     self.handles.append(torch.distributed.all_reduce(flat_grad[o:min(hi, o + max_elems)], group=self.group, async_op=True))
@@ -86,6 +95,8 @@ class FlatGradReducer:
         step = (step + 1023) // 1024 * 1024
         if self.stream is not None:
             self.stream.wait_stream(torch.cuda.current_stream())
+            for side in _grad_side_streams(flat_grad):
+                self.stream.wait_stream(side)
             with torch.cuda.stream(self.stream):
                 for o in range(0, n, step):
                     self.handles.append(torch.distributed.all_reduce(flat_grad[o:o + step], group=self.group, async_op=True))

@@ -12,6 +12,8 @@ contiguous; parameters are fp32
 weight/bias gradients are ACCUMULATED IN PLACE by the kernels (atomics / +=) and the autograd
 functions return None for them, so no per-parameter gradient tensors are ever materialised.
 """
+import os
+
 import torch
 
 from ._lib import lib
@@ -87,6 +89,71 @@ def side_stream(device):
         _side_streams[key] = torch.cuda.Stream(device=device)
         ensure_stream_workspace(_side_streams[key])
     return _side_streams[key]
+
+
+# ---- weight gradients on their own stream ---------------------------------------------------------------------------------
+# A weight-gradient launch is one round of equal-work blocks: they start together, wait for their tile DMAs together and end in
+# a chip-wide burst of slab writes followed by a small reduction kernel (tools/ab/wgrad_trace.py) -- MFMA and HBM idle in
+# turns.  dW of a layer depends only on (dY, saved x), not on the backward-data chain, so these launches go to a second stream
+# and their idle phases are filled by the dgrad GEMMs / attention / norm kernels of the main stream (and vice versa).
+# Ordering: the side stream waits for the main stream at each launch (dY exists), the tensors are record_stream()-ed, and
+# the main stream (plus, through grad_streams(), the gradient-exchange stream) waits for the side stream at the end of the
+# backward pass (autograd engine callback), i.e. before anything may read .grad.  SIDLSG_WGRAD_STREAM=0 turns it off.
+_WGRAD_SIDE = os.environ.get('SIDLSG_WGRAD_STREAM', '1') != '0'
+_wgrad_streams = {}
+_wgrad_join_armed = set()
+
+
+def wgrad_stream(device):
+    key = torch.device(device).index or 0
+    if key not in _wgrad_streams:
+        _wgrad_streams[key] = torch.cuda.Stream(device=device)
+        ensure_stream_workspace(_wgrad_streams[key])
+    return _wgrad_streams[key]
+
+
+def grad_streams(device):
+    """Side streams that may still be writing parameter gradients of `device` (a gradient exchange must wait for them)."""
+    key = torch.device(device).index or 0
+    return [_wgrad_streams[key]] if key in _wgrad_streams else []
+
+
+class _OnWgradStream:
+    """with _OnWgradStream(dy, x): <wgrad launches> -- inside a torch.autograd.Function.backward only."""
+
+    def __init__(self, *tensors):
+        self.tensors = tensors
+        self.on = _WGRAD_SIDE and tensors[0].dtype == BF16
+
+    def __enter__(self):
+        if not self.on:
+            return self
+        dev = self.tensors[0].device
+        self.side = wgrad_stream(dev)
+        self.side.wait_stream(torch.cuda.current_stream(dev))
+        self.cm = torch.cuda.stream(self.side)
+        self.cm.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if not self.on:
+            return False
+        self.cm.__exit__(*exc)
+        for t in self.tensors:
+            t.record_stream(self.side)
+        key = self.tensors[0].device.index or 0
+        if key not in _wgrad_join_armed:
+            side, dev = self.side, self.tensors[0].device
+
+            def join():
+                _wgrad_join_armed.discard(key)
+                torch.cuda.current_stream(dev).wait_stream(side)
+            try:
+                torch.autograd.Variable._execution_engine.queue_callback(join)
+                _wgrad_join_armed.add(key)
+            except RuntimeError:                 # not inside a backward pass: join right away
+                torch.cuda.current_stream(dev).wait_stream(side)
+        return False
 
 
 def ensure_stream_workspace(stream, nbytes=256 << 20):
@@ -207,8 +274,9 @@ class _Linear(torch.autograd.Function):
         fused_b = need_b and not need_rv and _wants_grad(weight) and x.dtype == BF16
         if _wants_grad(weight):
             M, K = x.shape
-            _fn('wgrad', x.dtype, '_bf16')(_p(dy), dy.stride(0), _p(x), x.stride(0), _p(weight.grad), _p(bias.grad) if fused_b else None,
-                                           M, weight.shape[0], K, _s())
+            with _OnWgradStream(dy, x):
+                _fn('wgrad', x.dtype, '_bf16')(_p(dy), dy.stride(0), _p(x), x.stride(0), _p(weight.grad), _p(bias.grad) if fused_b else None,
+                                               M, weight.shape[0], K, _s())
         drv = None
         if need_rv:
             drv = colsum(dy, ctx.rpb, per_batch=True, total=bias.grad if need_b else None)
@@ -264,8 +332,9 @@ class _Conv3x3(torch.autograd.Function):
             H, W = (2 * x.shape[1], 2 * x.shape[2]) if ups else (x.shape[1], x.shape[2])
             wgrad = _fn('conv3x3_wgrad', x.dtype, '_bf16')
             if not padded:
-                wgrad(_p(dy), Cout, _p(x), Cin, _p(weight.grad), _p(bias.grad) if fused_b else None,
-                      B, H, W, Cin, Cout, stride, ups, _s())
+                with _OnWgradStream(dy, x):
+                    wgrad(_p(dy), Cout, _p(x), Cin, _p(weight.grad), _p(bias.grad) if fused_b else None,
+                          B, H, W, Cin, Cout, stride, ups, _s())
             else:
                 tmp = torch.zeros((Cout, 9, Cin), device=dy.device, dtype=F32)
                 wgrad(_p(dy), Cout, _p(x), Cin, _p(tmp), None, B, H, W, Cin, Cout, stride, ups, _s())

@@ -259,6 +259,7 @@ def test_grad_segments_complete_when_marker_fires(dev):
     segment's gradients must already be final.  Snapshot each segment when its marker fires and compare with the
     gradient buffer after the whole backward (bit exact: nothing may accumulate into a segment afterwards)."""
     from oracle.unet_ref import CONFIGS as RC
+    from sid_lsg_amd import ops
     from sid_lsg_amd.unet import CONFIGS, HipUNet2DCondition
     for cfg_name, lat in (('tiny', 16), ('tiny40', 8)):
         cfg = RC[cfg_name]
@@ -271,6 +272,10 @@ def test_grad_segments_complete_when_marker_fires(dev):
         def cb(k):
             order.append(k)
             lo, hi = segs[k]
+            # the consumer's contract (FlatGradReducer.start_range): order after the current stream AND after the
+            # weight-gradient stream, then the segment is final
+            for side in ops.grad_streams(dev):
+                torch.cuda.current_stream().wait_stream(side)
             snaps[k] = net.flat_grads[lo:hi].clone()
         net.set_grad_ready_callback(cb)
         g = torch.Generator().manual_seed(1)
