@@ -141,18 +141,21 @@ class _OnWgradStream:
         self.cm.__exit__(*exc)
         for t in self.tensors:
             t.record_stream(self.side)
-        key = self.tensors[0].device.index or 0
+        # one join per backward pass and device, keyed by the autograd graph-task id (a pass that died with an exception
+        # must not leave the next one un-joined)
+        key = (self.tensors[0].device.index or 0, torch._C._current_graph_task_id())
         if key not in _wgrad_join_armed:
             side, dev = self.side, self.tensors[0].device
 
             def join():
                 _wgrad_join_armed.discard(key)
                 torch.cuda.current_stream(dev).wait_stream(side)
-            try:
-                torch.autograd.Variable._execution_engine.queue_callback(join)
+            if key[1] < 0:                       # not inside a backward pass: join right away
+                join()
+            else:
+                _wgrad_join_armed.clear()        # ids never repeat: anything left is from a pass that did not finish
                 _wgrad_join_armed.add(key)
-            except RuntimeError:                 # not inside a backward pass: join right away
-                torch.cuda.current_stream(dev).wait_stream(side)
+                torch.autograd.Variable._execution_engine.queue_callback(join)
         return False
 
 
