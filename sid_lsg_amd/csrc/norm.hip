@@ -18,6 +18,10 @@
 #include <stdlib.h>
 
 constexpr int GN_MAX_C = 2560;
+#ifndef SIDLSG_GN_U
+#define SIDLSG_GN_U 4
+#endif
+constexpr int GN_U = SIDLSG_GN_U;      // forward kernels: independent loads in flight per thread
 
 // thread layout shared by the GroupNorm kernels: blockDim.x = C8 * rows, thread owns channel chunk
 // cc (8 channels) and walks pixels rl, rl+rows, ...
@@ -36,12 +40,14 @@ __global__ void gn_stats_kernel(const T* __restrict__ x, float* __restrict__ par
     for (int e = 0; e < 8; e++) s[e] = q[e] = 0.f;
     const T* xb = x + (size_t)b * g.HW * g.C + cc * 8;
     int p = p0 + rl;
-    for (; p + 3 * g.rows < p1; p += 4 * g.rows) {        // 4 independent 16-byte loads in flight per thread
-        float v[4][8];
+    // GN_U independent 16-byte loads in flight per thread (8 measured slower than 4: 37 -> 44 us on 16 x 4096 x 320 -- the
+    // chunk of a block is only ~20 pixel rows per thread, the unrolled body then runs twice and leaves a serial tail)
+    for (; p + (GN_U - 1) * g.rows < p1; p += GN_U * g.rows) {
+        float v[GN_U][8];
 #pragma unroll
-        for (int u = 0; u < 4; u++) ldv8<T>(xb + (size_t)(p + u * g.rows) * g.C, v[u]);
+        for (int u = 0; u < GN_U; u++) ldv8<T>(xb + (size_t)(p + u * g.rows) * g.C, v[u]);
 #pragma unroll
-        for (int u = 0; u < 4; u++)
+        for (int u = 0; u < GN_U; u++)
 #pragma unroll
             for (int e = 0; e < 8; e++) { const float f = v[u][e]; s[e] += f; q[e] += f * f; }
     }
@@ -73,12 +79,18 @@ __global__ void gn_apply_kernel(const T* __restrict__ x, const float* __restrict
                                 T* __restrict__ y, float* __restrict__ stats, GnGeom g, float eps, int act) {
     extern __shared__ float sm[];  // mean[G], rstd[G]
     const int b = blockIdx.y, chunk = blockIdx.x;
-    for (int grp = threadIdx.x; grp < g.G; grp += blockDim.x) {
-        float a = 0.f, c = 0.f;
-        for (int k = 0; k < g.nch; k++) {
-            const float* o = part + (((size_t)b * g.nch + k) * g.G + grp) * 2;
-            a += o[0]; c += o[1];
-        }
+    // fold the nch per-chunk partials of every group: all threads load (one (sum, sumsq) pair each, independent loads), LDS
+    // float adds combine them -- a serial loop of nch dependent-latency loads in G threads cost several us per block
+    for (int i = threadIdx.x; i < 2 * g.G; i += blockDim.x) sm[i] = 0.f;
+    __syncthreads();
+    for (int i = threadIdx.x; i < g.G * g.nch; i += blockDim.x) {
+        const int grp = i % g.G, k = i / g.G;
+        const float2 o = *reinterpret_cast<const float2*>(part + (((size_t)b * g.nch + k) * g.G + grp) * 2);
+        atomicAdd(&sm[grp], o.x); atomicAdd(&sm[g.G + grp], o.y);
+    }
+    __syncthreads();
+    for (int grp = threadIdx.x; grp < g.G; grp += blockDim.x) {      // each group is read and overwritten by one thread
+        const float a = sm[grp], c = sm[g.G + grp];
         const float n = (float)g.cpg * (float)g.HW;
         const float mean = a / n;
         const float var = fmaxf(c / n - mean * mean, 0.f);
@@ -98,12 +110,12 @@ __global__ void gn_apply_kernel(const T* __restrict__ x, const float* __restrict
     const int p0 = chunk * g.ppb, p1 = min(g.HW, p0 + g.ppb);
     const size_t base = (size_t)b * g.HW * g.C + cc * 8;
     int p = p0 + rl;
-    for (; p + 3 * g.rows < p1; p += 4 * g.rows) {
-        float v[4][8];
+    for (; p + (GN_U - 1) * g.rows < p1; p += GN_U * g.rows) {
+        float v[GN_U][8];
 #pragma unroll
-        for (int u = 0; u < 4; u++) ldv8<T>(x + base + (size_t)(p + u * g.rows) * g.C, v[u]);
+        for (int u = 0; u < GN_U; u++) ldv8<T>(x + base + (size_t)(p + u * g.rows) * g.C, v[u]);
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
+        for (int u = 0; u < GN_U; u++) {
 #pragma unroll
             for (int e = 0; e < 8; e++) {
                 float f = v[u][e] * sc[e] + sh[e];
@@ -198,15 +210,18 @@ __global__ void gn_bwd_apply_kernel(const T* __restrict__ x, const T* __restrict
     // instead of in a separate elementwise kernel
     extern __shared__ float sm[];  // s1[G], s2[G]
     const int b = blockIdx.y, chunk = blockIdx.x;
-    for (int grp = threadIdx.x; grp < g.G; grp += blockDim.x) {
-        float s1 = 0.f, s2 = 0.f;
+    {   // fold the per-chunk group partials with all threads (see gn_apply_kernel)
         const float* gpart = part + (size_t)gridDim.y * g.nch * g.C * 2;
-        for (int k = 0; k < g.nch; k++) {
-            const float* o = gpart + (((size_t)b * g.nch + k) * g.G + grp) * 2;
-            s1 += o[0]; s2 += o[1];
+        for (int i = threadIdx.x; i < 2 * g.G; i += blockDim.x) sm[i] = 0.f;
+        __syncthreads();
+        for (int i = threadIdx.x; i < g.G * g.nch; i += blockDim.x) {
+            const int grp = i % g.G, k = i / g.G;
+            const float2 o = *reinterpret_cast<const float2*>(gpart + (((size_t)b * g.nch + k) * g.G + grp) * 2);
+            atomicAdd(&sm[grp], o.x); atomicAdd(&sm[g.G + grp], o.y);
         }
+        __syncthreads();
         const float n = (float)g.cpg * (float)g.HW;
-        sm[grp] = s1 / n; sm[g.G + grp] = s2 / n;
+        for (int i = threadIdx.x; i < 2 * g.G; i += blockDim.x) sm[i] = sm[i] / n;
     }
     __syncthreads();
     const int cc = threadIdx.x % g.C8, rl = threadIdx.x / g.C8;
