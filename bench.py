@@ -292,7 +292,7 @@ def main():
                                f'batch_gpu={b}, fp32 masters + bf16 MFMA compute, Adam(beta1=0)+EMA, random-init weights',
                    'global_batch': batch_size, 'parallelism': f'dp{world}', 'teacher_weights': args.teacher_weights},
         'step_tflops': value * img_tflop, 'step_mfma_frac': value * img_tflop / (PEAK_BF16_TFLOPS * world),
-        'loss_fake': float(lf), 'loss_G': float(lg),
+        'loss_fake': float(lf), 'loss_G': float(lg), 'peak_mem_gb': torch.cuda.max_memory_allocated(dev) / 2 ** 30,
     }
     if teacher is not None:
         n_fwd = (2 if args.kappa != 1 else 1) * b
