@@ -1069,7 +1069,7 @@ static int dispatch_gemm(const GemmParams& p, hipStream_t s) {
     static const int MIN_TILES = getenv("SIDLSG_GEMM_MIN_TILES") ? atoi(getenv("SIDLSG_GEMM_MIN_TILES")) : 384;
     static const int MIN_NK = getenv("SIDLSG_SPLITK_MIN_NK") ? atoi(getenv("SIDLSG_SPLITK_MIN_NK")) : 32;
     static const int MIN_KT = getenv("SIDLSG_SPLITK_MIN_KT") ? atoi(getenv("SIDLSG_SPLITK_MIN_KT")) : 8;
-    static const int V3_DIRECT_TILES = getenv("SIDLSG_V3_DIRECT_TILES") ? atoi(getenv("SIDLSG_V3_DIRECT_TILES")) : 384;
+    static const int V3_DIRECT_TILES = getenv("SIDLSG_V3_DIRECT_TILES") ? atoi(getenv("SIDLSG_V3_DIRECT_TILES")) : 256;   // 256 since the compact epilogue: 4096x1280x1280 28.1 -> 23.9 us
     {
         const long long t = tiles(128, n160 ? 160 : 128);
         const int nk = (p.K + BK - 1) / BK;
