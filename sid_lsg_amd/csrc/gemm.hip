@@ -1599,10 +1599,11 @@ static int launch_wgrad(WgradParams p, hipStream_t s) {
     int splits = 1;
     {
         const int cap = std::min(64, (p.M + 4 * WG_MB - 1) / (4 * WG_MB));
+        static const int slots = getenv("SIDLSG_WGRAD_SLOTS") ? atoi(getenv("SIDLSG_WGRAD_SLOTS")) : 512;   // A/B knob: resident blocks a launch may count on
         double best = 1e30;
         const double slab_us = (double)p.N * p.K * 4.0 / 4e6;
         for (int sp = 1; sp <= cap; sp++) {
-            const int rounds = (sp * tiles + 511) / 512;
+            const int rounds = (sp * tiles + slots - 1) / slots;
             const double rows = (double)((p.M + sp - 1) / sp);
             const double est = rounds * (rows * 0.024 + 3.0) + (sp > 1 ? sp * slab_us : 0.0);
             if (est < best) { best = est; splits = sp; }
