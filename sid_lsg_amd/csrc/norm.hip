@@ -73,6 +73,31 @@ __global__ void gn_stats_kernel(const T* __restrict__ x, float* __restrict__ par
     }
 }
 
+// sm[0..G) / sm[G..2G) = sum over the nch chunks of one sample's per-group partial pairs p[k][grp][2].  All threads load
+// (a serial loop of nch dependent-latency loads in G threads cost several us per block); the order of the additions is
+// fixed by the block size, so the result is deterministic.  sm needs 2*G*GN_FOLD floats; ends with a barrier.
+constexpr int GN_FOLD = 8;
+DEVFN void gn_fold_partials(const float* __restrict__ p, const GnGeom& g, float* sm) {
+    const int slices = min(GN_FOLD, max(1, (int)blockDim.x / g.G));
+    float* tmp = sm + 2 * g.G;                                 // [slices][G][2]
+    for (int item = threadIdx.x; item < slices * g.G; item += blockDim.x) {
+        const int grp = item % g.G, sl = item / g.G;
+        float a = 0.f, c = 0.f;
+        for (int k = sl; k < g.nch; k += slices) {
+            const float2 o = *reinterpret_cast<const float2*>(p + ((size_t)k * g.G + grp) * 2);
+            a += o.x; c += o.y;
+        }
+        tmp[(sl * g.G + grp) * 2] = a; tmp[(sl * g.G + grp) * 2 + 1] = c;
+    }
+    __syncthreads();
+    for (int q = threadIdx.x; q < g.G; q += blockDim.x) {
+        float a = 0.f, c = 0.f;
+        for (int j = 0; j < slices; j++) { a += tmp[(j * g.G + q) * 2]; c += tmp[(j * g.G + q) * 2 + 1]; }
+        sm[q] = a; sm[g.G + q] = c;
+    }
+    __syncthreads();
+}
+
 template <typename T>
 __global__ void gn_apply_kernel(const T* __restrict__ x, const float* __restrict__ part,
                                 const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -81,14 +106,7 @@ __global__ void gn_apply_kernel(const T* __restrict__ x, const float* __restrict
     const int b = blockIdx.y, chunk = blockIdx.x;
     // fold the nch per-chunk partials of every group: all threads load (one (sum, sumsq) pair each, independent loads), LDS
     // float adds combine them -- a serial loop of nch dependent-latency loads in G threads cost several us per block
-    for (int i = threadIdx.x; i < 2 * g.G; i += blockDim.x) sm[i] = 0.f;
-    __syncthreads();
-    for (int i = threadIdx.x; i < g.G * g.nch; i += blockDim.x) {
-        const int grp = i % g.G, k = i / g.G;
-        const float2 o = *reinterpret_cast<const float2*>(part + (((size_t)b * g.nch + k) * g.G + grp) * 2);
-        atomicAdd(&sm[grp], o.x); atomicAdd(&sm[g.G + grp], o.y);
-    }
-    __syncthreads();
+    gn_fold_partials(part + (size_t)b * g.nch * g.G * 2, g, sm);
     for (int grp = threadIdx.x; grp < g.G; grp += blockDim.x) {      // each group is read and overwritten by one thread
         const float a = sm[grp], c = sm[g.G + grp];
         const float n = (float)g.cpg * (float)g.HW;
@@ -212,14 +230,7 @@ __global__ void gn_bwd_apply_kernel(const T* __restrict__ x, const T* __restrict
     const int b = blockIdx.y, chunk = blockIdx.x;
     {   // fold the per-chunk group partials with all threads (see gn_apply_kernel)
         const float* gpart = part + (size_t)gridDim.y * g.nch * g.C * 2;
-        for (int i = threadIdx.x; i < 2 * g.G; i += blockDim.x) sm[i] = 0.f;
-        __syncthreads();
-        for (int i = threadIdx.x; i < g.G * g.nch; i += blockDim.x) {
-            const int grp = i % g.G, k = i / g.G;
-            const float2 o = *reinterpret_cast<const float2*>(gpart + (((size_t)b * g.nch + k) * g.G + grp) * 2);
-            atomicAdd(&sm[grp], o.x); atomicAdd(&sm[g.G + grp], o.y);
-        }
-        __syncthreads();
+        gn_fold_partials(gpart + (size_t)b * g.nch * g.G * 2, g, sm);
         const float n = (float)g.cpg * (float)g.HW;
         for (int i = threadIdx.x; i < 2 * g.G; i += blockDim.x) sm[i] = sm[i] / n;
     }
@@ -507,7 +518,7 @@ static int groupnorm_fwd_t(const void* x, const float* gamma, const float* beta,
     const int threads = g.C8 * g.rows;
     hipLaunchKernelGGL(gn_stats_kernel<T>, dim3(g.nch, B), dim3(threads), (size_t)g.rows * C * 2 * sizeof(float), s,
                        (const T*)x, ws, g);
-    hipLaunchKernelGGL(gn_apply_kernel<T>, dim3(g.nch, B), dim3(threads), (size_t)2 * G * sizeof(float), s,
+    hipLaunchKernelGGL(gn_apply_kernel<T>, dim3(g.nch, B), dim3(threads), (size_t)2 * G * (1 + GN_FOLD) * sizeof(float), s,
                        (const T*)x, ws, gamma, beta, (T*)y, stats, g, eps, silu);
     return sidlsg_last_error();
 }
@@ -522,7 +533,7 @@ static int groupnorm_bwd_t(const void* x, const void* dy, const float* stats, co
     const int threads = g.C8 * g.rows;
     hipLaunchKernelGGL(gn_bwd_stats_kernel<T>, dim3(g.nch, B), dim3(threads), (size_t)g.rows * C * 2 * sizeof(float), s,
                        (const T*)x, (const T*)dy, stats, gamma, beta, ws, g, silu);
-    hipLaunchKernelGGL(gn_bwd_apply_kernel<T>, dim3(g.nch, B), dim3(threads), (size_t)2 * G * sizeof(float), s,
+    hipLaunchKernelGGL(gn_bwd_apply_kernel<T>, dim3(g.nch, B), dim3(threads), (size_t)2 * G * (1 + GN_FOLD) * sizeof(float), s,
                        (const T*)x, (const T*)dy, stats, gamma, beta, ws, (const T*)dres, (T*)dx, g, silu);
     if (dgamma && dbeta) {
         const int P = B * g.nch;
