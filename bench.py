@@ -234,13 +234,16 @@ def main():
     for tm in (timer, timer_gn, timer_attn):
         if tm is not None:
             tm.__exit__()
-    # The timed region runs the teacher on a second HIP stream beside the fake-score network (sid_step.py): kernels of the two
+    # The timed region runs the teacher on a second HIP stream beside the fake-score network (sid_step.py) and the weight
+    # gradients on a third (ops._OnWgradStream): kernels of the
     # streams share the chip, so a launch's event-bracketed duration over the timed region (= what rocprofv3 --kernel-trace
     # reports for the same command) is longer than the kernel's own.  A few extra iterations AFTER the timed region, with that
     # overlap switched off, give each dominant kernel's stand-alone figure (`isolated` in the roofline objects).
     iso = {}
     if timer is not None and step.side is not None:
+        from sid_lsg_amd import ops as _ops
         side, step.side = step.side, None
+        wgrad_side, _ops._WGRAD_SIDE = _ops._WGRAD_SIDE, False      # weight gradients back on the main stream as well
         tms = dict(conv=KernelTimer(lib, 'sidlsg_conv3x3_bf16', conv_flops), gn=KernelTimer(lib, 'sidlsg_groupnorm_fwd', gn_bytes, stride=5),
                    attn=KernelTimer(lib, 'sidlsg_attn_fwd', attn_flops, stride=3))
         for tm in tms.values():
@@ -252,6 +255,7 @@ def main():
             tm.__exit__()
             iso[k] = tm.result()
         step.side = side
+        _ops._WGRAD_SIDE = wgrad_side
     # north_star's second figure: MFMA utilisation of the CFG teacher pass alone (phi forward on the [uncond; cond] batch of
     # 2b samples + guidance + x0), timed with events on a few extra passes after the timed region (rank 0)
     teacher = None
@@ -315,7 +319,7 @@ def main():
                            'achieved': ach, 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / PEAK_BF16_TFLOPS,
                            'isolated': (lambda q: {'achieved': q['flops'] / (q['ms'] * 1e-3) / 1e12, 'frac': q['flops'] / (q['ms'] * 1e-3) / 1e12 / PEAK_BF16_TFLOPS,
                                                    'avg_launch_ms': q['ms'] / max(q['launches'], 1), 'launches': q['launches'],
-                                                   'what': '3 iterations after the timed region with the teacher stream overlap off'})(iso['conv']) if 'conv' in iso else None,
+                                                   'what': '3 iterations after the timed region with the teacher-stream and weight-gradient-stream overlap off'})(iso['conv']) if 'conv' in iso else None,
                            'traffic': traffic, 'traffic_source': traffic_src, 'launches': r['launches'], 'launches_total': r['calls'], 'avg_launch_ms': r['ms'] / max(r['launches'], 1),
                            'algorithmic_tflop_per_launch': r['flops'] / max(r['launches'], 1) / 1e12}
     if timer_gn is not None:
