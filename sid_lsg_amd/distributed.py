@@ -66,10 +66,29 @@ class FlatGradReducer:
     the next phase's noise / text conditioning (which does not read the parameters), then wait().
     """
 
-    def __init__(self, nbuckets=4, group=None):
+    def __init__(self, nbuckets=4, group=None, exchange_dtype=None):
+        """exchange_dtype: None / torch.float32 = all-reduce the fp32 gradients in place (the reference's DDP semantics);
+        torch.bfloat16 (or SIDLSG_GRAD_EXCHANGE=bf16) = OPT-IN halved xGMI traffic: each message is rounded to bf16 into a
+        staging buffer, all-reduced in bf16 and written back to the fp32 gradient buffer.  This changes the numbers (8
+        mantissa bits per rank contribution, bf16 accumulation inside the collective) and is therefore off by default."""
         self.nbuckets, self.group = nbuckets, group
         self.stream = torch.cuda.Stream() if torch.cuda.is_available() else None
         self.handles = []
+        if exchange_dtype is None and os.environ.get('SIDLSG_GRAD_EXCHANGE', 'fp32').lower() in ('bf16', 'bfloat16'):
+            exchange_dtype = torch.bfloat16
+        if exchange_dtype not in (None, torch.float32, torch.bfloat16):
+            raise ValueError('exchange_dtype must be None, torch.float32 or torch.bfloat16')
+        self.exchange_dtype = exchange_dtype if exchange_dtype is not None else torch.float32
+        self._pending = []          # (fp32 view, bf16 staging tensor) pairs to write back in wait()
+
+    def _all_reduce(self, view):
+        """One message (called with the communication stream current, if there is one)."""
+        if self.exchange_dtype == torch.bfloat16:
+            stage = view.to(torch.bfloat16)
+            self.handles.append(torch.distributed.all_reduce(stage, group=self.group, async_op=True))
+            self._pending.append((view, stage))
+        else:
+            self.handles.append(torch.distributed.all_reduce(view, group=self.group, async_op=True))
 
     def start_range(self, flat_grad, lo, hi, max_elems=1 << 28):
         """all-reduce flat_grad[lo:hi] (in messages of <= max_elems elements = 1 GiB fp32) on the communication stream,
@@ -82,10 +101,10 @@ class FlatGradReducer:
                 self.stream.wait_stream(side)
             with torch.cuda.stream(self.stream):
                 for o in range(lo, hi, max_elems):
-                    self.handles.append(torch.distributed.all_reduce(flat_grad[o:min(hi, o + max_elems)], group=self.group, async_op=True))
+                    self._all_reduce(flat_grad[o:min(hi, o + max_elems)])
         else:
             for o in range(lo, hi, max_elems):
-                self.handles.append(torch.distributed.all_reduce(flat_grad[o:min(hi, o + max_elems)], group=self.group, async_op=True))
+                self._all_reduce(flat_grad[o:min(hi, o + max_elems)])
 
     def start(self, flat_grad):
         if get_world_size() == 1:
@@ -99,14 +118,23 @@ class FlatGradReducer:
                 self.stream.wait_stream(side)
             with torch.cuda.stream(self.stream):
                 for o in range(0, n, step):
-                    self.handles.append(torch.distributed.all_reduce(flat_grad[o:o + step], group=self.group, async_op=True))
+                    self._all_reduce(flat_grad[o:o + step])
         else:
             for o in range(0, n, step):
-                self.handles.append(torch.distributed.all_reduce(flat_grad[o:o + step], group=self.group, async_op=True))
+                self._all_reduce(flat_grad[o:o + step])
 
     def wait(self):
         for h in self.handles:
             h.wait()
         self.handles = []
+        if self._pending:                               # bf16 exchange: reduced values back into the fp32 gradients
+            ctx = torch.cuda.stream(self.stream) if self.stream is not None else None
+            if ctx is not None:
+                ctx.__enter__()
+            for view, stage in self._pending:
+                view.copy_(stage)
+            if ctx is not None:
+                ctx.__exit__(None, None, None)
+            self._pending = []
         if self.stream is not None:
             torch.cuda.current_stream().wait_stream(self.stream)

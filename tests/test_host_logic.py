@@ -223,6 +223,14 @@ h = ops.grad_ready_marker(h * 3.0, lambda: cb(0))
 assert fired == [0, 1] and torch.equal(x.grad, torch.full((4,), 30.0))
 red.start_range(g2, 0, 4000); red.wait()
 assert torch.equal(g2, expect)
+# opt-in bf16 exchange: each rank's contribution is rounded to bf16, the sum comes back into the fp32 buffer
+g3 = (torch.arange(10007, dtype=torch.float32) * 0.37 + 1.0) * (rank + 1)
+red16 = dist.FlatGradReducer(nbuckets=3, exchange_dtype=torch.bfloat16)
+red16.start(g3); red16.wait()
+want = (torch.arange(10007, dtype=torch.float32) * 0.37 + 1.0) * 3
+assert g3.dtype == torch.float32 and float(((g3 - want).abs() / want).max()) < 2.0 ** -7, float(((g3 - want).abs() / want).max())
+assert not torch.equal(g3, want)          # it IS a lossy exchange: off by default
+assert dist.FlatGradReducer().exchange_dtype == torch.float32
 dist.print0("REDUCER_OK", world)
 ''')
     env = dict(os.environ, MASTER_ADDR='127.0.0.1')
