@@ -155,9 +155,13 @@ constexpr int AT_KT = 64;   // keys per LDS tile
 // ONES (forward, D == DP - 8 only): V's first pad column holds 1.0, so O^T row D accumulates the softmax
 // denominator inside the P.V MFMAs (and is rescaled with O); the 16 VALU adds per query tile disappear.
 // K/V tiles are double buffered in LDS: one barrier per key tile.
-// (the d = 40 forward is VALU-bound and lives on 4 resident waves per SIMD: cap its registers at 128)
+// (the d = 40 forward is VALU-bound and lives on 4 resident waves per SIMD: cap its registers at 128; the d = 40 dQ kernel
+// declared for 2 blocks per SIMD, i.e. up to 256 registers, ran the backward 3 % faster than uncapped (190) or capped at 168)
+#ifndef SIDLSG_DQ_OCC
+#define SIDLSG_DQ_OCC 2
+#endif
 template <int DP, int QT, int MODE, bool ONES>
-__global__ __launch_bounds__(256, (DP <= 48 && MODE == 0) ? 4 : 1) void attn_q_kernel(AttnParams p) {
+__global__ __launch_bounds__(256, (DP <= 48 && MODE == 0) ? 4 : ((DP <= 48 && MODE == 1) ? SIDLSG_DQ_OCC : 1)) void attn_q_kernel(AttnParams p) {
     static_assert(!ONES || (MODE == 0 && DP % 16 == 0), "ones column: forward only");
     constexpr int LD = DP + 8;
     constexpr int DT = DP / 16;
