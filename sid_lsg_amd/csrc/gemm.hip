@@ -667,14 +667,21 @@ __global__ __launch_bounds__(256) void quantize_fp8_rows_kernel(const bf16* __re
 }
 
 // epilogue of a split-K GEMM: C = act(alpha * sum_s slab_s + bias + rowvec + res)
-__global__ void gemm_finish_kernel(GemmParams p) {
-    if (blockIdx.y != 0) return;
+__global__ void gemm_finish_kernel(GemmParams p, int nsp) {      // nsp: number of K splits (slabs)
     const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
     if (i >= (size_t)p.M * p.N) return;
     const int m = (int)(i / p.N), n = (int)(i - (size_t)m * p.N);      // N % 4 == 0 on this path
+    const size_t slab = (size_t)p.M * p.N;
     f32x4 v = *reinterpret_cast<const f32x4*>(p.ws + i);
-    const int nsp = (int)gridDim.y;                       // number of K splits (slabs)
-    for (int sidx = 1; sidx < nsp; sidx++) v += *reinterpret_cast<const f32x4*>(p.ws + (size_t)sidx * p.M * p.N + i);
+    int sidx = 1;
+    for (; sidx + 3 < nsp; sidx += 4) {                   // four independent loads in flight, fixed summation order
+        const f32x4 a = *reinterpret_cast<const f32x4*>(p.ws + (size_t)sidx * slab + i);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(p.ws + (size_t)(sidx + 1) * slab + i);
+        const f32x4 c = *reinterpret_cast<const f32x4*>(p.ws + (size_t)(sidx + 2) * slab + i);
+        const f32x4 d = *reinterpret_cast<const f32x4*>(p.ws + (size_t)(sidx + 3) * slab + i);
+        v += a; v += b; v += c; v += d;
+    }
+    for (; sidx < nsp; sidx++) v += *reinterpret_cast<const f32x4*>(p.ws + sidx * slab + i);
     const float* rv = p.rowvec ? p.rowvec + (size_t)(m / p.rows_per_batch) * p.ldrv : nullptr;
 #pragma unroll
     for (int e = 0; e < 4; e++) {
@@ -1028,7 +1035,7 @@ static int launch_gemm_v3(const GemmParams& p, hipStream_t s) {
     hipLaunchKernelGGL((gemm_v3_kernel<MODE>), dim3(tiles * splits), dim3(NTHREADS), lds, s, q);
     if (p.kt_per_split) {
         const size_t n4 = ((size_t)p.M * p.N + 3) / 4;
-        hipLaunchKernelGGL(gemm_finish_kernel, dim3((unsigned)((n4 + 255) / 256), splits), dim3(256), 0, s, p);
+        hipLaunchKernelGGL(gemm_finish_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, p, splits);
     }
     return sidlsg_last_error();
 }
@@ -1048,7 +1055,7 @@ static int launch_gemm(const GemmParams& p, hipStream_t s) {
     hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, MODE>), dim3(tiles, splits), dim3(NTHREADS), lds, s, p);
     if (p.kt_per_split) {
         const size_t n4 = ((size_t)p.M * p.N + 3) / 4;
-        hipLaunchKernelGGL(gemm_finish_kernel, dim3((unsigned)((n4 + 255) / 256), splits), dim3(256), 0, s, p);   // grid.y only carries the split count
+        hipLaunchKernelGGL(gemm_finish_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, p, splits);
     }
     return sidlsg_last_error();
 }
