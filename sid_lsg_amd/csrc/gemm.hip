@@ -1577,7 +1577,15 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restr
     const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
     if (i + 4 <= n) {
         f32x4 v = *reinterpret_cast<const f32x4*>(dW + i);
-        for (int sidx = 0; sidx < splits; sidx++) v += *reinterpret_cast<const f32x4*>(ws + (size_t)sidx * n + i);
+        int sidx = 0;
+        for (; sidx + 3 < splits; sidx += 4) {          // four independent slab loads in flight, fixed summation order
+            const f32x4 a = *reinterpret_cast<const f32x4*>(ws + (size_t)sidx * n + i);
+            const f32x4 b = *reinterpret_cast<const f32x4*>(ws + (size_t)(sidx + 1) * n + i);
+            const f32x4 c = *reinterpret_cast<const f32x4*>(ws + (size_t)(sidx + 2) * n + i);
+            const f32x4 d = *reinterpret_cast<const f32x4*>(ws + (size_t)(sidx + 3) * n + i);
+            v += a; v += b; v += c; v += d;
+        }
+        for (; sidx < splits; sidx++) v += *reinterpret_cast<const f32x4*>(ws + (size_t)sidx * n + i);
         *reinterpret_cast<f32x4*>(dW + i) = v;
     } else {
         for (size_t j = i; j < n; j++) {
@@ -1598,7 +1606,8 @@ static int launch_wgrad(WgradParams p, hipStream_t s) {
     const bool v2 = v2_on && aligned;
     // 160-wide n tiles: measured faster only where they cut the tile count by a third (conv, Cout = 320: 216 -> 178 us);
     // for N = 640 (5 -> 4 tiles) and the dense shapes the leaner 128 kernel wins
-    const int tn = (v2 && tn160_on && MODE == 1 && p.N == 320) ? 160 : WG_T;
+    static const bool tn160_dense = getenv("SIDLSG_WGRAD_TN160_DENSE") && atoi(getenv("SIDLSG_WGRAD_TN160_DENSE"));   // A/B switch
+    const int tn = (v2 && tn160_on && (MODE == 1 || tn160_dense) && p.N == 320) ? 160 : WG_T;
     const int tiles = ((p.N + tn - 1) / tn) * ((p.K + WG_T - 1) / WG_T);
     // Split the pixel contraction so the grid fills the chip in whole rounds of 512 resident blocks (256 CUs x 2).
     // Small cost model (us): rounds * (rows per block * 24 ns + 3 us block overhead) + slab reduction at ~4 TB/s;
