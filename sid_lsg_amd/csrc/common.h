@@ -35,6 +35,27 @@ DEVFN float gelu_grad_f(float x) {
     return cdf + x * pdf;
 }
 
+// bf16 activations: exact GELU through erff costs ~34 VALU instructions per element and made the GEGLU kernels VALU-bound
+// (3.3 TB/s); Abramowitz-Stegun 7.1.26 (|error| < 5.4e-7 on erf, < 3.7e-7 on gelu -- four orders below a bf16 ulp) needs 14,
+// and the exponential it uses is the Gaussian the derivative needs anyway.  The fp32-accurate mode keeps erff.
+DEVFN void gelu_fast(float x, float& gelu, float& dgelu) {
+    const float ax = fabsf(x) * 0.70710678118654752f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
+    float p = fmaf(1.061405429f, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    const float e = __builtin_amdgcn_exp2f(-0.72134752044448170f * x * x);   // exp(-x^2 / 2)
+    const float erfv = copysignf(fmaf(-p * t, e, 1.0f), x);                   // erf(x / sqrt 2)
+    const float cdf = fmaf(0.5f, erfv, 0.5f);
+    gelu = x * cdf;
+    dgelu = fmaf(x * 0.3989422804014327f, e, cdf);
+}
+template <typename T> DEVFN float gelu_t(float x) { return gelu_f(x); }
+template <> DEVFN float gelu_t<bf16>(float x) { float g, d; gelu_fast(x, g, d); return g; }
+template <typename T> DEVFN void gelu_pair_t(float x, float& g, float& d) { g = gelu_f(x); d = gelu_grad_f(x); }
+template <> DEVFN void gelu_pair_t<bf16>(float x, float& g, float& d) { gelu_fast(x, g, d); }
+
 DEVFN float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

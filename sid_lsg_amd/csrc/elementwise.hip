@@ -140,7 +140,7 @@ __global__ void geglu_fwd_kernel(const T* __restrict__ h, T* __restrict__ y, siz
     float a[8], g[8];
     ldv8<T>(h + m * 2 * F + c, a); ldv8<T>(h + m * 2 * F + F + c, g);
 #pragma unroll
-    for (int e = 0; e < 8; e++) a[e] *= gelu_f(g[e]);
+    for (int e = 0; e < 8; e++) a[e] *= gelu_t<T>(g[e]);
     stv8<T>(y + m * F + c, a);
 }
 template <typename T>
@@ -153,8 +153,10 @@ __global__ void geglu_bwd_kernel(const T* __restrict__ h, const T* __restrict__ 
     ldv8<T>(h + m * 2 * F + c, a); ldv8<T>(h + m * 2 * F + F + c, g); ldv8<T>(dy + m * F + c, d);
 #pragma unroll
     for (int e = 0; e < 8; e++) {
-        da[e] = d[e] * gelu_f(g[e]);
-        dg[e] = d[e] * a[e] * gelu_grad_f(g[e]);
+        float gl, gd;
+        gelu_pair_t<T>(g[e], gl, gd);
+        da[e] = d[e] * gl;
+        dg[e] = d[e] * a[e] * gd;
     }
     stv8<T>(dh + m * 2 * F + c, da);
     stv8<T>(dh + m * 2 * F + F + c, dg);

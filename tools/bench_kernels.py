@@ -2,7 +2,7 @@
 """Per-shape kernel micro-benchmarks on the SD1.5 work list -- the optimisation harness.
 Prints achieved TFLOP/s (contractions) or GB/s (HBM-bound kernels) per shape.  GPU only.
 
-    python tools/bench_kernels.py [conv] [gemm] [wgrad] [attn] [norm] [fp8] [--batch 16]
+    python tools/bench_kernels.py [conv] [gemm] [wgrad] [attn] [norm] [geglu] [fp8] [--batch 16]
 """
 import os
 import sys
@@ -156,6 +156,16 @@ def bench_norm(B):
                                                      gb.data_ptr(), ws.data_ptr(), rows, C, ops._s()))
         by = 1.0 * rows * C * 2
         print(f'  LN {rows}x{C}: fwd {tf * 1e6:7.1f} us {2 * by / tf / 1e9:6.0f} GB/s | bwd {tb * 1e6:7.1f} us {3 * by / tb / 1e9:6.0f} GB/s')
+
+
+def bench_geglu(B):
+    print('--- GEGLU fwd / bwd: us and GB/s (fwd: h 2F in, y F out; bwd: h, dy in, dh out)')
+    for M, F in ((B * 4096, 1280), (B * 1024, 2560), (B * 256, 5120)):
+        h, dy = r(M, 2 * F), r(M, F)
+        y, dh = torch.empty(M, F, device=dev, dtype=BF16), torch.empty(M, 2 * F, device=dev, dtype=BF16)
+        tf = timeit(lambda: lib.sidlsg_geglu_fwd(h.data_ptr(), y.data_ptr(), M, F, ops._s()))
+        tb = timeit(lambda: lib.sidlsg_geglu_bwd(h.data_ptr(), dy.data_ptr(), dh.data_ptr(), M, F, ops._s()))
+        print(f'  {M}x{F}: fwd {tf * 1e6:7.1f} us {3.0 * M * F * 2 / tf / 1e9:6.0f} GB/s | bwd {tb * 1e6:7.1f} us {5.0 * M * F * 2 / tb / 1e9:6.0f} GB/s')
 
 
 if __name__ == '__main__':
