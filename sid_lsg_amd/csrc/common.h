@@ -51,6 +51,13 @@ DEVFN void gelu_fast(float x, float& gelu, float& dgelu) {
     gelu = x * cdf;
     dgelu = fmaf(x * 0.3989422804014327f, e, cdf);
 }
+// SiLU on bf16 activations: v_rcp_f32 (1 ulp) instead of the IEEE division sequence -- 15 -> 6 VALU instructions per element
+// forward, 18 -> 8 for the derivative; GroupNorm+SiLU applies it to every element it streams.  fp32 mode keeps the division.
+DEVFN float sigmoid_fast(float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x)); }
+template <typename T> DEVFN float silu_t(float x) { return silu_f(x); }
+template <> DEVFN float silu_t<bf16>(float x) { return x * sigmoid_fast(x); }
+template <typename T> DEVFN float silu_grad_t(float x) { return silu_grad_f(x); }
+template <> DEVFN float silu_grad_t<bf16>(float x) { const float s = sigmoid_fast(x); return s * fmaf(x, 1.0f - s, 1.0f); }
 template <typename T> DEVFN float gelu_t(float x) { return gelu_f(x); }
 template <> DEVFN float gelu_t<bf16>(float x) { float g, d; gelu_fast(x, g, d); return g; }
 template <typename T> DEVFN void gelu_pair_t(float x, float& g, float& d) { g = gelu_f(x); d = gelu_grad_f(x); }

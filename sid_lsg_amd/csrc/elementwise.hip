@@ -116,7 +116,7 @@ __global__ void silu_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, size
     float v[8];
     ldv8<T>(x + i * 8, v);
 #pragma unroll
-    for (int e = 0; e < 8; e++) v[e] = silu_f(v[e]);
+    for (int e = 0; e < 8; e++) v[e] = silu_t<T>(v[e]);
     stv8<T>(y + i * 8, v);
 }
 template <typename T>
@@ -126,7 +126,7 @@ __global__ void silu_bwd_kernel(const T* __restrict__ x, const T* __restrict__ d
     float v[8], d[8];
     ldv8<T>(x + i * 8, v); ldv8<T>(dy + i * 8, d);
 #pragma unroll
-    for (int e = 0; e < 8; e++) d[e] *= silu_grad_f(v[e]);
+    for (int e = 0; e < 8; e++) d[e] *= silu_grad_t<T>(v[e]);
     stv8<T>(dx + i * 8, d);
 }
 

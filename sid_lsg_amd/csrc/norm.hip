@@ -137,7 +137,7 @@ __global__ void gn_apply_kernel(const T* __restrict__ x, const float* __restrict
 #pragma unroll
             for (int e = 0; e < 8; e++) {
                 float f = v[u][e] * sc[e] + sh[e];
-                if (act) f = silu_f(f);
+                if (act) f = silu_t<T>(f);
                 v[u][e] = f;
             }
             stv8<T>(y + base + (size_t)(p + u * g.rows) * g.C, v[u]);
@@ -149,7 +149,7 @@ __global__ void gn_apply_kernel(const T* __restrict__ x, const float* __restrict
 #pragma unroll
         for (int e = 0; e < 8; e++) {
             float f = v[e] * sc[e] + sh[e];
-            if (act) f = silu_f(f);
+            if (act) f = silu_t<T>(f);
             v[e] = f;
         }
         stv8<T>(y + base + (size_t)p * g.C, v);
@@ -183,7 +183,7 @@ __global__ void gn_bwd_stats_kernel(const T* __restrict__ x, const T* __restrict
             for (int e = 0; e < 8; e++) {
                 const float xh = (xv[u][e] - mu[e]) * rs[e];
                 float d = dv[u][e];
-                if (act) d *= silu_grad_f(xh * ga[e] + be[e]);
+                if (act) d *= silu_grad_t<T>(xh * ga[e] + be[e]);
                 a[e] += d * xh; c[e] += d;
             }
     }
@@ -194,7 +194,7 @@ __global__ void gn_bwd_stats_kernel(const T* __restrict__ x, const T* __restrict
         for (int e = 0; e < 8; e++) {
             const float xh = (xv[e] - mu[e]) * rs[e];
             float d = dv[e];
-            if (act) d *= silu_grad_f(xh * ga[e] + be[e]);
+            if (act) d *= silu_grad_t<T>(xh * ga[e] + be[e]);
             a[e] += d * xh; c[e] += d;
         }
     }
@@ -258,7 +258,7 @@ __global__ void gn_bwd_apply_kernel(const T* __restrict__ x, const T* __restrict
             for (int e = 0; e < 8; e++) {
                 const float xh = (xv[u][e] - mu[e]) * rs[e];
                 float d = dv[u][e];
-                if (act) d *= silu_grad_f(xh * ga[e] + be[e]);
+                if (act) d *= silu_grad_t<T>(xh * ga[e] + be[e]);
                 o[e] = rs[e] * (d * ga[e] - m1[e] - xh * m2[e]) + av[e];
             }
             stv8<T>(dx + base + (size_t)(p + u * g.rows) * g.C, o);
@@ -272,7 +272,7 @@ __global__ void gn_bwd_apply_kernel(const T* __restrict__ x, const T* __restrict
         for (int e = 0; e < 8; e++) {
             const float xh = (xv[e] - mu[e]) * rs[e];
             float d = dv[e];
-            if (act) d *= silu_grad_f(xh * ga[e] + be[e]);
+            if (act) d *= silu_grad_t<T>(xh * ga[e] + be[e]);
             o[e] = rs[e] * (d * ga[e] - m1[e] - xh * m2[e]) + av[e];
         }
         stv8<T>(dx + base + (size_t)p * g.C, o);
