@@ -127,14 +127,9 @@ class FlatGradReducer:
         for h in self.handles:
             h.wait()
         self.handles = []
-        if self._pending:                               # bf16 exchange: reduced values back into the fp32 gradients
-            ctx = torch.cuda.stream(self.stream) if self.stream is not None else None
-            if ctx is not None:
-                ctx.__enter__()
-            for view, stage in self._pending:
-                view.copy_(stage)
-            if ctx is not None:
-                ctx.__exit__(None, None, None)
+        if self._pending:                               # bf16 exchange: reduced values back into the fp32 gradients,
+            for view, stage in self._pending:           # on the CURRENT stream -- the one h.wait() has just ordered after
+                view.copy_(stage)                       # the collectives
             self._pending = []
         if self.stream is not None:
             torch.cuda.current_stream().wait_stream(self.stream)
