@@ -130,6 +130,8 @@ class FlatGradReducer:
         if self._pending:                               # bf16 exchange: reduced values back into the fp32 gradients,
             for view, stage in self._pending:           # on the CURRENT stream -- the one h.wait() has just ordered after
                 view.copy_(stage)                       # the collectives
+                if stage.is_cuda:
+                    stage.record_stream(torch.cuda.current_stream())     # allocated on the communication stream
             self._pending = []
         if self.stream is not None:
             torch.cuda.current_stream().wait_stream(self.stream)
