@@ -325,8 +325,12 @@ def main():
     if timer_gn is not None:
         r = timer_gn.result()
         ach = r['flops'] / (r['ms'] * 1e-3) / 1e9 if r['ms'] > 0 else 0.0
+        gn_traffic, gn_src = None, None
+        gpmc = os.path.join(ROOT, 'profiles', 'r02_gn_pmc.json')
+        if os.path.isfile(gpmc):      # same convention as the conv entry: PMC passes over the kernel micro-benchmark's GroupNorm shapes
+            gn_traffic, gn_src = json.load(open(gpmc)).get('avg_hbm_side_bytes_fwd_per_launch'), 'profiles/r02_gn_pmc.json (micro-benchmark of the SD1.5 GroupNorm shapes, batch 16; stats + apply kernels of one call)'
         out['roofline_gn'] = {'bound': 'hbm', 'kernel': 'GroupNorm(32)+SiLU forward (gn_stats_kernel + gn_apply_kernel, one entry point)',
-                              'achieved': ach, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': ach / PEAK_HBM_GBS, 'traffic': None,
+                              'achieved': ach, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': ach / PEAK_HBM_GBS, 'traffic': gn_traffic, 'traffic_source': gn_src,
                               'isolated': (lambda q: {'achieved': q['flops'] / (q['ms'] * 1e-3) / 1e9, 'frac': q['flops'] / (q['ms'] * 1e-3) / 1e9 / PEAK_HBM_GBS,
                                                       'avg_launch_ms': q['ms'] / max(q['launches'], 1)})(iso['gn']) if 'gn' in iso else None,
                               'launches': r['launches'], 'launches_total': r['calls'], 'avg_launch_ms': r['ms'] / max(r['launches'], 1),
