@@ -92,6 +92,16 @@ int sidlsg_attn_fwd(const void* Q, const void* K, const void* V, void* O, float*
 int sidlsg_attn_bwd(const void* Q, const void* K, const void* V, const void* O, const void* dO, const float* LSE, void* dQ,
                     void* dK, void* dV, float* delta, int B, int H, int Nq, int Nk, int D, int ldq, int ldk, int ldv, int ldo,
                     long long bsq, long long bsk, long long bsv, long long bso, void* stream);
+/* The same with PRE-SCALED queries: Q holds q * (D^-1/2 * log2 e) -- the caller folds the factor into the q rows of the
+ * projection weight's compute copy (sidlsg_scale_cast_ranges: one rounding, like the unscaled copy).  The QK^T accumulators
+ * are then seeded with -max / -LSE and feed v_exp_f32 directly.  The backward returns gradients with respect to the SCALED
+ * queries (dQ = ln2 dS K, dK = ln2 dS^T Q); the caller's weight-gradient call rescales the q rows (sidlsg_wgrad_bf16_rs). */
+int sidlsg_attn_fwd_ps(const void* Q, const void* K, const void* V, void* O, float* LSE, int B, int H, int Nq, int Nk, int D,
+                       int ldq, int ldk, int ldv, int ldo, long long bsq, long long bsk, long long bsv, long long bso,
+                       void* stream);
+int sidlsg_attn_bwd_ps(const void* Q, const void* K, const void* V, const void* O, const void* dO, const float* LSE, void* dQ,
+                       void* dK, void* dV, float* delta, int B, int H, int Nq, int Nk, int D, int ldq, int ldk, int ldv, int ldo,
+                       long long bsq, long long bsk, long long bsv, long long bso, void* stream);
 
 /* ---- scheduler / guidance glue (sid_sd_util.py:182-185, 242, 259-272) ----------------------
  * noisy_input: x_t = s0[b]*x0 + s1[b]*noise (x0 NULL -> zeros: the one-step generator input),

@@ -46,6 +46,12 @@ constexpr unsigned A_OOB = 0x80000000u;
 DEVFN __amdgpu_buffer_rsrc_t mk_rsrc(const bf16* p) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(p), 0, 0x7FFFFFFF, 0x00020000);
 }
+// descriptor over rows 0..nrows-1 of a [rows][ld] view whose rows are D elements wide: a 16-byte chunk of a row >= nrows
+// starts past num_records and reads zeros
+DEVFN __amdgpu_buffer_rsrc_t mk_rsrc_rows(const bf16* p, int nrows, int ld, int D) {
+    const long long bytes = nrows > 0 ? ((long long)(nrows - 1) * ld + D) * 2 : 0;
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(p), 0, (int)bytes, 0x00020000);
+}
 DEVFN bf16x8 bld8(__amdgpu_buffer_rsrc_t r, unsigned off) {
     return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
 }
@@ -82,18 +88,22 @@ DEVFN f32x4 mma_d(f32x4 acc, const Frag<DP>& a, const Frag<DP>& b) {
     for (int s = 0; s < Frag<DP>::N32; s++) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.w[s], b.w[s], acc, 0, 0, 0);
     return acc;
 }
-// LDS tile of ROWS x (DP + 8) bf16 plus slack for the over-read of the last row; pad columns and slack zeroed here
-// (disjoint from what TileRegs::store writes, so the caller's first barrier covers it).
+// LDS tile of ROWS rows with a row stride of LD = the smallest odd multiple of 16 elements >= DP (32 B x odd): with that
+// stride both the ds_read_b128 fragment reads (16-lane groups of the b128 access) and the ds_read_b64_tr_b16 transpose reads
+// (32-lane halves) touch every bank slot exactly once -- brute-forced over the access patterns of this file; the former
+// DP + 8 stride was 2-way conflicted on both (SQ_LDS_BANK_CONFLICT = 45 % of SQ_LDS_IDX_ACTIVE, profiles/r02_attn_pmc.json).
+// Columns DP..LD (when LD > DP) are never read.  The over-read of the K=32 slices (DP = 16, 48, 80: LD == DP) runs into
+// the NEXT row's first 16 columns (finite data, multiplied by the global operand's exact zeros) and, for the last row, into
+// 16 elements of slack that are zeroed once per block here.
+template <int DP>
+constexpr int tile_ld() { return ((DP + 15) / 16) % 2 ? (DP + 15) / 16 * 16 : (DP + 15) / 16 * 16 + 16; }
 template <int DP, int ROWS>
 DEVFN void lds_tile_init(bf16* tile) {
-    constexpr int LD = DP + 8;
-    for (int r = threadIdx.x; r < ROWS + 2; r += 256) {
-        bf16* p = r < ROWS ? tile + r * LD + DP : tile + ROWS * LD + (r - ROWS) * 8;
-        st8(p, zero8());
-    }
+    constexpr int LD = tile_ld<DP>();
+    if (threadIdx.x < 2) st8(tile + ROWS * LD + threadIdx.x * 8, zero8());
 }
 template <int DP, int ROWS>
-constexpr int lds_tile_elems() { return ROWS * (DP + 8) + 16; }
+constexpr int lds_tile_elems() { return ROWS * tile_ld<DP>() + 16; }
 
 // A operand = X^T for a row-major LDS tile X[row][LD]: rows r0 + {4g..4g+3} and r0 + 16 + {4g..4g+3},
 // columns c0..c0+15 -> lane i gets column c0+i, the 8 rows in the order that matches pack_p().
@@ -112,21 +122,30 @@ DEVFN bf16x8 pack_p(f32x4 a, f32x4 b) {
     return o;
 }
 
-// register-staged tile: ROWS x DP (zero padded past D / past nrows), 256 threads
+// register-staged tile: ROWS x DP (zero padded past D / past nrows), 256 threads.  Addressing: one 32-bit byte offset per
+// 16-byte chunk, computed ONCE per block (init); the tile position is the wave-uniform soffset of the buffer load, and rows
+// past the sequence end are cut off by the descriptor's num_records (mk_rsrc_rows) -- no per-tile address arithmetic or
+// bounds tests in the VALU-bound loop (they were ~35 VALU instructions per key tile).
 template <int DP, int ROWS>
 struct TileRegs {
     static constexpr int C8 = DP / 8;
     static constexpr int TCH = ROWS * C8;
     static constexpr int PER = (TCH + 255) / 256;
     bf16x8 v[PER];
-    DEVFN void load(__amdgpu_buffer_rsrc_t rs, long long ld, int row0, int nrows, int D) {
+    unsigned voff[PER];
+    DEVFN void init(int ld, int D) {
 #pragma unroll
         for (int j = 0; j < PER; j++) {
             const int idx = threadIdx.x + 256 * j;
             const int r = idx / C8, c = (idx - r * C8) * 8;
-            const bool ok = idx < TCH && (row0 + r) < nrows && c < D;
-            v[j] = bld8(rs, ok ? (unsigned)(((long long)(row0 + r) * ld + c) * 2) : A_OOB);
+            voff[j] = (idx < TCH && c < D) ? (unsigned)((r * ld + c) * 2) : A_OOB;
         }
+    }
+    // row0 * ld * 2 must fit 31 bits (checked by the launcher)
+    DEVFN void load(__amdgpu_buffer_rsrc_t rs, int ld, int row0) {
+        const unsigned soff = (unsigned)row0 * (unsigned)ld * 2u;
+#pragma unroll
+        for (int j = 0; j < PER; j++) v[j] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, voff[j], soff, 0));
     }
     // ones_col >= 0: element [r][ones_col] is written as 1.0 (a zero-pad column of the tile): the MFMA that contracts
     // the tile against the probabilities then yields their row sum in that output row for free.
@@ -160,11 +179,18 @@ constexpr int AT_KT = 64;   // keys per LDS tile
 #ifndef SIDLSG_DQ_OCC
 #define SIDLSG_DQ_OCC 2
 #endif
-template <int DP, int QT, int MODE, bool ONES>
+// PS ("pre-scaled"): Q arrives already multiplied by D^-0.5 * log2(e) (the caller folds the factor into the q rows of the
+// projection weight, see sidlsg_attn_fwd_ps), so the QK^T MFMA yields the scores in log2 units and its C operand is seeded
+// with -m (forward: the running maximum; dQ pass: -LSE): the accumulators come out as s - m and go straight into
+// v_exp_f32 -- the 32 v_fma (scale, subtract) per 64-key x 32-query wave tile disappear from the VALU-bound loop.  The dQ
+// pass seeds the dP = V dO^T MFMA with -delta the same way.  The first key tile of the forward is peeled (`first`): its
+// accumulators start from 0 and the running maximum is SET from it (it may be negative).
+template <int DP, int QT, int MODE, bool ONES, bool PS>
 __global__ __launch_bounds__(256, (DP <= 48 && MODE == 0) ? 4 : ((DP <= 48 && MODE == 1) ? SIDLSG_DQ_OCC : 1)) void attn_q_kernel(AttnParams p) {
     static_assert(!ONES || (MODE == 0 && DP % 16 == 0), "ones column: forward only");
-    constexpr int LD = DP + 8;
+    constexpr int LD = tile_ld<DP>();
     constexpr int DT = DP / 16;
+    constexpr int N32 = Frag<DP>::N32;
     constexpr int TE = lds_tile_elems<DP, AT_KT>();
     __shared__ __attribute__((aligned(16))) bf16 Ks[2][TE];
     __shared__ __attribute__((aligned(16))) bf16 Vs[2][TE];
@@ -172,8 +198,8 @@ __global__ __launch_bounds__(256, (DP <= 48 && MODE == 0) ? 4 : ((DP <= 48 && MO
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lg = lane >> 4;
     const int q0 = (blockIdx.x * 4 + wave) * (QT * 16);
     const bf16* Qb = p.Q + b * p.bsq + (long long)h * p.D;
-    const __amdgpu_buffer_rsrc_t rk = mk_rsrc(p.K + b * p.bsk + (long long)h * p.D);
-    const __amdgpu_buffer_rsrc_t rv = mk_rsrc(p.V + b * p.bsv + (long long)h * p.D);
+    const __amdgpu_buffer_rsrc_t rk = mk_rsrc_rows(p.K + b * p.bsk + (long long)h * p.D, p.Nk, p.ldk, p.D);
+    const __amdgpu_buffer_rsrc_t rv = mk_rsrc_rows(p.V + b * p.bsv + (long long)h * p.D, p.Nk, p.ldv, p.D);
     const int ones_col = ONES ? p.D : -1;
 #pragma unroll
     for (int i = 0; i < 2; i++) { lds_tile_init<DP, AT_KT>(Ks[i]); lds_tile_init<DP, AT_KT>(Vs[i]); }
@@ -197,7 +223,7 @@ __global__ __launch_bounds__(256, (DP <= 48 && MODE == 0) ? 4 : ((DP <= 48 && MO
             frag_from_global<DP>(fo, Ob + (long long)(ok ? q : 0) * p.ldo, lg, p.D, ok);
             float dsum = 0.f;
 #pragma unroll
-            for (int s2 = 0; s2 < Frag<DP>::N32; s2++)
+            for (int s2 = 0; s2 < N32; s2++)
 #pragma unroll
                 for (int e = 0; e < 8; e++) dsum += bf2f(fdo[qt].w[s2][e]) * bf2f(fo.w[s2][e]);
             dsum += __shfl_xor(dsum, 16, 64);
@@ -212,24 +238,33 @@ __global__ __launch_bounds__(256, (DP <= 48 && MODE == 0) ? 4 : ((DP <= 48 && MO
 #pragma unroll
         for (int qt = 0; qt < QT; qt++) o[i][qt] = (f32x4){0, 0, 0, 0};
     float m[QT], l[QT];
+    f32x4 seed_s[QT], seed_dp[QT];      // PS: C operands of the first QK^T / dP MFMA of a chain
 #pragma unroll
-    for (int qt = 0; qt < QT; qt++) { m[qt] = -INFINITY; l[qt] = 0.f; }
+    for (int qt = 0; qt < QT; qt++) {
+        m[qt] = -INFINITY; l[qt] = 0.f;
+        const float a = MODE == 1 ? -lse[qt] : 0.f, c = -dl[qt];
+        seed_s[qt] = (f32x4){a, a, a, a};
+        seed_dp[qt] = (f32x4){c, c, c, c};
+    }
 
     TileRegs<DP, AT_KT> tk, tv;
-    tk.load(rk, p.ldk, 0, p.Nk, p.D);
-    tv.load(rv, p.ldv, 0, p.Nk, p.D);
+    tk.init(p.ldk, p.D);
+    tv.init(p.ldv, p.D);
+    tk.load(rk, p.ldk, 0);
+    tv.load(rv, p.ldv, 0);
     tk.store(Ks[0], LD);
     tv.store(Vs[0], LD, ones_col);
     __syncthreads();
     int buf = 0;
-    // The tile body is instantiated twice: full tiles (no masking code at all; the compiler otherwise if-converts
+    // The tile body is instantiated several times: full tiles (no masking code at all; the compiler otherwise if-converts
     // the ragged-tile test into ~90 predicated VALU ops per tile in a VALU-bound loop) and the ragged last tile.
     // Forward: `has_next` is a compile-time flag like `ragged` -- a run-time `if (more)` around the prefetch / commit makes
     // the waitcnt pass merge two paths (same finding as in gemm_v3_kernel; A/B on one MI355X: forward +1.4 % at d=40, +3 %
     // at d=64/80).  The dQ pass measured 1-8 % SLOWER that way (register allocation), so it keeps the run-time test.
-    auto tile = [&](const int k0, auto ragged, auto has_next) {
+    auto tile = [&](const int k0, auto ragged, auto has_next, auto first) {
         const bool more = MODE == 0 ? decltype(has_next)::value : (k0 + AT_KT < p.Nk);
-        if (more) { tk.load(rk, p.ldk, k0 + AT_KT, p.Nk, p.D); tv.load(rv, p.ldv, k0 + AT_KT, p.Nk, p.D); }
+        constexpr bool FIRST = decltype(first)::value;
+        if (more) { tk.load(rk, p.ldk, k0 + AT_KT); tv.load(rv, p.ldv, k0 + AT_KT); }
         const bf16* Kt = Ks[buf];
         const bf16* Vt = Vs[buf];
         f32x4 s[4][QT];
@@ -237,11 +272,18 @@ __global__ __launch_bounds__(256, (DP <= 48 && MODE == 0) ? 4 : ((DP <= 48 && MO
         for (int kt = 0; kt < 4; kt++) {
             Frag<DP> fk;
             frag_from_lds<DP>(fk, Kt + (kt * 16 + li) * LD, lg);
+            // slice-major order: the two MFMAs of one accumulator's chain are QT instructions apart (back to back they
+            // serialise on the 16x16x32 result latency)
 #pragma unroll
-            for (int qt = 0; qt < QT; qt++) s[kt][qt] = mma_d<DP>((f32x4){0, 0, 0, 0}, fk, fq[qt]);
+            for (int sl = 0; sl < N32; sl++)
+#pragma unroll
+                for (int qt = 0; qt < QT; qt++) {
+                    const f32x4 c0 = (PS && !(MODE == 0 && FIRST)) ? seed_s[qt] : (f32x4){0, 0, 0, 0};
+                    s[kt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fk.w[sl], fq[qt].w[sl], sl == 0 ? c0 : s[kt][qt], 0, 0, 0);
+                }
         }
         // scores -> probabilities (keys of this lane: k0 + kt*16 + lg*4 + r).  The softmax is the VALU-bound part
-        // at d=40: raw v_exp_f32, scale folded into one FMA, masking only on the ragged last tile, and the
+        // at d=40: raw v_exp_f32, scale folded into one FMA (or into Q: PS), masking only on the ragged last tile, and the
         // running-max rescale of O deferred until the max grows by > 2^8 (LSE stays exact: m + log2(l)).
         if constexpr (decltype(ragged)::value) {
 #pragma unroll
@@ -264,51 +306,90 @@ __global__ __launch_bounds__(256, (DP <= 48 && MODE == 0) ? 4 : ((DP <= 48 && MO
                 mx = fmax3(mx, s[2][qt][3], s[3][qt][0]);
                 mx = fmax3(mx, s[3][qt][1], s[3][qt][2]);
                 mx = fmax2(mx, s[3][qt][3]);
-                mx *= p.scale2;                                    // scale2 > 0: max commutes with the scaling
-                // wave-uniform test on the lanes' LOCAL maxima (this lane group's 16 keys): the common path needs no
-                // cross-lane reduction (2 ds_bpermute round trips per query tile); only when the running max must move is
-                // the row maximum reduced over the 4 lane groups and everything held at the old max rescaled
-                if (__any(mx > m[qt] + 8.0f)) {
-                    mx = fmax2(mx, __shfl_xor(mx, 16, 64));
-                    mx = fmax2(mx, __shfl_xor(mx, 32, 64));
-                    const float mn = fmax2(m[qt], mx);
-                    const float alpha = __builtin_amdgcn_exp2f(m[qt] - mn);   // m = -inf on the first tile -> 0
-                    l[qt] *= alpha;
-                    m[qt] = mn;
+                if constexpr (PS) {
+                    // the accumulators hold s - m (first tile: s); mx is this lane group's maximum of them
+                    if (FIRST || __any(mx > 8.0f)) {
+                        mx = fmax2(mx, __shfl_xor(mx, 16, 64));
+                        mx = fmax2(mx, __shfl_xor(mx, 32, 64));
+                        // first tile: m := row maximum (any sign).  later: m grows by delta = max(0, row maximum of s - m)
+                        const float delta = FIRST ? mx : fmax2(mx, 0.f);
+                        if (!FIRST) {
+                            const float alpha = __builtin_amdgcn_exp2f(-delta);
+                            l[qt] *= alpha;
 #pragma unroll
-                    for (int i = 0; i < DT; i++) o[i][qt] *= alpha;
-                }
-                const float nm = -m[qt];
-                float sum = 0.f;
+                            for (int i = 0; i < DT; i++) o[i][qt] *= alpha;
+                        }
+                        m[qt] = FIRST ? delta : m[qt] + delta;
+                        const float nm = -m[qt];
+                        seed_s[qt] = (f32x4){nm, nm, nm, nm};
 #pragma unroll
-                for (int kt = 0; kt < 4; kt++)
+                        for (int kt = 0; kt < 4; kt++)
 #pragma unroll
-                    for (int r = 0; r < 4; r++) {
-                        const float e = __builtin_amdgcn_exp2f(fmaf(s[kt][qt][r], p.scale2, nm));
-                        s[kt][qt][r] = e;
-                        if (!ONES) sum += e;
+                            for (int r = 0; r < 4; r++) s[kt][qt][r] -= delta;
                     }
-                if (!ONES) l[qt] += sum;
+                    float sum = 0.f;
+#pragma unroll
+                    for (int kt = 0; kt < 4; kt++)
+#pragma unroll
+                        for (int r = 0; r < 4; r++) {
+                            const float e = __builtin_amdgcn_exp2f(s[kt][qt][r]);
+                            s[kt][qt][r] = e;
+                            if (!ONES) sum += e;
+                        }
+                    if (!ONES) l[qt] += sum;
+                } else {
+                    mx *= p.scale2;                                    // scale2 > 0: max commutes with the scaling
+                    // wave-uniform test on the lanes' LOCAL maxima (this lane group's 16 keys): the common path needs no
+                    // cross-lane reduction (2 ds_bpermute round trips per query tile); only when the running max must move is
+                    // the row maximum reduced over the 4 lane groups and everything held at the old max rescaled
+                    if (__any(mx > m[qt] + 8.0f)) {
+                        mx = fmax2(mx, __shfl_xor(mx, 16, 64));
+                        mx = fmax2(mx, __shfl_xor(mx, 32, 64));
+                        const float mn = fmax2(m[qt], mx);
+                        const float alpha = __builtin_amdgcn_exp2f(m[qt] - mn);   // m = -inf on the first tile -> 0
+                        l[qt] *= alpha;
+                        m[qt] = mn;
+#pragma unroll
+                        for (int i = 0; i < DT; i++) o[i][qt] *= alpha;
+                    }
+                    const float nm = -m[qt];
+                    float sum = 0.f;
+#pragma unroll
+                    for (int kt = 0; kt < 4; kt++)
+#pragma unroll
+                        for (int r = 0; r < 4; r++) {
+                            const float e = __builtin_amdgcn_exp2f(fmaf(s[kt][qt][r], p.scale2, nm));
+                            s[kt][qt][r] = e;
+                            if (!ONES) sum += e;
+                        }
+                    if (!ONES) l[qt] += sum;
+                }
             } else {
                 const float nl = -lse[qt];
 #pragma unroll
                 for (int kt = 0; kt < 4; kt++)
 #pragma unroll
-                    for (int r = 0; r < 4; r++) s[kt][qt][r] = __builtin_amdgcn_exp2f(fmaf(s[kt][qt][r], p.scale2, nl));
+                    for (int r = 0; r < 4; r++)
+                        s[kt][qt][r] = __builtin_amdgcn_exp2f(PS ? s[kt][qt][r] : fmaf(s[kt][qt][r], p.scale2, nl));
             }
         }
         if (MODE == 1) {
-            // dP^T = V dO^T ; dS^T = P^T * (dP^T - delta)   (overwrites s; the d^-1/2 factor is applied in the epilogue)
+            // dP^T = V dO^T ; dS^T = P^T * (dP^T - delta)   (overwrites s; the constant factor is applied in the epilogue)
 #pragma unroll
             for (int kt = 0; kt < 4; kt++) {
                 Frag<DP> fv;
                 frag_from_lds<DP>(fv, Vt + (kt * 16 + li) * LD, lg);
+                f32x4 dp[QT];
 #pragma unroll
-                for (int qt = 0; qt < QT; qt++) {
-                    const f32x4 dp = mma_d<DP>((f32x4){0, 0, 0, 0}, fv, fdo[qt]);
+                for (int sl = 0; sl < N32; sl++)
 #pragma unroll
-                    for (int r = 0; r < 4; r++) s[kt][qt][r] *= (dp[r] - dl[qt]);
-                }
+                    for (int qt = 0; qt < QT; qt++)
+                        dp[qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fv.w[sl], fdo[qt].w[sl],
+                                                                        sl == 0 ? (PS ? seed_dp[qt] : (f32x4){0, 0, 0, 0}) : dp[qt], 0, 0, 0);
+#pragma unroll
+                for (int qt = 0; qt < QT; qt++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) s[kt][qt][r] *= PS ? dp[qt][r] : (dp[qt][r] - dl[qt]);
             }
         }
         // second contraction over keys: forward uses V, dQ uses K
@@ -332,18 +413,28 @@ __global__ __launch_bounds__(256, (DP <= 48 && MODE == 0) ? 4 : ((DP <= 48 && MO
             buf ^= 1;
         }
     };
+    using T_ = std::true_type;
+    using F_ = std::false_type;
     int k0 = 0;
-    for (; k0 + 2 * AT_KT <= p.Nk; k0 += AT_KT) tile(k0, std::false_type{}, std::true_type{});       // full tile, a full tile follows
-    if (k0 + AT_KT <= p.Nk) {                                                                       // last full tile
-        if (k0 + AT_KT < p.Nk) tile(k0, std::false_type{}, std::true_type{}); else tile(k0, std::false_type{}, std::false_type{});
+    if constexpr (PS && MODE == 0) {     // peeled first tile (sets the running maximum)
+        if (p.Nk >= 2 * AT_KT) tile(0, F_{}, T_{}, T_{});
+        else if (p.Nk > AT_KT) tile(0, F_{}, T_{}, T_{});
+        else if (p.Nk == AT_KT) tile(0, F_{}, F_{}, T_{});
+        else tile(0, T_{}, F_{}, T_{});
+        k0 = AT_KT;
+    }
+    for (; k0 + 2 * AT_KT <= p.Nk; k0 += AT_KT) tile(k0, F_{}, T_{}, F_{});       // full tile, a full tile follows
+    if (k0 + AT_KT <= p.Nk) {                                                   // last full tile
+        if (k0 + AT_KT < p.Nk) tile(k0, F_{}, T_{}, F_{}); else tile(k0, F_{}, F_{}, F_{});
         k0 += AT_KT;
     }
-    if (k0 < p.Nk) tile(k0, std::true_type{}, std::false_type{});                                    // ragged tail
+    if (k0 < p.Nk) tile(k0, T_{}, F_{}, F_{});                                   // ragged tail
     // epilogue: lane holds, for query li of tile qt, d = dt*16 + lg*4 + r
 #pragma unroll
     for (int qt = 0; qt < QT; qt++) {
         const int q = q0 + qt * 16 + li;
-        float inv = MODE == 1 ? p.scale : 1.f;     // dQ = d^-1/2 * sum_k dS' K
+        // dQ = d^-1/2 * sum_k dS K; with pre-scaled Q the gradient wrt the SCALED q is ln2 * sum_k dS K
+        float inv = MODE == 1 ? (PS ? 0.6931471805599453f : p.scale) : 1.f;
         if (MODE == 0) {
             float lt;
             if (ONES) {
@@ -371,23 +462,25 @@ __global__ __launch_bounds__(256, (DP <= 48 && MODE == 0) ? 4 : ((DP <= 48 && MO
 
 // dK, dV: block = 4 waves * KT * 16 keys (wave owns KT key tiles), loop over 64-query tiles.
 constexpr int AK_QT = 64;
-template <int DP, int KT>
+// PS: Q pre-scaled (see attn_q_kernel): lse_s / dl_s hold -LSE / -delta and seed the S and dP accumulators, so the
+// probability is exp2(acc) and dS = P * acc' with no further arithmetic.
+template <int DP, int KT, bool PS>
 __global__ __launch_bounds__(256) void attn_dkdv_kernel(AttnParams p) {
-    constexpr int LD = DP + 8;
+    constexpr int LD = tile_ld<DP>();
     constexpr int DT = DP / 16;
     // Q / dO tiles double-buffered (2 x 2 x 7 KiB at d = 40): the next tile is written while other waves still read the
     // current one -> ONE barrier per 64-query stage
     constexpr int TE = lds_tile_elems<DP, AK_QT>();
     __shared__ __attribute__((aligned(16))) bf16 Qs2[2][TE];
     __shared__ __attribute__((aligned(16))) bf16 dOs2[2][TE];
-    __shared__ float lse_s[2][AK_QT], dl_s[2][AK_QT];
+    __shared__ __attribute__((aligned(16))) float lse_s[2][AK_QT], dl_s[2][AK_QT];
 #pragma unroll
     for (int i = 0; i < 2; i++) { lds_tile_init<DP, AK_QT>(Qs2[i]); lds_tile_init<DP, AK_QT>(dOs2[i]); }
     const int b = blockIdx.z, h = blockIdx.y;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lg = lane >> 4;
     const int key0 = (blockIdx.x * 4 + wave) * (KT * 16);
-    const __amdgpu_buffer_rsrc_t rq = mk_rsrc(p.Q + b * p.bsq + (long long)h * p.D);
-    const __amdgpu_buffer_rsrc_t rdo = mk_rsrc(p.dO + b * p.bso + (long long)h * p.D);
+    const __amdgpu_buffer_rsrc_t rq = mk_rsrc_rows(p.Q + b * p.bsq + (long long)h * p.D, p.Nq, p.ldq, p.D);
+    const __amdgpu_buffer_rsrc_t rdo = mk_rsrc_rows(p.dO + b * p.bso + (long long)h * p.D, p.Nq, p.ldo, p.D);
     const float* LSEb = p.LSE + ((long long)b * p.H + h) * p.Nq;
     const float* DLb = p.delta + ((long long)b * p.H + h) * p.Nq;
     Frag<DP> fk[KT], fv[KT];  // B operands: (k = d, col = key)
@@ -406,14 +499,17 @@ __global__ __launch_bounds__(256) void attn_dkdv_kernel(AttnParams p) {
         for (int i = 0; i < DT; i++) { dk[kt][i] = (f32x4){0, 0, 0, 0}; dv[kt][i] = (f32x4){0, 0, 0, 0}; }
 
     TileRegs<DP, AK_QT> tq, tdo;
+    tq.init(p.ldq, p.D);
+    tdo.init(p.ldo, p.D);
     float lse_r = 0.f, dl_r = 0.f;
     auto prefetch = [&](int q0) {
-        tq.load(rq, p.ldq, q0, p.Nq, p.D);
-        tdo.load(rdo, p.ldo, q0, p.Nq, p.D);
+        tq.load(rq, p.ldq, q0);
+        tdo.load(rdo, p.ldo, q0);
         if (threadIdx.x < AK_QT) {
             const int q = q0 + threadIdx.x;
             lse_r = q < p.Nq ? LSEb[q] : INFINITY;   // padded query rows contribute p = exp2(-inf) = 0
             dl_r = q < p.Nq ? DLb[q] : 0.f;
+            if (PS) { lse_r = -lse_r; dl_r = -dl_r; }
         }
     };
     prefetch(0);
@@ -434,6 +530,18 @@ __global__ __launch_bounds__(256) void attn_dkdv_kernel(AttnParams p) {
             frag_from_lds<DP>(fdo, dOs + (qt * 16 + li) * LD, lg);
 #pragma unroll
             for (int kt = 0; kt < KT; kt++) {
+                if constexpr (PS) {
+                    const f32x4 nl = *reinterpret_cast<const f32x4*>(&lse_s[pb_][qt * 16 + lg * 4]);
+                    const f32x4 nd = *reinterpret_cast<const f32x4*>(&dl_s[pb_][qt * 16 + lg * 4]);
+                    const f32x4 s = mma_d<DP>(nl, fq, fk[kt]);       // S[q][key] - LSE[q]: lane col=key li, rows q = lg*4+r
+                    const f32x4 dp = mma_d<DP>(nd, fdo, fv[kt]);     // dP - delta
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const float pr = __builtin_amdgcn_exp2f(s[r]);     // padded queries: -LSE = -inf -> 0
+                        pp[kt][qt][r] = pr;
+                        ds[kt][qt][r] = pr * dp[r];
+                    }
+                } else {
                 const f32x4 s = mma_d<DP>((f32x4){0, 0, 0, 0}, fq, fk[kt]);    // S[q][key]: lane col=key li, rows q = lg*4+r
                 const f32x4 dp = mma_d<DP>((f32x4){0, 0, 0, 0}, fdo, fv[kt]);
 #pragma unroll
@@ -444,6 +552,7 @@ __global__ __launch_bounds__(256) void attn_dkdv_kernel(AttnParams p) {
                     const float pr = __builtin_amdgcn_exp2f(fmaf(s[r], p.scale2, -lse_s[pb_][ql]));
                     pp[kt][qt][r] = pr;
                     ds[kt][qt][r] = pr * (dp[r] - dl_s[pb_][ql]);
+                }
                 }
             }
         }
@@ -482,8 +591,8 @@ __global__ __launch_bounds__(256) void attn_dkdv_kernel(AttnParams p) {
         for (int dt = 0; dt < DT; dt++) {
             const int d = dt * 16 + lg * 4;
             if (d + 4 <= p.D) {
-                bf16x4 a = {f2bf(dk[kt][dt][0] * p.scale), f2bf(dk[kt][dt][1] * p.scale), f2bf(dk[kt][dt][2] * p.scale),
-                            f2bf(dk[kt][dt][3] * p.scale)};
+                const float kf = PS ? 0.6931471805599453f : p.scale;     // PS: dK = ln2 * dS^T Q' (Q' = the pre-scaled queries)
+                bf16x4 a = {f2bf(dk[kt][dt][0] * kf), f2bf(dk[kt][dt][1] * kf), f2bf(dk[kt][dt][2] * kf), f2bf(dk[kt][dt][3] * kf)};
                 bf16x4 c = {f2bf(dv[kt][dt][0]), f2bf(dv[kt][dt][1]), f2bf(dv[kt][dt][2]), f2bf(dv[kt][dt][3])};
                 *reinterpret_cast<bf16x4*>(dKp + d) = a;
                 *reinterpret_cast<bf16x4*>(dVp + d) = c;
@@ -492,16 +601,17 @@ __global__ __launch_bounds__(256) void attn_dkdv_kernel(AttnParams p) {
     }
 }
 
-template <int DP, int QT, int KT>
+template <int DP, int QT, int KT, bool PS>
 static int launch_attn(const AttnParams& p, int mode, hipStream_t s) {
     const int qb = 4 * QT * 16, kb = 4 * KT * 16;
     if (mode == 0) {
-        if (p.D == DP - 8) hipLaunchKernelGGL((attn_q_kernel<DP, QT, 0, true>), dim3((p.Nq + qb - 1) / qb, p.H, p.B), dim3(256), 0, s, p);
-        else hipLaunchKernelGGL((attn_q_kernel<DP, QT, 0, false>), dim3((p.Nq + qb - 1) / qb, p.H, p.B), dim3(256), 0, s, p);
-    } else if (mode == 1) hipLaunchKernelGGL((attn_q_kernel<DP, QT, 1, false>), dim3((p.Nq + qb - 1) / qb, p.H, p.B), dim3(256), 0, s, p);
-    else hipLaunchKernelGGL((attn_dkdv_kernel<DP, KT>), dim3((p.Nk + kb - 1) / kb, p.H, p.B), dim3(256), 0, s, p);
+        if (p.D == DP - 8) hipLaunchKernelGGL((attn_q_kernel<DP, QT, 0, true, PS>), dim3((p.Nq + qb - 1) / qb, p.H, p.B), dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((attn_q_kernel<DP, QT, 0, false, PS>), dim3((p.Nq + qb - 1) / qb, p.H, p.B), dim3(256), 0, s, p);
+    } else if (mode == 1) hipLaunchKernelGGL((attn_q_kernel<DP, QT, 1, false, PS>), dim3((p.Nq + qb - 1) / qb, p.H, p.B), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((attn_dkdv_kernel<DP, KT, PS>), dim3((p.Nk + kb - 1) / kb, p.H, p.B), dim3(256), 0, s, p);
     return sidlsg_last_error();
 }
+template <bool PS>
 static int dispatch_attn(const AttnParams& p, int mode, hipStream_t s) {
     if (p.D % 8 || p.D <= 0 || p.D > 160) return SIDLSG_EINVAL;
     const int dp = (p.D + 15) / 16 * 16;
@@ -512,16 +622,47 @@ static int dispatch_attn(const AttnParams& p, int mode, hipStream_t s) {
     static const bool allow_kt2 = !(getenv("SIDLSG_ATTN_KT2") && atoi(getenv("SIDLSG_ATTN_KT2")) == 0);
     const bool kt2 = allow_kt2 && mode == 2 && p.Nk >= 1024;
     switch (dp) {
-        case 16: return launch_attn<16, 2, 1>(p, mode, s);
-        case 32: return launch_attn<32, 2, 1>(p, mode, s);
-        case 48: return kt2 ? launch_attn<48, 2, 2>(p, mode, s) : launch_attn<48, 2, 1>(p, mode, s);
-        case 64: return launch_attn<64, 2, 1>(p, mode, s);
-        case 80: return launch_attn<80, 2, 1>(p, mode, s);
-        case 96: return launch_attn<96, 2, 1>(p, mode, s);
-        case 128: return launch_attn<128, 2, 1>(p, mode, s);
-        case 160: return launch_attn<160, 2, 1>(p, mode, s);
+        case 16: return launch_attn<16, 2, 1, PS>(p, mode, s);
+        case 32: return launch_attn<32, 2, 1, PS>(p, mode, s);
+        case 48: return kt2 ? launch_attn<48, 2, 2, PS>(p, mode, s) : launch_attn<48, 2, 1, PS>(p, mode, s);
+        case 64: return launch_attn<64, 2, 1, PS>(p, mode, s);
+        case 80: return launch_attn<80, 2, 1, PS>(p, mode, s);
+        case 96: return launch_attn<96, 2, 1, PS>(p, mode, s);
+        case 128: return launch_attn<128, 2, 1, PS>(p, mode, s);
+        case 160: return launch_attn<160, 2, 1, PS>(p, mode, s);
     }
     return SIDLSG_EINVAL;
+}
+
+// buffer offsets are 32-bit: one batch element's rows must span < 2 GiB
+static bool attn_spans_ok(int Nq, int Nk, int ldq, int ldk, int ldv, int ldo) {
+    const long long lim = 0x7FFFFFFFLL / 2;
+    return (long long)Nq * ldq < lim && (long long)Nk * ldk < lim && (long long)Nk * ldv < lim && (long long)Nq * ldo < lim;
+}
+static int attn_fwd_impl(bool ps, const void* Q, const void* K, const void* V, void* O, float* LSE, int B, int H, int Nq, int Nk, int D,
+                         int ldq, int ldk, int ldv, int ldo, long long bsq, long long bsk, long long bsv, long long bso, void* stream) {
+    if (((ldq | ldk | ldv | ldo) & 3) || !attn_spans_ok(Nq, Nk, ldq, ldk, ldv, ldo)) return SIDLSG_EINVAL;
+    AttnParams p{};
+    p.Q = (const bf16*)Q; p.K = (const bf16*)K; p.V = (const bf16*)V; p.O = (bf16*)O; p.LSE = LSE;
+    p.B = B; p.H = H; p.Nq = Nq; p.Nk = Nk; p.D = D; p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo;
+    p.bsq = bsq; p.bsk = bsk; p.bsv = bsv; p.bso = bso;
+    p.scale = 1.0f / sqrtf((float)D); p.scale2 = p.scale * 1.4426950408889634f;
+    return ps ? dispatch_attn<true>(p, 0, (hipStream_t)stream) : dispatch_attn<false>(p, 0, (hipStream_t)stream);
+}
+static int attn_bwd_impl(bool ps, const void* Q, const void* K, const void* V, const void* O, const void* dO, const float* LSE, void* dQ,
+                         void* dK, void* dV, float* delta, int B, int H, int Nq, int Nk, int D, int ldq, int ldk, int ldv, int ldo,
+                         long long bsq, long long bsk, long long bsv, long long bso, void* stream) {
+    if (((ldq | ldk | ldv | ldo) & 3) || !attn_spans_ok(Nq, Nk, ldq, ldk, ldv, ldo)) return SIDLSG_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    AttnParams p{};
+    p.Q = (const bf16*)Q; p.K = (const bf16*)K; p.V = (const bf16*)V; p.dO = (const bf16*)dO;
+    p.dQ = (bf16*)dQ; p.dK = (bf16*)dK; p.dV = (bf16*)dV; p.LSE = const_cast<float*>(LSE); p.delta = delta;
+    p.B = B; p.H = H; p.Nq = Nq; p.Nk = Nk; p.D = D; p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo;
+    p.bsq = bsq; p.bsk = bsk; p.bsv = bsv; p.bso = bso;
+    p.scale = 1.0f / sqrtf((float)D); p.scale2 = p.scale * 1.4426950408889634f;
+    p.O = const_cast<bf16*>((const bf16*)O); p.delta_out = delta;
+    if (int e = ps ? dispatch_attn<true>(p, 1, s) : dispatch_attn<false>(p, 1, s)) return e;
+    return ps ? dispatch_attn<true>(p, 2, s) : dispatch_attn<false>(p, 2, s);
 }
 
 extern "C" {
@@ -531,30 +672,28 @@ extern "C" {
 int sidlsg_attn_fwd(const void* Q, const void* K, const void* V, void* O, float* LSE, int B, int H, int Nq, int Nk, int D,
                     int ldq, int ldk, int ldv, int ldo, long long bsq, long long bsk, long long bsv, long long bso,
                     void* stream) {
-    if ((ldq | ldk | ldv | ldo) & 3) return SIDLSG_EINVAL;
-    AttnParams p{};
-    p.Q = (const bf16*)Q; p.K = (const bf16*)K; p.V = (const bf16*)V; p.O = (bf16*)O; p.LSE = LSE;
-    p.B = B; p.H = H; p.Nq = Nq; p.Nk = Nk; p.D = D; p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo;
-    p.bsq = bsq; p.bsk = bsk; p.bsv = bsv; p.bso = bso;
-    p.scale = 1.0f / sqrtf((float)D); p.scale2 = p.scale * 1.4426950408889634f;
-    return dispatch_attn(p, 0, (hipStream_t)stream);
+    return attn_fwd_impl(false, Q, K, V, O, LSE, B, H, Nq, Nk, D, ldq, ldk, ldv, ldo, bsq, bsk, bsv, bso, stream);
 }
 
 // dQ, dK, dV given dO (same layout as O).  delta: workspace [B][H][Nq] fp32.
 int sidlsg_attn_bwd(const void* Q, const void* K, const void* V, const void* O, const void* dO, const float* LSE, void* dQ,
                     void* dK, void* dV, float* delta, int B, int H, int Nq, int Nk, int D, int ldq, int ldk, int ldv, int ldo,
                     long long bsq, long long bsk, long long bsv, long long bso, void* stream) {
-    if ((ldq | ldk | ldv | ldo) & 3) return SIDLSG_EINVAL;
-    hipStream_t s = (hipStream_t)stream;
-    AttnParams p{};
-    p.Q = (const bf16*)Q; p.K = (const bf16*)K; p.V = (const bf16*)V; p.dO = (const bf16*)dO;
-    p.dQ = (bf16*)dQ; p.dK = (bf16*)dK; p.dV = (bf16*)dV; p.LSE = const_cast<float*>(LSE); p.delta = delta;
-    p.B = B; p.H = H; p.Nq = Nq; p.Nk = Nk; p.D = D; p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo;
-    p.bsq = bsq; p.bsk = bsk; p.bsv = bsv; p.bso = bso;
-    p.scale = 1.0f / sqrtf((float)D); p.scale2 = p.scale * 1.4426950408889634f;
-    p.O = const_cast<bf16*>((const bf16*)O); p.delta_out = delta;
-    if (int e = dispatch_attn(p, 1, s)) return e;
-    return dispatch_attn(p, 2, s);
+    return attn_bwd_impl(false, Q, K, V, O, dO, LSE, dQ, dK, dV, delta, B, H, Nq, Nk, D, ldq, ldk, ldv, ldo, bsq, bsk, bsv, bso, stream);
+}
+
+// The same with PRE-SCALED queries: Q holds q * (D^-0.5 * log2 e) -- the caller folds the factor into the q rows of the
+// projection weight (sidlsg_scale_cast_ranges), which costs no extra rounding: O = softmax2(Q K^T) V with softmax2 in base 2.
+// The backward returns the gradient with respect to the SCALED queries (dQ = ln2 * dS K, dK = ln2 * dS^T Q).
+int sidlsg_attn_fwd_ps(const void* Q, const void* K, const void* V, void* O, float* LSE, int B, int H, int Nq, int Nk, int D,
+                       int ldq, int ldk, int ldv, int ldo, long long bsq, long long bsk, long long bsv, long long bso,
+                       void* stream) {
+    return attn_fwd_impl(true, Q, K, V, O, LSE, B, H, Nq, Nk, D, ldq, ldk, ldv, ldo, bsq, bsk, bsv, bso, stream);
+}
+int sidlsg_attn_bwd_ps(const void* Q, const void* K, const void* V, const void* O, const void* dO, const float* LSE, void* dQ,
+                       void* dK, void* dV, float* delta, int B, int H, int Nq, int Nk, int D, int ldq, int ldk, int ldv, int ldo,
+                       long long bsq, long long bsk, long long bsv, long long bso, void* stream) {
+    return attn_bwd_impl(true, Q, K, V, O, dO, LSE, dQ, dK, dV, delta, B, H, Nq, Nk, D, ldq, ldk, ldv, ldo, bsq, bsk, bsv, bso, stream);
 }
 
 }  // extern "C"

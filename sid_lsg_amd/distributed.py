@@ -66,12 +66,14 @@ class FlatGradReducer:
     the next phase's noise / text conditioning (which does not read the parameters), then wait().
     """
 
-    def __init__(self, nbuckets=4, group=None, exchange_dtype=None):
+    def __init__(self, nbuckets=4, group=None, exchange_dtype=None, min_world=2):
         """exchange_dtype: None / torch.float32 = all-reduce the fp32 gradients in place (the reference's DDP semantics);
         torch.bfloat16 (or SIDLSG_GRAD_EXCHANGE=bf16) = OPT-IN halved xGMI traffic: each message is rounded to bf16 into a
         staging buffer, all-reduced in bf16 and written back to the fp32 gradient buffer.  This changes the numbers (8
-        mantissa bits per rank contribution, bf16 accumulation inside the collective) and is therefore off by default."""
-        self.nbuckets, self.group = nbuckets, group
+        mantissa bits per rank contribution, bf16 accumulation inside the collective) and is therefore off by default.
+        min_world: the exchange is skipped below this world size (2: a single rank has nothing to exchange; 1 makes a
+        one-rank job run the collectives anyway -- how the RCCL path is exercised on a one-GPU box)."""
+        self.nbuckets, self.group, self.min_world = nbuckets, group, int(min_world)
         self.stream = torch.cuda.Stream() if torch.cuda.is_available() else None
         self.handles = []
         if exchange_dtype is None and os.environ.get('SIDLSG_GRAD_EXCHANGE', 'fp32').lower() in ('bf16', 'bfloat16'):
@@ -93,7 +95,7 @@ class FlatGradReducer:
     def start_range(self, flat_grad, lo, hi, max_elems=1 << 28):
         """all-reduce flat_grad[lo:hi] (in messages of <= max_elems elements = 1 GiB fp32) on the communication stream,
         ordered after everything already enqueued on the current stream.  Several ranges may be in flight; wait() joins all."""
-        if get_world_size() == 1 or hi <= lo:
+        if get_world_size() < self.min_world or hi <= lo:
             return
         if self.stream is not None:
             self.stream.wait_stream(torch.cuda.current_stream())
@@ -107,7 +109,7 @@ class FlatGradReducer:
                 self._all_reduce(flat_grad[o:min(hi, o + max_elems)])
 
     def start(self, flat_grad):
-        if get_world_size() == 1:
+        if get_world_size() < self.min_world:
             return
         n = flat_grad.numel()
         step = (n + self.nbuckets - 1) // self.nbuckets

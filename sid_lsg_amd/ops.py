@@ -52,14 +52,21 @@ def _fn(name, dtype, bf16_suffix=''):
 
 
 def _wants_grad(p):
-    """Weight gradients are wanted iff the parameter requires grad.  Its `.grad` must then be the pre-bound view of the
-    network's flat gradient buffer: HipUNet2DCondition re-binds (and zeroes) the views at the start of every forward if a
-    foreign optimizer ran `zero_grad(set_to_none=True)` (sid_training_loop.py:390,469), so a None here is a caller bug."""
+    """Weight gradients are wanted iff the parameter requires grad.  Its `.grad` is the pre-bound view of the network's flat
+    gradient buffer: HipUNet2DCondition re-binds (and zeroes) the views at the start of every forward if a foreign optimizer
+    ran `zero_grad(set_to_none=True)` (sid_training_loop.py:390,469); a None that appears between a forward and its backward
+    is re-bound here the same way."""
     if p is None or not p.requires_grad:
         return False
     if p.grad is None:
-        raise RuntimeError('parameter requires grad but has no gradient buffer bound (zero_grad(set_to_none=True) between '
-                           'forward and backward?): weight gradients would be lost')
+        # zero_grad(set_to_none=True) between a forward and its backward (a retained graph, an accumulation round of a
+        # foreign optimizer): None means zero to the caller, so the flat-buffer view comes back zeroed
+        flat = getattr(p, '_flat_grad', None)
+        if flat is None:
+            raise RuntimeError('parameter requires grad but has no gradient buffer to bind (not a HipUNet2DCondition parameter?): '
+                               'weight gradients would be lost')
+        flat.zero_()
+        p.grad = flat
     return True
 
 
@@ -67,9 +74,15 @@ def _wants_grad(p):
 _workspace = {}
 
 
+def _dev_key(device):
+    """Cache key of a device: its index; an index-less 'cuda' device means the CURRENT device (not device 0)."""
+    idx = torch.device(device).index
+    return torch.cuda.current_device() if idx is None else idx
+
+
 def ensure_workspace(device, nbytes=512 << 20):
     """fp32 split-K scratch for the small-pixel-count convs/GEMMs (allocated once per device through torch's allocator)."""
-    key = torch.device(device).index or 0
+    key = _dev_key(device)
     if key not in _workspace:
         ws = torch.empty(nbytes // 4, device=device, dtype=F32)
         lib.sidlsg_set_workspace(ws.data_ptr(), ws.numel() * 4)
@@ -84,7 +97,7 @@ _side_streams = {}
 def side_stream(device):
     """The process-wide second compute stream of `device` (with its private split-K workspace): created once, shared by
     every SiDStep -- the C library keeps at most 4 stream workspaces."""
-    key = torch.device(device).index or 0
+    key = _dev_key(device)
     if key not in _side_streams:
         _side_streams[key] = torch.cuda.Stream(device=device)
         ensure_stream_workspace(_side_streams[key])
@@ -105,7 +118,7 @@ _wgrad_join_armed = set()
 
 
 def wgrad_stream(device):
-    key = torch.device(device).index or 0
+    key = _dev_key(device)
     if key not in _wgrad_streams:
         _wgrad_streams[key] = torch.cuda.Stream(device=device)
         ensure_stream_workspace(_wgrad_streams[key])
@@ -114,7 +127,7 @@ def wgrad_stream(device):
 
 def grad_streams(device):
     """Side streams that may still be writing parameter gradients of `device` (a gradient exchange must wait for them)."""
-    key = torch.device(device).index or 0
+    key = _dev_key(device)
     return [_wgrad_streams[key]] if key in _wgrad_streams else []
 
 
@@ -143,7 +156,7 @@ class _OnWgradStream:
             t.record_stream(self.side)
         # one join per backward pass and device, keyed by the autograd graph-task id (a pass that died with an exception
         # must not leave the next one un-joined)
-        key = (self.tensors[0].device.index or 0, torch._C._current_graph_task_id())
+        key = (_dev_key(self.tensors[0].device), torch._C._current_graph_task_id())
         if key not in _wgrad_join_armed:
             side, dev = self.side, self.tensors[0].device
 
@@ -153,7 +166,9 @@ class _OnWgradStream:
             if key[1] < 0:                       # not inside a backward pass: join right away
                 join()
             else:
-                _wgrad_join_armed.clear()        # ids never repeat: anything left is from a pass that did not finish
+                # ids never repeat: anything left for THIS device is from a pass that did not finish
+                for stale in [k for k in _wgrad_join_armed if k[0] == key[0]]:
+                    _wgrad_join_armed.discard(stale)
                 _wgrad_join_armed.add(key)
                 torch.autograd.Variable._execution_engine.queue_callback(join)
         return False

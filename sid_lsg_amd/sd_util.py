@@ -38,8 +38,15 @@ def _ddp_exchange(net, out):
         return out
 
     def exchange():
-        torch.distributed.all_reduce(inner.flat_grads)
-        inner.flat_grads.div_(world)
+        # engine callbacks run in FIFO order and this one was queued by the FIRST node of the backward, i.e. before the
+        # weight-gradient stream's own join callback (armed at the first wgrad launch): wait for that stream here
+        g = inner.flat_grads
+        if g.is_cuda:
+            cur = torch.cuda.current_stream(g.device)
+            for s in ops.grad_streams(g.device):
+                cur.wait_stream(s)
+        torch.distributed.all_reduce(g)
+        g.div_(world)
     return ops.after_backward(out, exchange)
 
 

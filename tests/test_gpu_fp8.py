@@ -66,6 +66,23 @@ def test_gemm_fp8w_exact_against_its_contract(dev, M, N, K):
     assert float((got.float() - full).abs().max()) <= 2 ** -8 * float(full.abs().max()) * 1.01, 'epilogue'
 
 
+def test_gemm_fp8w_saturates_large_activations(dev):
+    """Activations past the e4m3 range (the un-normalised residual stream of real weights can exceed 448) are clamped to
+    +-448 before the conversion -- the contract's q_act -- instead of turning into NaN."""
+    from sid_lsg_amd import ops
+    torch.manual_seed(3)
+    M, N, K = 256, 64, 128
+    a = torch.randn(M, K, device=dev) * 300.0
+    a[0, :8] = torch.tensor([449., -449., 1e4, -1e4, 3e38, -3e38, 448., -448.], device=dev)
+    a = a.to(BF16)
+    assert float(a.float().abs().max()) > 448
+    q = ops.Fp8Weight((torch.randn(N, K, device=dev) * 0.05).to(BF16))
+    got = ops.gemm(a, q, out_f32=True)
+    assert torch.isfinite(got).all(), 'overflowing activations must saturate, not become NaN'
+    ref = (q_act(a).double() @ q.dequantize().double().t()).float()
+    assert float((got - ref).abs().max()) <= 1e-4 * float(ref.abs().max())
+
+
 @pytest.mark.parametrize('B,H,cin,cout,stride,ups', [(2, 16, 64, 64, 1, 0), (1, 32, 320, 320, 1, 0), (2, 16, 32, 48, 2, 0), (2, 16, 128, 64, 1, 1),
                                                      (1, 8, 2560, 1280, 1, 0), (3, 9, 16, 8, 1, 0)])
 def test_conv3x3_fp8w_exact_against_its_contract(dev, B, H, cin, cout, stride, ups):

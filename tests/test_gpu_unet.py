@@ -142,6 +142,69 @@ def test_sid_iteration_full_size_config1(dev, kappa):
         torch.set_num_threads(min(8, os.cpu_count() or 8))
 
 
+def test_sid_iteration_full_size_sd21_base(dev):
+    """BASELINE.json configs[3] / [4] model: the full SD2.1-base UNet (865.9 M parameters; 5/10/20/20 heads of d = 64,
+    Linear proj_in / proj_out, 1024-wide text states), kappa = 2 (`run_sid.sh:110`), batch 1, 64x64x4 latents: one complete
+    iteration against the fp32 CPU oracle in both compute modes (fp32: north_star's 1e-3; bf16: the stated bf16 bounds)."""
+    try:
+        _iteration_parity(dev, 'sd21-base', lat=64, b=1, rounds=1, lr=1e-6, kappa=2.0, alpha=1.0, iters=1,
+                          ema_names=('conv_in.weight', 'conv_out.bias'), modes=(BF16, F32))
+    finally:
+        torch.set_num_threads(min(8, os.cpu_count() or 8))
+
+
+def test_sd21_base_768px_forward_backward(dev):
+    """configs[3] resolution: SD2.1-base at 96x96 latents (768^2 images): self-attention over N = 9216 / 2304 / 576 / 144
+    tokens at d = 64.  Forward and input / parameter gradients of the full-size network against the fp32 CPU oracle, bf16
+    production mode (weights rounded to bf16 on both sides, like test_unet_forward_backward) and the fp32-accurate mode."""
+    from oracle import fixtures
+    from oracle.unet_ref import CONFIGS as RC
+    from sid_lsg_amd.unet import CONFIGS, HipUNet2DCondition
+    cfg_name, lat, B = 'sd21-base', 96, 1
+    cfg = RC[cfg_name]
+    torch.set_num_threads(min(64, os.cpu_count() or 8))
+    try:
+        ref = fixtures.make_unet(cfg_name)
+        g = torch.Generator().manual_seed(0)
+        x = torch.randn(B, 4, lat, lat, generator=g)
+        t = torch.tensor([625])
+        ctx = torch.randn(B, cfg.text_len, cfg.cross_attention_dim, generator=g).to(BF16)
+        dy = torch.randn(B, 4, lat, lat, generator=g)
+        for cd in (F32, BF16):
+            if cd == BF16:
+                with torch.no_grad():
+                    for p in ref.parameters():
+                        if p.ndim >= 2:
+                            p.copy_(p.to(BF16).float())
+            ref.requires_grad_(True)
+            ref.zero_grad(set_to_none=True)
+            xr = x.clone().requires_grad_()
+            yr = ref(xr, t, encoder_hidden_states=ctx.float()).sample
+            yr.backward(dy)
+            hip = HipUNet2DCondition(CONFIGS[cfg_name], compute_dtype=cd).materialize(dev, source=ref.state_dict()).requires_grad_(True)
+            xd = x.to(dev).requires_grad_()
+            y = hip(xd, t.to(dev), encoder_hidden_states=ctx.to(dev).to(cd)).sample
+            y.backward(dy.to(dev))
+            fmax, fl2 = rel_err(y, yr)
+            _, dl2 = rel_err(xd.grad, xr.grad)
+            ref_p = dict(ref.named_parameters())
+            worst, wname = 0.0, ''
+            for name, p in hip.named_parameters():
+                gr = ref_p[name].grad
+                e = ((p.grad.detach().float().cpu() - gr).norm() / (gr.norm() + 1e-5)).item()
+                if e > worst:
+                    worst, wname = e, name
+            print(f'sd21-base 96x96 [{cd}]: fwd rel max {fmax:.2e} l2 {fl2:.2e}; dx l2 {dl2:.2e}; worst param grad {worst:.2e} ({wname})')
+            if cd == F32:
+                assert fmax < 1e-4 and dl2 < 5e-4 and worst < 5e-3
+            else:
+                assert fmax < 4e-2 and fl2 < 2e-2 and dl2 < 4e-2 and worst < 8e-2
+            del hip
+            torch.cuda.empty_cache()
+    finally:
+        torch.set_num_threads(min(8, os.cpu_count() or 8))
+
+
 def _iteration_parity(dev, cfg_name, lat, b, rounds, lr, kappa, alpha, iters, ema_names, modes=(BF16,)):
     from oracle import fixtures, sid_ref
     from oracle.scheduler_ref import DDPMSchedulerRef
@@ -151,7 +214,7 @@ def _iteration_parity(dev, cfg_name, lat, b, rounds, lr, kappa, alpha, iters, em
     from sid_lsg_amd.sid_step import SiDStep
     from sid_lsg_amd.unet import CONFIGS, HipUNet2DCondition
     cfg = RC[cfg_name]
-    if cfg_name == 'sd15':          # the full-size oracle iteration wants the host's cores (conftest caps the default at 8)
+    if cfg_name in ('sd15', 'sd21-base'):          # the full-size oracle iteration wants the host's cores (conftest caps the default at 8)
         torch.set_num_threads(min(64, os.cpu_count() or 8))
     phi_r = fixtures.make_unet(cfg_name).eval().requires_grad_(False)
     psi_r = fixtures.make_unet(cfg_name, seed=77).requires_grad_(False)   # psi != phi so the G loss is non-trivial at step 0
@@ -465,13 +528,17 @@ def test_two_rank_loop_matches_reference_ddp_golden(dev, golden_dir, tmp_path, p
     rank's own loss curve and the (rank-identical) final weights.  Two processes share this GPU and exchange over gloo
     (tests/mp_loop_worker.py); the exchange logic (FlatGradReducer, overlapped psi / segment-wise G exchange, mean in the
     optimizer kernel) is the production one.  fp32 mode: 1e-3 (north_star); bf16: the bounds of the 1-rank golden test."""
+    import socket
     import subprocess
     import sys
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:        # a free port (a fixed one collides in TIME_WAIT between
+        sk.bind(('127.0.0.1', 0))                                        # the two precisions of this test)
+        port = sk.getsockname()[1]
     golden = os.path.join(golden_dir, 'loop2_k15_a1.npz')
     out = str(tmp_path / 'loop2')
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
-           '--master-port', '29561', os.path.join(os.path.dirname(os.path.abspath(__file__)), 'mp_loop_worker.py'), golden, out, precision]
+           '--master-port', str(port), os.path.join(os.path.dirname(os.path.abspath(__file__)), 'mp_loop_worker.py'), golden, out, precision]
     res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
     g = np.load(golden)
@@ -622,3 +689,53 @@ def test_weight_gradient_stream_changes_nothing(dev):
     diff = float((ref - grads[True][0]).abs().max()) / scale
     print(f'run-to-run {noise:.2e}, single-stream vs weight-gradient stream {diff:.2e} (relative to the largest gradient)')
     assert noise < 1e-5 and diff < 1e-5
+
+
+def test_side_streams_change_nothing_in_the_step(dev):
+    """The teacher runs on a second stream beside the fake-score network (SiDStep.side) and the weight gradients on a third
+    (ops._OnWgradStream); tensors cross streams through autograd's saved-tensor handling + record_stream.  Three iterations
+    with both switches ON must give the losses and weights of the single-stream run, up to the fp32-atomics ordering noise
+    that exists on one stream already (Adam with beta1 = 0 turns a sign flip of a ~0 gradient into a 2 lr step)."""
+    from sid_lsg_amd import ops
+    from sid_lsg_amd.optim import FusedAdamEMA
+    from sid_lsg_amd.scheduler import DDPMScheduler
+    from sid_lsg_amd.sid_step import SiDStep
+    from sid_lsg_amd.unet import CONFIGS, HipUNet2DCondition
+    cfg_name, lat, b, lr, iters = 'tiny40', 16, 4, 2e-5, 3
+    cfg = CONFIGS[cfg_name]
+    results = {}
+    saved = ops._WGRAD_SIDE
+    try:
+        for on in (False, True):
+            ops._WGRAD_SIDE = on
+            phi = HipUNet2DCondition(cfg).materialize(dev, seed=1)
+            psi = HipUNet2DCondition(cfg).materialize(dev, seed=2)
+            G, G_ema = phi.clone_network(), phi.clone_network(with_grad_buffers=False)
+            opt_f = FusedAdamEMA(psi.parameters(), lr=lr, betas=(0.0, 0.999), eps=1e-8)
+            opt_g = FusedAdamEMA(G.parameters(), lr=lr, betas=(0.0, 0.999), eps=1e-8)
+            step = SiDStep(G, psi, phi, G_ema, DDPMScheduler().to(dev), opt_f, opt_g, alpha=1.0, cfg_train_fake=1.5, cfg_eval_fake=1.5,
+                           cfg_eval_real=1.5, batch_gpu_total=b, init_timestep=625)
+            step.side = ops.side_stream(dev) if on else None
+            gen = torch.Generator().manual_seed(3)
+            losses = []
+            for it in range(iters):
+                inputs = {ph: [dict(z=torch.randn(b, 4, lat, lat, generator=gen).to(dev), noise=torch.randn(b, 4, lat, lat, generator=gen).to(dev),
+                                    t=torch.randint(20, 980, (b,), generator=gen).to(dev),
+                                    cond=torch.randn(b, cfg.text_len, cfg.cross_attention_dim, generator=gen).to(dev).to(BF16),
+                                    uncond=torch.randn(b, cfg.text_len, cfg.cross_attention_dim, generator=gen).to(dev).to(BF16))]
+                          for ph in ('A', 'B')}
+                lf, lg = step.iteration(inputs, ema_beta=0.9)
+                losses += [float(lf), float(lg)]
+            torch.cuda.synchronize()
+            results[on] = dict(losses=np.array(losses), G=G.flat_params.clone(), psi=psi.flat_params.clone(), ema=G_ema.flat_params.clone())
+    finally:
+        ops._WGRAD_SIDE = saved
+    a, bb = results[False], results[True]
+    rel = np.abs(a['losses'] - bb['losses']) / np.abs(a['losses'])
+    print(f'losses single-stream {a["losses"]} side streams {bb["losses"]} rel {rel}')
+    assert rel.max() < 2e-4
+    for k in ('G', 'psi', 'ema'):
+        d = (a[k] - bb[k]).abs()
+        frac_same = float((d < 1e-9).float().mean())
+        print(f'{k}: {frac_same:.5f} of the weights bit-equal, max difference {float(d.max()):.2e} (lr {lr})')
+        assert float(d.max()) <= 2.01 * lr * iters and frac_same > 0.98
