@@ -218,13 +218,15 @@ def main():
         one_iteration(it)
     sync()
     timer = timer_gn = timer_attn = None
+    # the self-attention forward entry point the networks use: pre-scaled queries unless switched off (unet._build_prescale_plan)
+    ATTN_FWD = 'sidlsg_attn_fwd_ps' if any(getattr(m, 'prescaled', False) for m in phi.modules()) else 'sidlsg_attn_fwd'
     if not args.no_kernel_timing and rank == 0:      # roofline of the dominant kernel, sampled live over the timed region
         timer = KernelTimer(lib, 'sidlsg_conv3x3_bf16', conv_flops)
         timer.__enter__()
         # north_star's two other pieces of evidence: HBM GB/s on GroupNorm, MFMA utilisation on attention (forward entry points)
         timer_gn = KernelTimer(lib, 'sidlsg_groupnorm_fwd', gn_bytes, stride=5)
         timer_gn.__enter__()
-        timer_attn = KernelTimer(lib, 'sidlsg_attn_fwd', attn_flops, stride=3)
+        timer_attn = KernelTimer(lib, ATTN_FWD, attn_flops, stride=3)
         timer_attn.__enter__()
     t0 = time.time()
     for it in range(args.warmup, args.warmup + args.steps):
@@ -245,7 +247,7 @@ def main():
         side, step.side = step.side, None
         wgrad_side, _ops._WGRAD_SIDE = _ops._WGRAD_SIDE, False      # weight gradients back on the main stream as well
         tms = dict(conv=KernelTimer(lib, 'sidlsg_conv3x3_bf16', conv_flops), gn=KernelTimer(lib, 'sidlsg_groupnorm_fwd', gn_bytes, stride=5),
-                   attn=KernelTimer(lib, 'sidlsg_attn_fwd', attn_flops, stride=3))
+                   attn=KernelTimer(lib, ATTN_FWD, attn_flops, stride=3))
         for tm in tms.values():
             tm.__enter__()
         for it in range(args.warmup + args.steps, args.warmup + args.steps + 3):

@@ -93,9 +93,10 @@ int sidlsg_attn_bwd(const void* Q, const void* K, const void* V, const void* O, 
                     void* dK, void* dV, float* delta, int B, int H, int Nq, int Nk, int D, int ldq, int ldk, int ldv, int ldo,
                     long long bsq, long long bsk, long long bsv, long long bso, void* stream);
 /* The same with PRE-SCALED queries: Q holds q * (D^-1/2 * log2 e) -- the caller folds the factor into the q rows of the
- * projection weight's compute copy (sidlsg_scale_cast_ranges: one rounding, like the unscaled copy).  The QK^T accumulators
- * are then seeded with -max / -LSE and feed v_exp_f32 directly.  The backward returns gradients with respect to the SCALED
- * queries (dQ = ln2 dS K, dK = ln2 dS^T Q); the caller's weight-gradient call rescales the q rows (sidlsg_wgrad_bf16_rs). */
+ * projection weight's FORWARD compute copy (sidlsg_scale_cast_ranges: one rounding, like the unscaled copy).  The QK^T
+ * accumulators are then seeded with -max / -LSE and feed v_exp_f32 directly.  The backward returns the SAME tensors as
+ * sidlsg_attn_bwd: gradients with respect to the unscaled q (= Q / (D^-1/2 log2 e)), k and v -- so the projection's weight
+ * gradient is the ordinary one and its backward-data operand is the UNSCALED transposed weight. */
 int sidlsg_attn_fwd_ps(const void* Q, const void* K, const void* V, void* O, float* LSE, int B, int H, int Nq, int Nk, int D,
                        int ldq, int ldk, int ldv, int ldo, long long bsq, long long bsk, long long bsv, long long bso,
                        void* stream);
@@ -156,6 +157,11 @@ int sidlsg_transpose_w_batched(const void* jobs, int njobs, int nblocks, void* s
 /* Same, from the bf16 COMPUTE copies (src of a record points at bf16 [N][T][K]; 4 instead of 6 bytes per parameter):
  * 64x64 tiles -> blk0 / nblocks count ceil(N/64)*ceil(K/64) tiles per tap; N and K multiples of 8. */
 int sidlsg_transpose_w16_batched(const void* jobs, int njobs, int nblocks, void* stream);
+/* Scaled re-cast of parameter ranges, dst[i] = bf16(scale * src[i]): folds the attention's D^-1/2 log2(e) factor into the q
+ * rows of a projection weight's bf16 COMPUTE copy (sidlsg_attn_fwd_ps).  jobs: DEVICE array of
+ *   struct { const float* src; void* dst; int n, blk0; float scale; int pad; }   (32 bytes)
+ * sorted by blk0 = index of the job's first block of 2048 elements; nblocks = total. */
+int sidlsg_scale_cast_ranges(const void* jobs, int njobs, int nblocks, void* stream);
 
 /* ---- reference plugin op: torch_utils/ops/bias_act.cpp:32 `bias_act(x,b,xref,yref,dy,grad,dim,act,alpha,gain,clamp)`
  * act: 1 linear 2 relu 3 lrelu 4 tanh 5 sigmoid 6 elu 7 selu 8 softplus 9 swish (bias_act.py:23-33).

@@ -179,6 +179,10 @@ constexpr int AT_KT = 64;   // keys per LDS tile
 #ifndef SIDLSG_DQ_OCC
 #define SIDLSG_DQ_OCC 2
 #endif
+// (A software-pipelined variant of the PS forward -- QK^T of tile j+1 beside the exponentials of tile j in one basic block --
+// was built and measured neutral, commit 2bea052: the MFMA + VALU core alone runs the
+// d = 40 forward in 333 us, LDS fragment reads add ~100 us and tile staging + barrier ~110 us: the loop is bound by those
+// stalls, not by MFMA/VALU overlap.)
 // PS ("pre-scaled"): Q arrives already multiplied by D^-0.5 * log2(e) (the caller folds the factor into the q rows of the
 // projection weight, see sidlsg_attn_fwd_ps), so the QK^T MFMA yields the scores in log2 units and its C operand is seeded
 // with -m (forward: the running maximum; dQ pass: -LSE): the accumulators come out as s - m and go straight into
@@ -433,8 +437,8 @@ __global__ __launch_bounds__(256, (DP <= 48 && MODE == 0) ? 4 : ((DP <= 48 && MO
 #pragma unroll
     for (int qt = 0; qt < QT; qt++) {
         const int q = q0 + qt * 16 + li;
-        // dQ = d^-1/2 * sum_k dS K; with pre-scaled Q the gradient wrt the SCALED q is ln2 * sum_k dS K
-        float inv = MODE == 1 ? (PS ? 0.6931471805599453f : p.scale) : 1.f;
+        // dQ = d^-1/2 * sum_k dS K: the gradient with respect to the UNSCALED queries, also when Q arrived pre-scaled
+        float inv = MODE == 1 ? p.scale : 1.f;
         if (MODE == 0) {
             float lt;
             if (ONES) {
@@ -449,217 +453,6 @@ __global__ __launch_bounds__(256, (DP <= 48 && MODE == 0) ? 4 : ((DP <= 48 && MO
         }
         if (q >= p.Nq) continue;
         bf16* dst = (MODE == 0 ? p.O : p.dQ) + b * (MODE == 0 ? p.bso : p.bsq) + (long long)q * (MODE == 0 ? p.ldo : p.ldq) + (long long)h * p.D;
-#pragma unroll
-        for (int dt = 0; dt < DT; dt++) {
-            const int d = dt * 16 + lg * 4;
-            if (d + 4 <= p.D) {
-                bf16x4 v = {f2bf(o[dt][qt][0] * inv), f2bf(o[dt][qt][1] * inv), f2bf(o[dt][qt][2] * inv), f2bf(o[dt][qt][3] * inv)};
-                *reinterpret_cast<bf16x4*>(dst + d) = v;
-            }
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------------------------
-// Software-pipelined forward for pre-scaled queries (Nk a multiple of 64, >= 128): the loop body of key tile j is ONE basic
-// block that holds
-//     the QK^T MFMAs of tile j+1 (accumulators seeded with -m)   next to   exp2 / bf16 packing of tile j's scores
-//     the P.V MFMAs of tile j                                       next to   the lane-local maximum of tile j+1's scores
-// so that every MFMA has independent VALU work behind it IN THE SAME WAVE'S instruction stream (tools/ubench/mfma_valu.hip:
-// 4 v_exp_f32 behind each 16x16x32 MFMA cost 17 ns per group against 14.7 ns for the exps alone and 8 ns for the MFMA alone;
-// the un-pipelined loop runs MFMA phase and softmax phase back to back and measured their SUM).  The only branch of the body
-// is the (rare) running-maximum update at its top, taken when a lane's maximum of s - m exceeds 8; it rescales O, l and the
-// not yet exponentiated scores of tile j.  The two score register sets alternate roles (loop unrolled by two).
-// LDS: K tiles are staged one tile further ahead than V tiles (K_{j+2} and V_{j+1} are committed at the bottom of iteration
-// j); two buffers each, one barrier per tile.
-#ifndef SIDLSG_SP_ABL
-#define SIDLSG_SP_ABL 0      // measurement builds (tools/ab/attn_abl.sh): 1 no exp, 2 no QK^T MFMAs, 3 no P.V MFMAs, 4 no staging, 5 no LDS reads
-#endif
-#ifndef SIDLSG_SP_OCC
-#define SIDLSG_SP_OCC 3
-#endif
-template <int DP, bool ONES>
-__global__ __launch_bounds__(256, DP <= 48 ? SIDLSG_SP_OCC : 2) void attn_fwd_sp_kernel(AttnParams p) {
-    constexpr int QT = 2;
-    constexpr int LD = tile_ld<DP>();
-    constexpr int DT = DP / 16;
-    constexpr int N32 = Frag<DP>::N32;
-    constexpr int TE = lds_tile_elems<DP, AT_KT>();
-    __shared__ __attribute__((aligned(16))) bf16 Ks[2][TE];
-    __shared__ __attribute__((aligned(16))) bf16 Vs[2][TE];
-    const int b = blockIdx.z, h = blockIdx.y;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lg = lane >> 4;
-    const int q0 = (blockIdx.x * 4 + wave) * (QT * 16);
-    const bf16* Qb = p.Q + b * p.bsq + (long long)h * p.D;
-    const __amdgpu_buffer_rsrc_t rk = mk_rsrc_rows(p.K + b * p.bsk + (long long)h * p.D, p.Nk, p.ldk, p.D);
-    const __amdgpu_buffer_rsrc_t rv = mk_rsrc_rows(p.V + b * p.bsv + (long long)h * p.D, p.Nk, p.ldv, p.D);
-    const int ones_col = ONES ? p.D : -1;
-#pragma unroll
-    for (int i = 0; i < 2; i++) { lds_tile_init<DP, AT_KT>(Ks[i]); lds_tile_init<DP, AT_KT>(Vs[i]); }
-    Frag<DP> fq[QT];
-#pragma unroll
-    for (int qt = 0; qt < QT; qt++) {
-        const int q = q0 + qt * 16 + li;
-        const bool ok = q < p.Nq;
-        frag_from_global<DP>(fq[qt], Qb + (long long)(ok ? q : 0) * p.ldq, lg, p.D, ok);
-    }
-    f32x4 o[DT][QT];
-#pragma unroll
-    for (int i = 0; i < DT; i++)
-#pragma unroll
-        for (int qt = 0; qt < QT; qt++) o[i][qt] = (f32x4){0, 0, 0, 0};
-    float m[QT], l[QT];
-    f32x4 seed[QT];
-    f32x4 SA[4][QT], SB[4][QT];
-    float mxA[QT], mxB[QT];
-
-    auto qk = [&](const bf16* Kt, f32x4 (&S)[4][QT], bool seeded) {
-#pragma unroll
-        for (int kt = 0; kt < 4; kt++) {
-            Frag<DP> fk;
-            if ((SIDLSG_SP_ABL == 5 || SIDLSG_SP_ABL == 45 || SIDLSG_SP_ABL == 145) && seeded) fk = fq[kt & 1]; else
-            frag_from_lds<DP>(fk, Kt + (kt * 16 + li) * LD, lg);
-#pragma unroll
-            for (int sl = 0; sl < N32; sl++)
-#pragma unroll
-                for (int qt = 0; qt < QT; qt++)
-                    S[kt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fk.w[sl], fq[qt].w[sl],
-                                                                        sl == 0 ? (seeded ? seed[qt] : (f32x4){0, 0, 0, 0}) : S[kt][qt], 0, 0, 0);
-        }
-    };
-    auto lane_max = [&](const f32x4 (&S)[4][QT], int qt) {
-        float mx = fmax3(S[0][qt][0], S[0][qt][1], S[0][qt][2]);
-        mx = fmax3(mx, S[0][qt][3], S[1][qt][0]);
-        mx = fmax3(mx, S[1][qt][1], S[1][qt][2]);
-        mx = fmax3(mx, S[1][qt][3], S[2][qt][0]);
-        mx = fmax3(mx, S[2][qt][1], S[2][qt][2]);
-        mx = fmax3(mx, S[2][qt][3], S[3][qt][0]);
-        mx = fmax3(mx, S[3][qt][1], S[3][qt][2]);
-        return fmax2(mx, S[3][qt][3]);
-    };
-
-    // prologue: K0, V0 -> LDS; K1 in flight; S(tile 0) with zero seed; m := row maximum of tile 0
-    const int nt = p.Nk / AT_KT;
-    TileRegs<DP, AT_KT> tk, tv;
-    tk.init(p.ldk, p.D);
-    tv.init(p.ldv, p.D);
-    tk.load(rk, p.ldk, 0);
-    tv.load(rv, p.ldv, 0);
-    tk.store(Ks[0], LD);
-    tv.store(Vs[0], LD, ones_col);
-    tk.load(rk, p.ldk, AT_KT);
-    __syncthreads();
-    qk(Ks[0], SA, false);
-#pragma unroll
-    for (int qt = 0; qt < QT; qt++) {
-        float mx = lane_max(SA, qt);
-        mx = fmax2(mx, __shfl_xor(mx, 16, 64));
-        mx = fmax2(mx, __shfl_xor(mx, 32, 64));
-        m[qt] = mx; l[qt] = 0.f;
-        seed[qt] = (f32x4){-mx, -mx, -mx, -mx};
-#pragma unroll
-        for (int kt = 0; kt < 4; kt++)
-#pragma unroll
-            for (int r = 0; r < 4; r++) SA[kt][qt][r] -= mx;
-        mxA[qt] = 0.f;
-    }
-    tk.store(Ks[1], LD);
-    __syncthreads();
-
-    // one key tile: Sc = scores of tile j (already s - m), mxc = their lane-local maxima; Sn / mxn receive tile j + 1
-    auto body = [&](const int j, f32x4 (&Sc)[4][QT], float (&mxc)[QT], f32x4 (&Sn)[4][QT], float (&mxn)[QT], auto has_next) {
-        constexpr bool NEXT = decltype(has_next)::value;
-        if (__any(fmax2(mxc[0], mxc[1]) > 8.0f)) {          // rare: the running maximum moves
-#pragma unroll
-            for (int qt = 0; qt < QT; qt++) {
-                float mx = mxc[qt];
-                mx = fmax2(mx, __shfl_xor(mx, 16, 64));
-                mx = fmax2(mx, __shfl_xor(mx, 32, 64));
-                const float delta = fmax2(mx, 0.f);
-                const float alpha = __builtin_amdgcn_exp2f(-delta);
-                l[qt] *= alpha;
-#pragma unroll
-                for (int i = 0; i < DT; i++) o[i][qt] *= alpha;
-                m[qt] += delta;
-                const float nm = -m[qt];
-                seed[qt] = (f32x4){nm, nm, nm, nm};
-#pragma unroll
-                for (int kt = 0; kt < 4; kt++)
-#pragma unroll
-                    for (int r = 0; r < 4; r++) Sc[kt][qt][r] -= delta;
-            }
-        }
-        if (NEXT && !(SIDLSG_SP_ABL == 4 || SIDLSG_SP_ABL == 45 || SIDLSG_SP_ABL == 145)) {                     // K_{j+2} (reads zeros past the sequence end) and V_{j+1}
-            tk.load(rk, p.ldk, (j + 2) * AT_KT);
-            tv.load(rv, p.ldv, (j + 1) * AT_KT);
-        }
-        __builtin_amdgcn_sched_barrier(0);      // the loads stay at the top of the body (the scheduler sank them next to their use)
-        const bf16* Vt = Vs[j & 1];
-        if (NEXT && SIDLSG_SP_ABL != 2) qk(Ks[(j + 1) & 1], Sn, true);
-        bf16x8 pb[2][QT];
-#pragma unroll
-        for (int qt = 0; qt < QT; qt++) {
-            float sum = 0.f;
-#pragma unroll
-            for (int kt = 0; kt < 4; kt++)
-#pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    const float e = (SIDLSG_SP_ABL == 1 || SIDLSG_SP_ABL == 145) ? Sc[kt][qt][r] : __builtin_amdgcn_exp2f(Sc[kt][qt][r]);
-                    Sc[kt][qt][r] = e;
-                    if (!ONES) sum += e;
-                }
-            if (!ONES) l[qt] += sum;
-            pb[0][qt] = pack_p(Sc[0][qt], Sc[1][qt]);
-            pb[1][qt] = pack_p(Sc[2][qt], Sc[3][qt]);
-        }
-#pragma unroll
-        for (int kb = 0; kb < 2; kb++)
-#pragma unroll
-            for (int dt = 0; dt < DT; dt++) {
-                if (SIDLSG_SP_ABL == 3) { o[dt][0][0] += bf2f(pb[kb][0][dt & 7]); o[dt][1][1] += bf2f(pb[kb][1][dt & 7]); continue; }
-                const bf16x8 fa = (SIDLSG_SP_ABL == 5 || SIDLSG_SP_ABL == 45 || SIDLSG_SP_ABL == 145) ? fq[0].w[0] : tr_frag32(Vt, LD, kb * 32, dt * 16, li, lg);
-#pragma unroll
-                for (int qt = 0; qt < QT; qt++) o[dt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, pb[kb][qt], o[dt][qt], 0, 0, 0);
-            }
-        if (NEXT) {
-#pragma unroll
-            for (int qt = 0; qt < QT; qt++) mxn[qt] = lane_max(Sn, qt);
-            asm volatile("" : "+v"(mxn[0]), "+v"(mxn[1]));      // computed here, beside the P.V MFMAs, not at the next use
-            if (!(SIDLSG_SP_ABL == 4 || SIDLSG_SP_ABL == 45 || SIDLSG_SP_ABL == 145)) {
-                tk.store(Ks[j & 1], LD);                       // K_{j+2}: the buffer K_j left after iteration j - 1
-                tv.store(Vs[(j + 1) & 1], LD, ones_col);      // V_{j+1}
-                __syncthreads();
-            }
-        }
-    };
-    using T_ = std::true_type;
-    using F_ = std::false_type;
-    int j = 0;
-    for (; j + 2 < nt; j += 2) {
-        body(j, SA, mxA, SB, mxB, T_{});
-        body(j + 1, SB, mxB, SA, mxA, T_{});
-    }
-    if (nt - j == 2) {
-        body(j, SA, mxA, SB, mxB, T_{});
-        body(j + 1, SB, mxB, SA, mxA, F_{});
-    } else {
-        body(j, SA, mxA, SB, mxB, F_{});
-    }
-#pragma unroll
-    for (int qt = 0; qt < QT; qt++) {
-        const int q = q0 + qt * 16 + li;
-        float lt;
-        if (ONES) {
-            lt = __shfl(o[DT - 1][qt][0], li + 32, 64);        // row D = (DT-1)*16 + 8: lane group 2, r = 0
-        } else {
-            lt = l[qt];
-            lt += __shfl_xor(lt, 16, 64);
-            lt += __shfl_xor(lt, 32, 64);
-        }
-        const float inv = lt > 0.f ? 1.f / lt : 0.f;
-        if (q < p.Nq && lg == 0 && p.LSE) p.LSE[((long long)b * p.H + h) * p.Nq + q] = m[qt] + log2f(lt);
-        if (q >= p.Nq) continue;
-        bf16* dst = p.O + b * p.bso + (long long)q * p.ldo + (long long)h * p.D;
 #pragma unroll
         for (int dt = 0; dt < DT; dt++) {
             const int d = dt * 16 + lg * 4;
@@ -815,12 +608,6 @@ __global__ __launch_bounds__(256) void attn_dkdv_kernel(AttnParams p) {
 template <int DP, int QT, int KT, bool PS>
 static int launch_attn(const AttnParams& p, int mode, hipStream_t s) {
     const int qb = 4 * QT * 16, kb = 4 * KT * 16;
-    static const bool allow_sp = !(getenv("SIDLSG_ATTN_SP") && atoi(getenv("SIDLSG_ATTN_SP")) == 0);
-    if constexpr (PS && DP >= 48 && DP <= 96) if (mode == 0 && allow_sp && p.Nk % AT_KT == 0 && p.Nk >= 2 * AT_KT) {
-        if (p.D == DP - 8) hipLaunchKernelGGL((attn_fwd_sp_kernel<DP, true>), dim3((p.Nq + 127) / 128, p.H, p.B), dim3(256), 0, s, p);
-        else hipLaunchKernelGGL((attn_fwd_sp_kernel<DP, false>), dim3((p.Nq + 127) / 128, p.H, p.B), dim3(256), 0, s, p);
-        return sidlsg_last_error();
-    }
     if (mode == 0) {
         if (p.D == DP - 8) hipLaunchKernelGGL((attn_q_kernel<DP, QT, 0, true, PS>), dim3((p.Nq + qb - 1) / qb, p.H, p.B), dim3(256), 0, s, p);
         else hipLaunchKernelGGL((attn_q_kernel<DP, QT, 0, false, PS>), dim3((p.Nq + qb - 1) / qb, p.H, p.B), dim3(256), 0, s, p);
@@ -901,7 +688,8 @@ int sidlsg_attn_bwd(const void* Q, const void* K, const void* V, const void* O, 
 
 // The same with PRE-SCALED queries: Q holds q * (D^-0.5 * log2 e) -- the caller folds the factor into the q rows of the
 // projection weight (sidlsg_scale_cast_ranges), which costs no extra rounding: O = softmax2(Q K^T) V with softmax2 in base 2.
-// The backward returns the gradient with respect to the SCALED queries (dQ = ln2 * dS K, dK = ln2 * dS^T Q).
+// The backward returns the same tensors as sidlsg_attn_bwd: gradients with respect to the UNSCALED queries (dQ = d^-1/2 dS K),
+// keys (dK = d^-1/2 dS^T q = ln2 dS^T Q) and values.
 int sidlsg_attn_fwd_ps(const void* Q, const void* K, const void* V, void* O, float* LSE, int B, int H, int Nq, int Nk, int D,
                        int ldq, int ldk, int ldv, int ldo, long long bsq, long long bsk, long long bsv, long long bso,
                        void* stream) {

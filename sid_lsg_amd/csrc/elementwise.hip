@@ -553,8 +553,38 @@ static int transpose_w_batched_t(const void* jobs, int njobs, int nblocks, void*
     return sidlsg_last_error();
 }
 
+// Scaled re-cast of parameter ranges: dst[i] = bf16(scale * src[i]) -- used to fold the attention's D^-1/2 log2(e) factor
+// into the q rows of the projection weights' COMPUTE copy (one rounding from the fp32 master, like the plain copy).
+// Job record: { const float* src; bf16* dst; int n; int blk0; float scale; int pad; } (32 bytes); 2048 elements per block.
+struct ScJob { const float* src; bf16* dst; int n, blk0; float scale; int pad; };
+__global__ __launch_bounds__(256) void scale_cast_ranges_kernel(const ScJob* __restrict__ jobs, int njobs) {
+    const int bid = blockIdx.x;
+    int lo = 0, hi = njobs - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (jobs[mid].blk0 <= bid) lo = mid; else hi = mid - 1;
+    }
+    const ScJob j = jobs[lo];
+    const int i0 = ((bid - j.blk0) * 256 + threadIdx.x) * 8;
+    if (i0 >= j.n) return;
+    if (i0 + 8 <= j.n && (((uintptr_t)(j.src + i0)) & 15) == 0 && (((uintptr_t)(j.dst + i0)) & 15) == 0) {
+        float v[8];
+        ldv8<float>(j.src + i0, v);
+#pragma unroll
+        for (int e = 0; e < 8; e++) v[e] *= j.scale;
+        stv8<bf16>(j.dst + i0, v);
+    } else {
+        for (int e = i0; e < j.n && e < i0 + 8; e++) j.dst[e] = f2bf(j.src[e] * j.scale);
+    }
+}
+
 extern "C" {
 
+int sidlsg_scale_cast_ranges(const void* jobs, int njobs, int nblocks, void* stream) {
+    if (!jobs || njobs <= 0 || nblocks <= 0) return SIDLSG_EINVAL;
+    hipLaunchKernelGGL(scale_cast_ranges_kernel, dim3(nblocks), dim3(256), 0, (hipStream_t)stream, (const ScJob*)jobs, njobs);
+    return sidlsg_last_error();
+}
 int sidlsg_transpose_w16_batched(const void* jobs, int njobs, int nblocks, void* stream) {
     if (!jobs || njobs <= 0 || nblocks <= 0) return SIDLSG_EINVAL;
     hipLaunchKernelGGL(transpose_w16_batched_kernel, dim3(nblocks), dim3(256), 0, (hipStream_t)stream, (const TwJob*)jobs, njobs);

@@ -470,25 +470,30 @@ class _Attention(torch.autograd.Function):
     """q: [B,Nq,*] view with heads*D channels starting at column qoff of a row of width ldq; same for k, v."""
 
     @staticmethod
-    def forward(ctx, qbuf, kvbuf, heads, D, qoff, koff, voff):
+    def forward(ctx, qbuf, kvbuf, heads, D, qoff, koff, voff, prescaled=False):
         _chk(qbuf, ACT)
         _chk(kvbuf, qbuf.dtype)
+        # prescaled: the queries arrive multiplied by D^-1/2 log2(e) (folded into the projection's forward weight copy,
+        # HipUNet2DCondition._build_prescale_plan) -> the `_ps` entry points; bf16 only
+        sfx = '_ps' if (prescaled and qbuf.dtype == BF16) else ''
+        if prescaled and not sfx:
+            raise RuntimeError('pre-scaled queries exist in the bf16 compute mode only')
         B, Nq, ldq = qbuf.shape
         Nk, ldk = kvbuf.shape[1], kvbuf.shape[2]
         C = heads * D
         o = torch.empty((B, Nq, C), device=qbuf.device, dtype=qbuf.dtype)
         lse = torch.empty((B, heads, Nq), device=qbuf.device, dtype=F32)
         es = qbuf.element_size()
-        _fn('attn_fwd', qbuf.dtype)(qbuf.data_ptr() + qoff * es, kvbuf.data_ptr() + koff * es, kvbuf.data_ptr() + voff * es, _p(o), _p(lse),
+        _fn('attn_fwd' + sfx, qbuf.dtype)(qbuf.data_ptr() + qoff * es, kvbuf.data_ptr() + koff * es, kvbuf.data_ptr() + voff * es, _p(o), _p(lse),
                                     B, heads, Nq, Nk, D, ldq, ldk, ldk, C, Nq * ldq, Nk * ldk, Nk * ldk, Nq * C, _s())
         ctx.save_for_backward(qbuf, kvbuf, o, lse)
-        ctx.cfg = (heads, D, qoff, koff, voff)
+        ctx.cfg = (heads, D, qoff, koff, voff, sfx)
         return o
 
     @staticmethod
     def backward(ctx, do):
         qbuf, kvbuf, o, lse = ctx.saved_tensors
-        heads, D, qoff, koff, voff = ctx.cfg
+        heads, D, qoff, koff, voff, sfx = ctx.cfg
         B, Nq, ldq = qbuf.shape
         Nk, ldk = kvbuf.shape[1], kvbuf.shape[2]
         C = heads * D
@@ -500,22 +505,22 @@ class _Attention(torch.autograd.Function):
         dkv = dq if same else torch.empty_like(kvbuf)
         delta = torch.empty((B, heads, Nq), device=qbuf.device, dtype=F32)
         es = qbuf.element_size()
-        _fn('attn_bwd', qbuf.dtype)(qbuf.data_ptr() + qoff * es, kvbuf.data_ptr() + koff * es, kvbuf.data_ptr() + voff * es, _p(o), _p(do),
+        _fn('attn_bwd' + sfx, qbuf.dtype)(qbuf.data_ptr() + qoff * es, kvbuf.data_ptr() + koff * es, kvbuf.data_ptr() + voff * es, _p(o), _p(do),
                             _p(lse), dq.data_ptr() + qoff * es, dkv.data_ptr() + koff * es, dkv.data_ptr() + voff * es, _p(delta),
                             B, heads, Nq, Nk, D, ldq, ldk, ldk, C, Nq * ldq, Nk * ldk, Nk * ldk, Nq * C, _s())
-        return dq, (None if same else dkv), None, None, None, None, None
+        return dq, (None if same else dkv), None, None, None, None, None, None
 
 
-def self_attention(qkv, heads):
+def self_attention(qkv, heads, prescaled=False):
     """qkv: [B,N,3C] (fused projection output) -> [B,N,C]"""
     C = qkv.shape[2] // 3
-    return _Attention.apply(qkv, qkv, heads, C // heads, 0, C, 2 * C)
+    return _Attention.apply(qkv, qkv, heads, C // heads, 0, C, 2 * C, prescaled)
 
 
-def cross_attention(q, kv, heads):
+def cross_attention(q, kv, heads, prescaled=False):
     """q: [B,N,C]; kv: [B,L,2C] (fused k|v projection of the text states) -> [B,N,C]"""
     C = q.shape[2]
-    return _Attention.apply(q, kv, heads, C // heads, 0, 0, C)
+    return _Attention.apply(q, kv, heads, C // heads, 0, 0, C, prescaled)
 
 
 class _GEGLU(torch.autograd.Function):
@@ -794,6 +799,11 @@ def transpose_w_batched(jobs, njobs, nblocks, dtype=BF16, src16=False):
         lib.sidlsg_transpose_w16_batched(_p(jobs), njobs, nblocks, _s())
     else:
         _fn('transpose_w_batched', dtype)(_p(jobs), njobs, nblocks, _s())
+
+
+def scale_cast_ranges(jobs, njobs, nblocks):
+    """jobs: device uint8 tensor of njobs records (include/sidlsg_hip.h): dst = bf16(scale * src) per range."""
+    lib.sidlsg_scale_cast_ranges(_p(jobs), njobs, nblocks, _s())
 
 
 def cast_bf16(src_f32, out=None):

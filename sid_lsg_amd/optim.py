@@ -56,6 +56,11 @@ class FusedAdamEMA:
         self.exp_avg_sq = torch.zeros_like(flat)
         self.exp_avg = torch.zeros_like(flat) if self.betas[0] != 0 else None   # beta1 = 0 (the recipe) needs no first moment
         self.hyper = torch.zeros(16, device=flat.device, dtype=torch.float32)
+        # the step's scalars travel through a small ring of PINNED host slots with non-blocking copies: a pageable
+        # host-to-device copy blocks the host until the stream has drained, i.e. it was a device sync per optimizer step
+        self._hyper_host = [torch.zeros(16, dtype=torch.float32).pin_memory() for _ in range(4)]
+        self._hyper_evt = [None] * 4
+        self._hyper_slot = 0
         self.ema = self.w16 = None
         self.grad_scale = 1.0
 
@@ -73,7 +78,15 @@ class FusedAdamEMA:
         t = self.step_count
         h = [self.lr, b1, b2, self.eps, 1 - b1 ** t, math.sqrt(1 - b2 ** t), float(ema_beta), self.weight_decay,
              1.0 if self.decoupled else 0.0, float(self.clip_value) if self.clip_value else 0.0, self.grad_scale]
-        self.hyper[:len(h)].copy_(torch.tensor(h, dtype=torch.float32))
+        k = self._hyper_slot = (self._hyper_slot + 1) % len(self._hyper_host)
+        if self._hyper_evt[k] is not None:
+            self._hyper_evt[k].synchronize()          # the copy that last read this slot (4 optimizer steps ago) has completed
+        host = self._hyper_host[k]
+        host[:len(h)] = torch.tensor(h, dtype=torch.float32)
+        self.hyper.copy_(host, non_blocking=True)
+        evt = self._hyper_evt[k] or torch.cuda.Event()
+        evt.record()
+        self._hyper_evt[k] = evt
 
     def launch(self, use_ema=True, zero_grad=True):
         lib.sidlsg_adam_ema(self.flat.data_ptr(), self.grad.data_ptr(), ops._p(self.exp_avg), self.exp_avg_sq.data_ptr(),

@@ -190,7 +190,12 @@ class TextConditioner:
     def encode(self, prompts):
         ids = self.tokenizer(list(prompts), padding='max_length', max_length=self.tokenizer.model_max_length, truncation=True,
                              return_tensors='pt').input_ids
-        return self.text_encoder(ids.to(self.text_encoder.device))[0].to(self.out_dtype).contiguous()
+        dev = self.text_encoder.device
+        if dev.type == 'cuda':           # pinned + non-blocking: a pageable copy would block the host until the stream drains
+            ids = ids.pin_memory().to(dev, non_blocking=True)
+        else:
+            ids = ids.to(dev)
+        return self.text_encoder(ids)[0].to(self.out_dtype).contiguous()
 
     def uncond(self, batch):
         if self._uncond is None:

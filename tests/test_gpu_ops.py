@@ -262,6 +262,56 @@ def test_self_attention(dev, B, N, heads, D):
     close(qd.grad[..., 2 * C:], r.grad[..., 2 * C:], 2e-2, 'dv')
 
 
+@pytest.mark.parametrize('B,N,heads,D', [(2, 64, 2, 16), (1, 256, 4, 32), (2, 200, 2, 40), (1, 1024, 2, 64), (2, 256, 2, 80), (1, 128, 2, 40),
+                                         (1, 320, 2, 160), (1, 4096, 1, 40), (1, 2304, 2, 64), (2, 77, 2, 40), (1, 33, 1, 40)])
+def test_self_attention_prescaled_queries(dev, B, N, heads, D):
+    """The `_ps` entry points: Q arrives multiplied by D^-1/2 log2(e) (the network folds the factor into the projection's
+    forward weight copy); output and ALL gradients must be those of plain attention on the unscaled queries q = Q / c --
+    the backward deliberately returns d loss / d q (not d loss / d Q), see include/sidlsg_hip.h.  Includes an input whose
+    row maximum jumps by > 2^8 between key tiles (the deferred running-maximum update) and all-negative score rows."""
+    from sid_lsg_amd import ops
+    C = heads * D
+    c = D ** -0.5 * 1.4426950408889634
+    qkv = rnd(B, N, 3 * C, seed=1)
+    if N >= 256:
+        qkv[:, N // 2 + 3, C:C + D] *= 12.0            # one key far above the rest, in the middle of the sequence
+        qkv[:, :, 0] -= 0.5
+    qs = qkv.clone()
+    qs[..., :C] = (qkv[..., :C].float() * c).to(BF16)
+    r = qs.float()
+    r[..., :C] /= c                                      # the unscaled queries the kernel's arithmetic sees
+    r.requires_grad_()
+    yr = attn_ref(r[..., :C], r[..., C:2 * C], r[..., 2 * C:], heads)
+    do = rnd(B, N, C, seed=2)
+    yr.backward(do.float())
+    qd = qs.to(dev).requires_grad_()
+    y = ops.self_attention(qd, heads, prescaled=True)
+    close(y, yr, 1.2e-2, 'fwd')
+    y.backward(do.to(dev))
+    close(qd.grad[..., :C], r.grad[..., :C], 2e-2, 'dq')
+    close(qd.grad[..., C:2 * C], r.grad[..., C:2 * C], 2e-2, 'dk')
+    close(qd.grad[..., 2 * C:], r.grad[..., 2 * C:], 2e-2, 'dv')
+
+
+def test_cross_attention_prescaled_queries(dev):
+    from sid_lsg_amd import ops
+    B, N, L, heads, D = 2, 256, 77, 2, 40
+    C = heads * D
+    c = D ** -0.5 * 1.4426950408889634
+    q, kv = rnd(B, N, C, seed=1), rnd(B, L, 2 * C, seed=3)
+    qs = (q.float() * c).to(BF16)
+    qr, kr = (qs.float() / c).requires_grad_(), kv.float().requires_grad_()
+    yr = attn_ref(qr, kr[..., :C], kr[..., C:], heads)
+    do = rnd(B, N, C, seed=2)
+    yr.backward(do.float())
+    qd, kd = qs.to(dev).requires_grad_(), kv.to(dev).requires_grad_()
+    y = ops.cross_attention(qd, kd, heads, prescaled=True)
+    close(y, yr, 1.2e-2, 'fwd')
+    y.backward(do.to(dev))
+    close(qd.grad, qr.grad, 2e-2, 'dq')
+    close(kd.grad, kr.grad, 2e-2, 'dkv')
+
+
 @pytest.mark.parametrize('B,N,L,heads,D', [(2, 256, 77, 2, 40), (2, 64, 13, 4, 32), (1, 1024, 77, 8, 80), (2, 100, 77, 2, 160)])
 def test_cross_attention(dev, B, N, L, heads, D):
     from sid_lsg_amd import ops

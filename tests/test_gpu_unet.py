@@ -116,10 +116,15 @@ def test_glue_matches_reference_golden(dev, golden_dir):
                     assert e < 4e-2, f'denoise {cfg} b{b} k{kappa} x0{px0}: {e}'
 
 
-# Loss tolerances of the bf16 production path against the fp32 oracle: 2x the worst error observed on MI355X
-# (tiny: 5e-4 / 2e-3; SD1.5 full size: 4e-5 / 9e-4 at kappa 1.5, 3.5e-4 / 3e-3 at kappa 4.5 -- guidance multiplies the bf16
-# difference of the two CFG branches).  The fp32 mode is held to north_star's 1e-3 (observed ~1e-6).
-TOL_LOSS = {BF16: (2e-3, 6e-3), F32: (1e-3, 1e-3)}
+# Loss tolerances of the bf16 production path against the fp32 oracle.  north_star's 1e-3 is asserted in the fp32 mode
+# (observed ~1e-6 on every configuration).  In bf16 the fake-score loss is within 2e-3 everywhere (observed <= 8e-4); the
+# GENERATOR loss is a small signed sum of large terms (y_real - y_fake)(y_fake - x)/w built from two bf16 network outputs with
+# ~1e-2 relative error each, so its error is rounding noise whose sample changes with every change of a rounding path:
+# 12 (configuration, iteration) samples on the tiny networks under two attention rounding paths (queries scaled before /
+# after the bf16 rounding) gave 5e-4 ... 6.6e-3 with no systematic difference; full size: 6.5e-4 (SD1.5, kappa 1.5),
+# 2.0e-3 (SD2.1-base, kappa 2), 4.6e-3 (SD1.5, kappa 4.5: the guidance multiplies the bf16 difference of the CFG branches).
+# Bound: 1e-2.  bf16 is NOT claimed to meet 1e-3 on the generator loss outside kappa = 1.5 at full size (README).
+TOL_LOSS = {BF16: (2e-3, 1e-2), F32: (1e-3, 1e-3)}
 TOL_SIGN = {BF16: 0.97, F32: 0.999}
 
 
@@ -605,7 +610,14 @@ def test_load_sd15_from_diffusers_layout_directory(dev, tmp_path):
     # the fused projection views see the loaded weights, and the compute copies were refreshed
     blk = unet.down_blocks[0].attentions[0].transformer_blocks[0].attn1
     assert torch.equal(blk.fused['w'][:blk.to_q.weight.shape[0]].cpu(), ref.state_dict()['down_blocks.0.attentions.0.transformer_blocks.0.attn1.to_q.weight'])
-    assert torch.equal(blk.fused['w16'].float().cpu(), blk.fused['w'].to(BF16).float().cpu())
+    # forward compute copy: k | v rows are the rounded masters; the q rows carry the softmax factor D^-1/2 log2(e), folded in
+    # BEFORE the single bf16 rounding (unet._build_prescale_plan); the backward-data operand stays unscaled
+    C = blk.to_q.weight.shape[0]
+    assert blk.prescaled
+    assert torch.equal(blk.fused['w16'][C:].float().cpu(), blk.fused['w'][C:].to(BF16).float().cpu())
+    c = (C // blk.heads) ** -0.5 * 1.4426950408889634
+    assert torch.equal(blk.fused['w16'][:C].float().cpu(), (blk.fused['w'][:C] * torch.tensor(c, dtype=F32)).to(BF16).float().cpu())
+    assert torch.equal(blk.fused['w16t'].float().cpu(), blk.fused['w'].to(BF16).float().t().contiguous().cpu())
     for k, v in te.state_dict().items():
         assert torch.equal(te2.state_dict()[k].cpu(), v), k
     for k, v in vae.state_dict().items():

@@ -83,14 +83,12 @@ def main():
         nb = 1 if N >= 4096 else 2
         for ps, x in ((False, qkv), (True, qkv_ps)):
             xin = x[:nb].clone()
-            if ps:   # reference of the PS call: the un-scaled queries are q' / c2 (what the kernel's math sees), gradient wrt q' = grad_q / c2
+            if ps:   # reference of the PS call: the un-scaled queries are q' / c2 (what the kernel's math sees)
                 xr = xin.float()
                 xr[:, :, :C] /= c2
             else:
                 xr = xin.float()
-            o_ref, g_ref = reference(xr, heads, D, do[:nb])
-            if ps:
-                g_ref[:, :, :C] /= c2
+            o_ref, g_ref = reference(xr, heads, D, do[:nb])      # the PS backward returns the gradient wrt the unscaled q too
             o, dqkv = res[ps][2][:nb].float(), res[ps][3][:nb].float()
             eo = float((o - o_ref).abs().max() / o_ref.abs().max())
             eg = [float((dqkv[:, :, i * C:(i + 1) * C] - g_ref[:, :, i * C:(i + 1) * C]).norm() / g_ref[:, :, i * C:(i + 1) * C].norm()) for i in range(3)]
