@@ -84,6 +84,28 @@ def conv_flops(*a):
     return 2.0 * B * Ho * Wo * Cout * 9 * Cin
 
 
+def gemm_flops(*a):
+    # sidlsg_gemm_bf16(A, lda, W, C, ldc, bias, res, ldres, rowvec, ld_rowvec, rows_per_batch, M, N, K, alpha, flags, stream)
+    return 2.0 * a[11] * a[12] * a[13]
+
+
+def wgrad_flops(*a):
+    # sidlsg_wgrad_bf16(dY, ldy, A, lda, dW, dBias, M, N, K, stream)
+    return 2.0 * a[6] * a[7] * a[8]
+
+
+def conv_wgrad_flops(*a):
+    # sidlsg_conv3x3_wgrad_bf16(dY, ldy, X, ldx, dW, dBias, B, H, Wd, Cin, Cout, stride, ups, stream)
+    B, H, Wd, Cin, Cout, stride = a[6], a[7], a[8], a[9], a[10], a[11]
+    Ho, Wo = (H - 1) // stride + 1, (Wd - 1) // stride + 1
+    return 2.0 * B * Ho * Wo * Cout * 9 * Cin
+
+
+def attn_bwd_flops(*a):
+    # sidlsg_attn_bwd(Q, K, V, O, dO, LSE, dQ, dK, dV, delta, B, H, Nq, Nk, D, ...): 5 contractions of the forward's 2
+    return 2.5 * 4.0 * a[10] * a[11] * a[12] * a[13] * a[14]
+
+
 def gn_bytes(*a):
     # sidlsg_groupnorm_fwd(x, gamma, beta, y, stats, ws, B, HW, C, G, eps, silu, stream): algorithmic bytes = read x + write y (bf16)
     return 2.0 * 2.0 * a[6] * a[7] * a[8]
@@ -148,6 +170,9 @@ def main():
     ap.add_argument('--teacher-weights', default='bf16', choices=['bf16', 'fp8'],
                     help="fp8: the frozen teacher's forward weights as e4m3 + per-channel scales (BASELINE configs[4] precision; "
                          "not the headline configuration)")
+    ap.add_argument('--graph', action='store_true',
+                    help='run the timed region through SiDStep.iteration_graphed (one HIP graph per iteration); per-kernel event '
+                         'timing then happens on eager iterations after the timed region')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true')
     args = ap.parse_args()
@@ -207,7 +232,9 @@ def main():
             inputs[ph].append(dict(z=z, noise=noise, t=t, cond=cond.encode(prompts), uncond=cond.uncond(b)))
         half = min(50 * 1000, it * batch_size * 0.05)
         beta = 0.5 ** (batch_size / max(half, 1e-8))
-        return step.iteration(inputs, ema_beta=beta)
+        return (step.iteration_graphed if use_graph else step.iteration)(inputs, ema_beta=beta)
+
+    use_graph = args.graph
 
     def sync():
         if world > 1:
@@ -217,37 +244,56 @@ def main():
     for it in range(args.warmup):
         one_iteration(it)
     sync()
-    timer = timer_gn = timer_attn = None
-    # the self-attention forward entry point the networks use: pre-scaled queries unless switched off (unet._build_prescale_plan)
-    ATTN_FWD = 'sidlsg_attn_fwd_ps' if any(getattr(m, 'prescaled', False) for m in phi.modules()) else 'sidlsg_attn_fwd'
-    if not args.no_kernel_timing and rank == 0:      # roofline of the dominant kernel, sampled live over the timed region
-        timer = KernelTimer(lib, 'sidlsg_conv3x3_bf16', conv_flops)
-        timer.__enter__()
-        # north_star's two other pieces of evidence: HBM GB/s on GroupNorm, MFMA utilisation on attention (forward entry points)
-        timer_gn = KernelTimer(lib, 'sidlsg_groupnorm_fwd', gn_bytes, stride=5)
-        timer_gn.__enter__()
-        timer_attn = KernelTimer(lib, ATTN_FWD, attn_flops, stride=3)
-        timer_attn.__enter__()
+    timers = {}
+    # the attention entry points the networks use: pre-scaled queries unless switched off (unet._build_prescale_plan)
+    ps = any(getattr(m, 'prescaled', False) for m in phi.modules())
+    ATTN_FWD, ATTN_BWD = ('sidlsg_attn_fwd_ps', 'sidlsg_attn_bwd_ps') if ps else ('sidlsg_attn_fwd', 'sidlsg_attn_bwd')
+
+    def make_timers():
+        """One HIP-event timer per kernel family of the step (entry point of the C ABI, work per launch, sampling stride)."""
+        return dict(conv=KernelTimer(lib, 'sidlsg_conv3x3_bf16', conv_flops), gemm=KernelTimer(lib, 'sidlsg_gemm_bf16', gemm_flops, stride=11),
+                    attn=KernelTimer(lib, ATTN_FWD, attn_flops, stride=3), attn_bwd=KernelTimer(lib, ATTN_BWD, attn_bwd_flops, stride=3),
+                    wgrad=KernelTimer(lib, 'sidlsg_wgrad_bf16', wgrad_flops, stride=7), conv_wgrad=KernelTimer(lib, 'sidlsg_conv3x3_wgrad_bf16', conv_wgrad_flops, stride=5),
+                    gn=KernelTimer(lib, 'sidlsg_groupnorm_fwd', gn_bytes, stride=5))
+    if not args.no_kernel_timing and rank == 0 and not use_graph:      # rooflines of the step's kernel families, sampled live over the timed region
+        timers = make_timers()
+        for tm in timers.values():
+            tm.__enter__()
     t0 = time.time()
     for it in range(args.warmup, args.warmup + args.steps):
         lf, lg = one_iteration(it)
     sync()
     dt = time.time() - t0
-    for tm in (timer, timer_gn, timer_attn):
-        if tm is not None:
-            tm.__exit__()
+    for tm in timers.values():
+        tm.__exit__()
+    t_host = None
+    if use_graph:                  # per-kernel events cannot see inside a graph launch: sample eager iterations now
+        hs = time.time()
+        for it in range(args.warmup + args.steps, args.warmup + args.steps + 3):
+            one_iteration(it)
+        t_host = (time.time() - hs) / 3 * 1e3          # host time to enqueue one graphed iteration (inputs + text encode + replay)
+        torch.cuda.synchronize()
+        use_graph = False
+        if not args.no_kernel_timing and rank == 0:
+            timers = make_timers()
+            for tm in timers.values():
+                tm.__enter__()
+            for it in range(args.warmup + args.steps + 3, args.warmup + args.steps + 6):
+                one_iteration(it)
+            torch.cuda.synchronize()
+            for tm in timers.values():
+                tm.__exit__()
     # The timed region runs the teacher on a second HIP stream beside the fake-score network (sid_step.py) and the weight
     # gradients on a third (ops._OnWgradStream): kernels of the
     # streams share the chip, so a launch's event-bracketed duration over the timed region (= what rocprofv3 --kernel-trace
     # reports for the same command) is longer than the kernel's own.  A few extra iterations AFTER the timed region, with that
-    # overlap switched off, give each dominant kernel's stand-alone figure (`isolated` in the roofline objects).
+    # overlap switched off, give each family's stand-alone figure (`isolated` in the roofline objects).
     iso = {}
-    if timer is not None and step.side is not None:
+    if timers and step.side is not None:
         from sid_lsg_amd import ops as _ops
         side, step.side = step.side, None
         wgrad_side, _ops._WGRAD_SIDE = _ops._WGRAD_SIDE, False      # weight gradients back on the main stream as well
-        tms = dict(conv=KernelTimer(lib, 'sidlsg_conv3x3_bf16', conv_flops), gn=KernelTimer(lib, 'sidlsg_groupnorm_fwd', gn_bytes, stride=5),
-                   attn=KernelTimer(lib, ATTN_FWD, attn_flops, stride=3))
+        tms = make_timers()
         for tm in tms.values():
             tm.__enter__()
         for it in range(args.warmup + args.steps, args.warmup + args.steps + 3):
@@ -261,7 +307,7 @@ def main():
     # north_star's second figure: MFMA utilisation of the CFG teacher pass alone (phi forward on the [uncond; cond] batch of
     # 2b samples + guidance + x0), timed with events on a few extra passes after the timed region (rank 0)
     teacher = None
-    if not args.no_kernel_timing and rank == 0:
+    if timers:
         from sid_lsg_amd.sd_util import hip_denoise, hip_prepare_denoise
         with torch.no_grad():
             prompts = synth_prompts(b, seed=12345)
@@ -298,54 +344,59 @@ def main():
                                f'batch_gpu={b}, fp32 masters + bf16 MFMA compute, Adam(beta1=0)+EMA, random-init weights',
                    'global_batch': batch_size, 'parallelism': f'dp{world}', 'teacher_weights': args.teacher_weights},
         'step_tflops': value * img_tflop, 'step_mfma_frac': value * img_tflop / (PEAK_BF16_TFLOPS * world),
-        'loss_fake': float(lf), 'loss_G': float(lg), 'peak_mem_gb': torch.cuda.max_memory_allocated(dev) / 2 ** 30,
+        'graph': bool(args.graph), 'host_enqueue_ms_per_step': t_host, 'loss_fake': float(lf), 'loss_G': float(lg), 'peak_mem_gb': torch.cuda.max_memory_allocated(dev) / 2 ** 30,
     }
     if teacher is not None:
         n_fwd = (2 if args.kappa != 1 else 1) * b
         tf = n_fwd * f_tflop / (teacher * 1e-3)
         out['teacher_pass'] = {'what': f'phi forward on the CFG batch of {n_fwd} samples + guidance + x0 (no grad)', 'ms': teacher,
                                'tflops': tf, 'mfma_frac': tf / PEAK_BF16_TFLOPS}
-    if timer is not None:
-        r = timer.result()
-        ach = r['flops'] / (r['ms'] * 1e-3) / 1e12 if r['ms'] > 0 else 0.0
+    if timers:
+        KERNELS = {'conv': 'implicit-GEMM conv3x3 fwd + dgrad (gemm_v3_kernel<1>, gemm_bf16_kernel<*,*,1|2>)',
+                   'gemm': 'dense GEMM fwd + dgrad: Linear / 1x1 conv over tokens (gemm_v3_kernel<0>, gemm_bf16_kernel<*,*,0>, gemm_finish_kernel)',
+                   'attn': f'flash attention forward, self + cross ({ATTN_FWD}: attn_q_kernel<*,*,0,*,*>)',
+                   'attn_bwd': f'flash attention backward ({ATTN_BWD}: attn_q_kernel<*,*,1,*,*> + attn_dkdv_kernel)',
+                   'wgrad': 'dense weight gradient dW += dY^T A (wgrad_v2_kernel<0> + wgrad_reduce_kernel)',
+                   'conv_wgrad': 'conv3x3 weight gradient (wgrad_v2_kernel<1>, wgrad_v2w_kernel<1> + wgrad_reduce_kernel)',
+                   'gn': 'GroupNorm(32)+SiLU forward (gn_stats_kernel + gn_apply_kernel, one entry point)'}
+
+        def roof(key):
+            r = timers[key].result()
+            hbm = key == 'gn'
+            div, peak, unit = (1e9, PEAK_HBM_GBS, 'GB/s') if hbm else (1e12, PEAK_BF16_TFLOPS, 'TFLOP/s')
+            ach = r['flops'] / (r['ms'] * 1e-3) / div if r['ms'] > 0 else 0.0
+            o = {'bound': 'hbm' if hbm else 'mfma', 'kernel': KERNELS[key], 'achieved': ach, 'peak': peak, 'unit': unit, 'frac': ach / peak,
+                 'traffic': None, 'launches': r['launches'], 'launches_total': r['calls'], 'avg_launch_ms': r['ms'] / max(r['launches'], 1),
+                 # share of the step: sampled average duration x all launches of the timed region (streams overlap: the shares of all
+                 # families add up to more than the wall time)
+                 'est_ms_per_step': r['ms'] / max(r['launches'], 1) * r['calls'] / args.steps,
+                 ('algorithmic_bytes_per_launch' if hbm else 'algorithmic_tflop_per_launch'): r['flops'] / max(r['launches'], 1) / (1 if hbm else 1e12)}
+            q = iso.get(key)
+            if q is not None and q['ms'] > 0:
+                a2 = q['flops'] / (q['ms'] * 1e-3) / div
+                o['isolated'] = {'achieved': a2, 'frac': a2 / peak, 'avg_launch_ms': q['ms'] / max(q['launches'], 1), 'launches': q['launches'],
+                                 'what': '3 iterations after the timed region with the teacher-stream and weight-gradient-stream overlap off'}
+            return o
+        objs = {k: roof(k) for k in timers}
         # HBM-side bytes per launch: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, gfx950-corrected) of the SAME
-        # entry point on the SAME layer shapes, collected with the kernel micro-benchmark (tools/bench_kernels.py conv, batch
-        # 16) -- not inside this timed step (PMC passes serialise kernels); the committed summary says so itself
-        traffic, traffic_src = None, None
-        for name in ('r02_conv_pmc.json', 'r01_conv_pmc.json'):
-            pmc = os.path.join(ROOT, 'profiles', name)
-            if os.path.isfile(pmc):
-                traffic, traffic_src = json.load(open(pmc)).get('avg_hbm_side_bytes_per_launch'), f'profiles/{name} (micro-benchmark of the step\'s conv shapes)'
-                break
-        out['roofline'] = {'bound': 'mfma', 'kernel': 'implicit-GEMM conv3x3 fwd + dgrad (gemm_v3_kernel<1>, gemm_bf16_kernel<*,*,1|2>)',
-                           'achieved': ach, 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / PEAK_BF16_TFLOPS,
-                           'isolated': (lambda q: {'achieved': q['flops'] / (q['ms'] * 1e-3) / 1e12, 'frac': q['flops'] / (q['ms'] * 1e-3) / 1e12 / PEAK_BF16_TFLOPS,
-                                                   'avg_launch_ms': q['ms'] / max(q['launches'], 1), 'launches': q['launches'],
-                                                   'what': '3 iterations after the timed region with the teacher-stream and weight-gradient-stream overlap off'})(iso['conv']) if 'conv' in iso else None,
-                           'traffic': traffic, 'traffic_source': traffic_src, 'launches': r['launches'], 'launches_total': r['calls'], 'avg_launch_ms': r['ms'] / max(r['launches'], 1),
-                           'algorithmic_tflop_per_launch': r['flops'] / max(r['launches'], 1) / 1e12}
-    if timer_gn is not None:
-        r = timer_gn.result()
-        ach = r['flops'] / (r['ms'] * 1e-3) / 1e9 if r['ms'] > 0 else 0.0
-        gn_traffic, gn_src = None, None
-        gpmc = os.path.join(ROOT, 'profiles', 'r02_gn_pmc.json')
-        if os.path.isfile(gpmc):      # same convention as the conv entry: PMC passes over the kernel micro-benchmark's GroupNorm shapes
-            gn_traffic, gn_src = json.load(open(gpmc)).get('avg_hbm_side_bytes_fwd_per_launch'), 'profiles/r02_gn_pmc.json (micro-benchmark of the SD1.5 GroupNorm shapes, batch 16; stats + apply kernels of one call)'
-        out['roofline_gn'] = {'bound': 'hbm', 'kernel': 'GroupNorm(32)+SiLU forward (gn_stats_kernel + gn_apply_kernel, one entry point)',
-                              'achieved': ach, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': ach / PEAK_HBM_GBS, 'traffic': gn_traffic, 'traffic_source': gn_src,
-                              'isolated': (lambda q: {'achieved': q['flops'] / (q['ms'] * 1e-3) / 1e9, 'frac': q['flops'] / (q['ms'] * 1e-3) / 1e9 / PEAK_HBM_GBS,
-                                                      'avg_launch_ms': q['ms'] / max(q['launches'], 1)})(iso['gn']) if 'gn' in iso else None,
-                              'launches': r['launches'], 'launches_total': r['calls'], 'avg_launch_ms': r['ms'] / max(r['launches'], 1),
-                              'algorithmic_bytes_per_launch': r['flops'] / max(r['launches'], 1)}
-    if timer_attn is not None:
-        r = timer_attn.result()
-        ach = r['flops'] / (r['ms'] * 1e-3) / 1e12 if r['ms'] > 0 else 0.0
-        out['roofline_attn'] = {'bound': 'mfma', 'kernel': 'flash attention forward, self + cross (attn_q_kernel<*,*,0,*>)', 'achieved': ach,
-                                'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / PEAK_BF16_TFLOPS, 'traffic': None,
-                                'isolated': (lambda q: {'achieved': q['flops'] / (q['ms'] * 1e-3) / 1e12, 'frac': q['flops'] / (q['ms'] * 1e-3) / 1e12 / PEAK_BF16_TFLOPS,
-                                                        'avg_launch_ms': q['ms'] / max(q['launches'], 1)})(iso['attn']) if 'attn' in iso else None,
-                                'launches': r['launches'], 'launches_total': r['calls'], 'avg_launch_ms': r['ms'] / max(r['launches'], 1),
-                                'algorithmic_tflop_per_launch': r['flops'] / max(r['launches'], 1) / 1e12}
+        # entry point on the SAME layer shapes, collected with the kernel micro-benchmark (tools/bench_kernels.py, batch 16) -- not
+        # inside this timed step (PMC passes serialise kernels); the committed summaries say so themselves
+        for key, names, field in (('conv', ('r03_conv_pmc.json', 'r02_conv_pmc.json'), 'avg_hbm_side_bytes_per_launch'),
+                                  ('gn', ('r03_gn_pmc.json', 'r02_gn_pmc.json'), 'avg_hbm_side_bytes_fwd_per_launch'),
+                                  ('gemm', ('r03_gemm_pmc.json',), 'avg_hbm_side_bytes_per_launch')):
+            for name in names:
+                pmc = os.path.join(ROOT, 'profiles', name)
+                if os.path.isfile(pmc):
+                    objs[key]['traffic'] = json.load(open(pmc)).get(field)
+                    objs[key]['traffic_source'] = f'profiles/{name} (micro-benchmark of the step\'s shapes, batch 16)'
+                    break
+        # `roofline` = the family that takes the largest share of the step (dense GEMM since round 2's conv work; the MFMA
+        # families are compared by est_ms_per_step); every family keeps its own object
+        mfma = ['conv', 'gemm', 'attn_bwd', 'attn', 'wgrad', 'conv_wgrad']
+        dominant = max(mfma, key=lambda k: objs[k]['est_ms_per_step'])
+        out['roofline'] = dict(objs[dominant], family=dominant, why='largest est_ms_per_step of the MFMA kernel families in the timed region')
+        for k in timers:
+            out['roofline_' + k] = objs[k]
     if not args.no_cpu_baseline and world == 1:
         # torch's CPU backend degrades badly when oversubscribed on many-core hosts (256 threads: 160 s per forward);
         # 32 threads is the measured sweet spot class for one fp32 conv-heavy forward -> cores = threads actually used

@@ -93,10 +93,19 @@ class FusedAdamEMA:
                             ops._p(self.ema) if use_ema else None, ops._p(self.w16), self.hyper.data_ptr(), self.flat.numel(),
                             1 if zero_grad else 0, ops._s())
 
-    @torch.no_grad()
-    def step(self, ema_beta=None, zero_grad=True):
+    def begin_step(self, ema_beta=None):
+        """Host half of a step: advance the step counter and put the step's scalars (bias corrections, EMA beta, 1/world) in
+        device memory.  step() does this itself unless `external_scalars` is set -- the captured HIP graph of the training
+        step (SiDStep.iteration_graphed) contains only launch(), and its owner calls begin_step() before every replay."""
         self.step_count += 1
         self.set_hyper(0.0 if ema_beta is None else ema_beta)
+
+    external_scalars = False
+
+    @torch.no_grad()
+    def step(self, ema_beta=None, zero_grad=True):
+        if not self.external_scalars:
+            self.begin_step(ema_beta)
         self.launch(use_ema=ema_beta is not None and self.ema is not None, zero_grad=zero_grad)
 
     def state_dict(self):

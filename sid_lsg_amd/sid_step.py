@@ -32,6 +32,9 @@ class SiDStep:
         self.ls, self.lsg, self.bgt = float(loss_scaling), float(loss_scaling_G), int(batch_gpu_total)
         self.init_timestep = int(init_timestep)
         self.reducer, self.world = reducer, world_size
+        # gradients are exchanged when there is more than one rank -- or when the reducer was built to run its collectives
+        # on a single rank too (FlatGradReducer(min_world=1): how the RCCL path is exercised on a one-GPU box)
+        self.exchange = reducer is not None and (world_size > 1 or getattr(reducer, 'min_world', 2) <= 1)
         self.overlap_g = os.environ.get('SIDLSG_OVERLAP_G', '1') != '0'    # A/B switch; results are identical either way
         # Phase B evaluates the teacher and the fake-score network on the SAME noisy CFG batch (identical layer shapes): the
         # teacher runs on a second HIP stream (forward, and through autograd its data-gradient backward), so the two
@@ -39,6 +42,7 @@ class SiDStep:
         self.side = None
         if os.environ.get('SIDLSG_TEACHER_STREAM', '1') != '0' and torch.cuda.is_available():     # A/B switch (+2 % images/s on MI355X)
             self.side = ops.side_stream(G.flat_params.device)
+        self._graphs, self._graph_warm = {}, False
         opt_fake.grad_scale = opt_G.grad_scale = 1.0 / world_size     # DDP mean, folded into the optimizer kernel
         opt_fake.attach(ema=None, w16=fake_score.flat_w16)
         opt_G.attach(ema=(G_ema.flat_params if (G_ema is not None and G_ema is not G) else None), w16=G.flat_w16)
@@ -109,7 +113,7 @@ class SiDStep:
         self.G.requires_grad_(True)                                                 # :468
         self.psi.requires_grad_(False)
         loss = None
-        overlap = self.reducer is not None and self.world > 1 and self.overlap_g
+        overlap = self.exchange and self.overlap_g
         segs = self.G.grad_segments() if overlap else None
         for i, r in enumerate(rounds):
             if overlap and i == len(rounds) - 1:
@@ -126,7 +130,7 @@ class SiDStep:
 
     # ---- optimizer + data-parallel exchange ------------------------------------------------------
     def _optimizer_step(self, net, opt, ema_beta, started=False):
-        if self.reducer is not None and self.world > 1:
+        if self.exchange:
             if not started:
                 self.reducer.start(net.flat_grads)  # few large all-reduce(SUM) on the comm stream
             self.reducer.wait()
@@ -140,7 +144,7 @@ class SiDStep:
         after phase A's backward and only WAITED for right before psi is evaluated in phase B, i.e. they overlap with
         the generator forward and the teacher forward of the first phase-B round."""
         lf = self.fake_backward(inputs['A'])
-        overlap = self.reducer is not None and self.world > 1
+        overlap = self.exchange
         if overlap:
             self.reducer.start(self.psi.flat_grads)
 
@@ -148,3 +152,53 @@ class SiDStep:
             self._optimizer_step(self.psi, self.opt_fake, ema_beta=None, started=overlap)
         lg = self.generator_update(inputs['B'], ema_beta=ema_beta, before_fake_eval=finish_fake)
         return lf, lg
+
+    # ---- the same iteration as ONE HIP graph ---------------------------------------------------------------------------
+    @staticmethod
+    def _signature(inputs, ema_beta):
+        return (tuple((ph, tuple(tuple((k, tuple(v.shape), str(v.dtype)) for k, v in sorted(r.items()) if v is not None) for r in inputs[ph]))
+                      for ph in ('A', 'B')), ema_beta is None)
+
+    def iteration_graphed(self, inputs, ema_beta=None):
+        """iteration() replayed from a captured HIP graph: the ~6500 launches of one iteration (all three streams, both
+        optimizer kernels, for world > 1 the RCCL all-reduces on the communication stream) become one hipGraphLaunch, so the
+        host cost of an iteration is the input copies + two scalar uploads instead of ~140 ms of Python enqueueing.
+        The C ABI is allocation- and sync-free (include/sidlsg_hip.h), torch's allocations inside the capture come from the
+        graph's private pool, and everything that varies between iterations lives in device memory: the inputs (copied
+        into static buffers) and the optimizers' scalars (FusedAdamEMA.begin_step).
+        Call protocol: the first call runs eagerly (lazy initialisations: workspaces, hipBLASLt handles of torch ops); the
+        second call with a given input signature captures and replays; later calls replay.  Returns (loss_fake, loss_G) as
+        STATIC device scalars that the next replay overwrites -- read them before the next call.
+        Requires the fused optimizers (mode 1); a foreign optimizer / DDP wrapper (mode 2) has host logic per step."""
+        if not self._graph_warm:
+            self._graph_warm = True
+            return self.iteration(inputs, ema_beta=ema_beta)
+        sig = self._signature(inputs, ema_beta)
+        g = self._graphs.get(sig)
+        if g is None:
+            static = {ph: [{k: (v.clone() if v is not None else None) for k, v in r.items()} for r in inputs[ph]] for ph in ('A', 'B')}
+            self.opt_fake.begin_step(None)
+            self.opt_G.begin_step(ema_beta)
+            self.opt_fake.external_scalars = self.opt_G.external_scalars = True
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            # with a process group alive its watchdog thread polls events (hipEventQuery) at any time: under the default
+            # 'global' capture mode that call, made by ANOTHER thread, aborts the process ("operation not permitted when
+            # stream is capturing"); 'thread_local' confines the check to this thread.  Single-process runs keep 'global'.
+            dist_on = torch.distributed.is_available() and torch.distributed.is_initialized()
+            try:
+                with torch.cuda.graph(graph, capture_error_mode='thread_local' if dist_on else 'global'):
+                    lf, lg = self.iteration(static, ema_beta=ema_beta)
+            finally:
+                self.opt_fake.external_scalars = self.opt_G.external_scalars = False
+            g = self._graphs[sig] = dict(graph=graph, static=static, out=(lf, lg))
+        else:
+            for ph in ('A', 'B'):
+                for dst, src in zip(g['static'][ph], inputs[ph]):
+                    for k, v in src.items():
+                        if v is not None:
+                            dst[k].copy_(v, non_blocking=True)
+            self.opt_fake.begin_step(None)
+            self.opt_G.begin_step(ema_beta)
+        g['graph'].replay()
+        return g['out']

@@ -141,5 +141,30 @@ def run_nccl(out):
     torch.distributed.destroy_process_group()
 
 
+def run_graph(out):
+    """The gradient exchange INSIDE the captured iteration: FlatGradReducer(min_world=1) on backend 'nccl', so RCCL's
+    all-reduce kernels are captured on the communication stream (psi exchange overlapped with the generator forward,
+    segment-wise G exchange from the backward markers) and replayed."""
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    from sid_lsg_amd.distributed import FlatGradReducer
+    torch.cuda.set_device(0)
+    dev = torch.device('cuda', 0)
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    torch.distributed.init_process_group('nccl', device_id=dev)
+    from sid_lsg_amd._lib import lib
+    lib.load()
+    from test_gpu_unet import _graph_vs_eager
+    # warm RCCL up outside any capture (communicator creation is lazy)
+    w = torch.ones(8, device=dev)
+    torch.distributed.all_reduce(w)
+    torch.cuda.synchronize()
+    results, lr, iters = _graph_vs_eager(dev, reducer_factory=lambda: FlatGradReducer(min_world=1))
+    a, g = results['eager'], results['graph']
+    np.savez(f'{out}.rank0.npz', eager=a['losses'], graph=g['losses'], dG=float((a['G'] - g['G']).abs().max()),
+             dpsi=float((a['psi'] - g['psi']).abs().max()), lr=lr, iters=iters, ngraphs=g['ngraphs'])
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
 if __name__ == '__main__':
-    {'ddp': run_ddp, 'nccl': run_nccl}[sys.argv[1]](sys.argv[2])
+    {'ddp': run_ddp, 'nccl': run_nccl, 'graph': run_graph}[sys.argv[1]](sys.argv[2])

@@ -96,3 +96,17 @@ def test_rccl_two_ranks_sharing_one_gpu(dev, tmp_path):
     lines = [ln for ln in text.splitlines() if any(k in ln for k in known)][:6]
     print('RCCL refused two ranks on one device:\n' + '\n'.join(lines))
     assert hit, 'unexpected failure (not an RCCL refusal):\n' + text[-3000:]
+
+
+def test_rccl_collectives_inside_the_captured_iteration(dev, tmp_path):
+    """The HIP-graphed iteration with the gradient exchange in it: RCCL all-reduces (world 1, forced) are captured on the
+    communication stream together with the compute / teacher / weight-gradient streams and replayed; losses and weights
+    must equal the eager run's."""
+    out = str(tmp_path / 'graph')
+    res = launch(1, 'graph', out)
+    assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
+    r = np.load(f'{out}.rank0.npz')
+    rel = np.abs(r['eager'] - r['graph']) / np.abs(r['eager'])
+    print(f"eager {r['eager']} graph {r['graph']} max weight difference G {float(r['dG']):.2e} psi {float(r['dpsi']):.2e}")
+    assert int(r['ngraphs']) == 1 and rel.max() < 2e-4
+    assert max(float(r['dG']), float(r['dpsi'])) <= 2.01 * float(r['lr']) * int(r['iters'])

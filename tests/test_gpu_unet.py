@@ -751,3 +751,60 @@ def test_side_streams_change_nothing_in_the_step(dev):
         frac_same = float((d < 1e-9).float().mean())
         print(f'{k}: {frac_same:.5f} of the weights bit-equal, max difference {float(d.max()):.2e} (lr {lr})')
         assert float(d.max()) <= 2.01 * lr * iters and frac_same > 0.98
+
+
+def _graph_vs_eager(dev, reducer_factory=None, iters=4):
+    """Runs `iters` iterations twice from identical initial state and inputs: eagerly and through SiDStep.iteration_graphed
+    (first call eager, second captures + replays, later ones replay).  Returns the two result dicts."""
+    from sid_lsg_amd.optim import FusedAdamEMA
+    from sid_lsg_amd.scheduler import DDPMScheduler
+    from sid_lsg_amd.sid_step import SiDStep
+    from sid_lsg_amd.unet import CONFIGS, HipUNet2DCondition
+    cfg_name, lat, b, lr = 'tiny40', 16, 2, 2e-5
+    cfg = CONFIGS[cfg_name]
+    results = {}
+    for mode in ('eager', 'graph'):
+        phi = HipUNet2DCondition(cfg).materialize(dev, seed=1)
+        psi = HipUNet2DCondition(cfg).materialize(dev, seed=2)
+        G, G_ema = phi.clone_network(), phi.clone_network(with_grad_buffers=False)
+        opt_f = FusedAdamEMA(psi.parameters(), lr=lr, betas=(0.0, 0.999), eps=1e-8)
+        opt_g = FusedAdamEMA(G.parameters(), lr=lr, betas=(0.0, 0.999), eps=1e-8)
+        red = reducer_factory() if reducer_factory is not None else None
+        step = SiDStep(G, psi, phi, G_ema, DDPMScheduler().to(dev), opt_f, opt_g, alpha=1.0, cfg_train_fake=1.5, cfg_eval_fake=1.5,
+                       cfg_eval_real=1.5, batch_gpu_total=2 * b, init_timestep=625, reducer=red, world_size=1)
+        gen = torch.Generator().manual_seed(3)
+        losses = []
+        for it in range(iters):
+            inputs = {ph: [dict(z=torch.randn(b, 4, lat, lat, generator=gen).to(dev), noise=torch.randn(b, 4, lat, lat, generator=gen).to(dev),
+                                t=torch.randint(20, 980, (b,), generator=gen).to(dev),
+                                cond=torch.randn(b, cfg.text_len, cfg.cross_attention_dim, generator=gen).to(dev).to(BF16),
+                                uncond=torch.randn(b, cfg.text_len, cfg.cross_attention_dim, generator=gen).to(dev).to(BF16))
+                               for _ in range(2)] for ph in ('A', 'B')}                      # two accumulation rounds
+            beta = 0.5 + 0.1 * it                                                            # a scalar that changes every iteration
+            lf, lg = (step.iteration if mode == 'eager' else step.iteration_graphed)(inputs, ema_beta=beta)
+            losses += [float(lf), float(lg)]
+        torch.cuda.synchronize()
+        results[mode] = dict(losses=np.array(losses), G=G.flat_params.clone(), psi=psi.flat_params.clone(), ema=G_ema.flat_params.clone(),
+                             steps=(opt_f.step_count, opt_g.step_count), ngraphs=len(step._graphs))
+    return results, lr, iters
+
+
+def _assert_graph_equals_eager(results, lr, iters):
+    a, g = results['eager'], results['graph']
+    assert g['ngraphs'] == 1 and a['ngraphs'] == 0
+    assert a['steps'] == g['steps'] == (iters, iters)
+    rel = np.abs(a['losses'] - g['losses']) / np.abs(a['losses'])
+    print(f'losses eager {a["losses"]} graph {g["losses"]} rel {rel}')
+    assert rel.max() < 2e-4
+    for k in ('G', 'psi', 'ema'):
+        d = (a[k] - g[k]).abs()
+        same = float((d < 1e-9).float().mean())
+        print(f'{k}: {same:.5f} of the weights bit-equal, max difference {float(d.max()):.2e} (lr {lr})')
+        # identical kernels on identical data; what differs is the fp32-atomics ordering noise (a ~0 gradient flipping sign = 2 lr)
+        assert float(d.max()) <= 2.01 * lr * iters and same > 0.98
+
+
+def test_graphed_iteration_equals_eager(dev):
+    """SiDStep.iteration_graphed: one HIP graph per iteration (three streams, autograd backward, both fused optimizer
+    kernels, EMA) against the eager iteration: same losses and weights over 4 iterations with changing inputs and EMA beta."""
+    _assert_graph_equals_eager(*_graph_vs_eager(dev))
