@@ -1044,6 +1044,270 @@ static int launch_gemm_v3(const GemmParams& p, hipStream_t s) {
     return sidlsg_last_error();
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// "A-stationary" dense GEMM for the wide short-contraction products of the 64 x 64 stage (K = 320, N >= 2560: the FF-in
+// projection).  The shape is memory bound (65536 x 2560 x 320: 42 MB in, 335 MB out, 107 GFLOP = 63 us of HBM time against
+// 43 us of MFMA time) and ran at a third of either bound in gemm_v3_kernel: with 5 K-tiles per output tile a block spends as
+// long in its prologue (first tile DMA: nothing to overlap it), epilogue and store drain as in the K loop, and every K-tile
+// waits a full L2 -> LDS round trip because only one tile is in flight.
+// Here a block keeps its 128 x 320 panel of A in LDS for its whole life (80 KiB, loaded once) and walks over the 160-wide
+// column tiles of its range; the W tiles stream through a 3-slot ring as ONE continuous sequence of 160 x 64 chunks -- the
+// DMA of chunk s+3 is issued when chunk s has been read, so two chunks are always in flight and no tile restarts the
+// pipeline -- the epilogue's loads (bias, residual) are issued at the tile's first chunk, and its stores drain behind the
+// next tile's MFMAs.  That needs counted waits, which works because EVERY vector-memory operation of the loop is a buffer
+// operation that is always issued (out-of-range lanes carry the OOB offset instead of being predicated off): the
+// s_waitcnt vmcnt(N) immediates below count them exactly.  One block of 4 waves per CU (LDS: 80 + 60 + 10 KiB).
+// Output tile -> global memory through a per-wave 16 x 80 LDS transposition buffer (row-major 160-byte runs; the MFMA
+// layout's 64-byte half lines are taken at half rate by the L2, see gemm_store_rows).
+// Measured (MI355X, in-session A/B against gemm_v3_kernel): 65536 x 2560 x 320 220 -> 157 us, 32768 x 2560 x 320 86 -> 77 us;
+// N = 1280 / 960 tie and N = 320 loses (two tiles do not amortise the panel load with one block per CU) -> dispatched from
+// N = 2560.  Variants measured slower and not kept: 8 waves with 32 x 80 wave tiles (1.55x the LDS fragment traffic per MFMA:
+// 172 us), and the write-out software-pipelined into the next tile's chunks (its LDS round trips stall the MFMA stream: 185 us).
+// Requires K == 64 * NKT, N % 160 == 0, bf16 output, no row vector / activation / fp32 / accumulate flags.
+struct AsLoads {          // epilogue operands of one tile, fetched at its first chunk
+    f32x4 b[5];
+    bf16x8 r[4][3];
+};
+template <int NKT, bool RES>
+__global__ __launch_bounds__(NTHREADS, 1) void gemm_as_kernel(GemmParams p) {
+    constexpr int BM = 128, BN = 160, MT = 4, NT = 5, R = 3;
+    constexpr int ACH = BM * BK, WST = BN * BK, LDT = 80;
+    constexpr int NLD = 5 + (RES ? 12 : 0);     // buffer loads of AsLoads per wave
+    constexpr int NST = 12;                      // buffer stores of one tile's epilogue per wave
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    bf16* Ap = reinterpret_cast<bf16*>(smem);    // [NKT][128][64]
+    bf16* Wr = Ap + NKT * ACH;                   // [R][160][64]
+    bf16* Tb = Wr + R * WST;                     // [4 waves][16][LDT]
+    const int tiles_n = p.N / BN;
+    const int tpi = p.group_m;                   // column tiles per work item
+    const int items_per_panel = (tiles_n + tpi - 1) / tpi;
+    int bid = blockIdx.x;
+    {
+        const int nblk = gridDim.x;
+        const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int mt = bid / items_per_panel, it = bid - mt * items_per_panel;
+    const int m0 = mt * BM;
+    const int nt0 = it * tpi, ntl = min(tpi, tiles_n - nt0);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 80;
+    const int li = lane & 15, lg = lane >> 4;
+    const int lrow = lane >> 3, lslot = lane & 7;
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(p.A), 0, (int)p.a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(p.W), 0, (int)p.w_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.bias), 0, p.bias ? p.N * 4 : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(p.res), 0, 0x7FFFFFFF, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<bf16*>(p.C), 0, 0x7FFFFFFF, 0x00020000);
+
+    // ---- A panel: all NKT chunks at once (4 DMAs per wave and chunk)
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int r = wave * 32 + j * 8 + lrow;
+        const int kcs = lslot ^ ((r >> 1) & 7);
+        const int m = m0 + r;
+        const unsigned off = m < p.M ? ((unsigned)m * (unsigned)p.lda + kcs * 8) * 2u : OOB;
+#pragma unroll
+        for (int kc = 0; kc < NKT; kc++)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lptr_t)(Ap + kc * ACH + (wave * 32 + j * 8) * BK), 16, off, kc * BK * 2, 0, 0);
+    }
+    // ---- W stream: chunk s = (tile s / NKT of this item, K chunk s % NKT) -> ring slot s % R
+    unsigned boff[5];
+#pragma unroll
+    for (int j = 0; j < 5; j++) {
+        const int r = (wave + 4 * j) * 8 + lrow;
+        boff[j] = ((unsigned)r * (unsigned)p.K + (lslot ^ wsw(r)) * 8) * 2u;
+    }
+    const int S = ntl * NKT;
+    // (every lambda of this kernel is force-inlined: a closure left out of line drags the kernel arguments into scratch and
+    // the buffer descriptors into VGPRs -> waterfall loops around every buffer operation)
+    auto issue_w = [&](int s2) __attribute__((always_inline)) {   // always 5 DMAs; past the end of the item they fetch nothing (zeros into a dead slot)
+        const int t = s2 / NKT, kc = s2 - t * NKT;
+        const int slot = s2 % R;
+        const unsigned so = ((unsigned)((nt0 + t) * BN) * (unsigned)p.K + kc * BK) * 2u;
+        const bool live = s2 < S;
+#pragma unroll
+        for (int j = 0; j < 5; j++)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lptr_t)(Wr + slot * WST + (wave + 4 * j) * 8 * BK), 16, live ? boff[j] : OOB, live ? so : 0u, 0, 0);
+    };
+    issue_w(0); issue_w(1); issue_w(2);
+
+    f32x4 acc[NT][MT];
+    int wrow[NT];
+#pragma unroll
+    for (int ni = 0; ni < NT; ni++) {
+        const bool paired = (ni | 1) < NT;
+        wrow[ni] = wn0 + (paired ? 32 * (ni >> 1) + (li >> 2) * 8 + (ni & 1) * 4 + (li & 3) : 16 * ni + li);
+    }
+    auto read_frags = [&](int kc, int slot, int kk, bf16x8 (&fa)[MT], bf16x8 (&fw)[NT]) __attribute__((always_inline)) {
+        const bf16* a = Ap + kc * ACH;
+        const bf16* b = Wr + slot * WST;
+        const int ch = kk * 4 + lg;
+#pragma unroll
+        for (int mi = 0; mi < MT; mi++) {
+            const int r = wm0 + mi * 16 + li;
+            fa[mi] = *reinterpret_cast<const bf16x8*>(a + r * BK + ((ch ^ ((r >> 1) & 7)) << 3));
+        }
+#pragma unroll
+        for (int ni = 0; ni < NT; ni++) {
+            const int r = wrow[ni];
+            fw[ni] = *reinterpret_cast<const bf16x8*>(b + r * BK + ((ch ^ wsw(r)) << 3));
+        }
+    };
+    auto mfma_block = [&](const bf16x8 (&fa)[MT], const bf16x8 (&fw)[NT]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int ni = 0; ni < NT; ni++)
+#pragma unroll
+            for (int mi = 0; mi < MT; mi++)
+                acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[ni], fa[mi], acc[ni][mi], 0, 0, 0);
+    };
+    // epilogue operands of the tile whose first column is n0: 5 bias loads (+ 12 residual loads), always issued
+    auto tile_loads = [&](int n0, AsLoads& L) __attribute__((always_inline)) {
+        const int nb = n0 + wn0;
+        L.b[0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rb, (unsigned)(nb + lg * 8) * 4u, 0, 0));
+        L.b[1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rb, (unsigned)(nb + lg * 8 + 4) * 4u, 0, 0));
+        L.b[2] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rb, (unsigned)(nb + 32 + lg * 8) * 4u, 0, 0));
+        L.b[3] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rb, (unsigned)(nb + 32 + lg * 8 + 4) * 4u, 0, 0));
+        L.b[4] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rb, (unsigned)(nb + 64 + lg * 4) * 4u, 0, 0));
+        if (RES) {
+#pragma unroll
+            for (int mi = 0; mi < MT; mi++) {
+                const int m = m0 + wm0 + mi * 16 + li;
+                const bool ok = m < p.M;
+                const unsigned row = ok ? (unsigned)m * (unsigned)p.ldres : 0u;
+#pragma unroll
+                for (int pr = 0; pr < 3; pr++) {
+                    const int n = nb + 32 * pr + lg * (pr < 2 ? 8 : 4);
+                    const unsigned off = ok ? (row + (unsigned)n) * 2u : OOB;
+                    if (pr < 2) L.r[mi][pr] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rr, off, 0, 0));
+                    else {
+                        const u32x2 t = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rr, off, 0, 0));
+                        L.r[mi][pr] = __builtin_bit_cast(bf16x8, (u32x4){t[0], t[1], 0u, 0u});
+                    }
+                }
+            }
+        }
+    };
+    // acc -> bf16 tile -> global: per 16-row block through this wave's LDS buffer, 3 buffer stores (160-byte rows)
+    bf16* tb = Tb + wave * 16 * LDT;
+    auto epilogue = [&](int n0, const AsLoads& L) __attribute__((always_inline)) {
+#pragma unroll
+        for (int mi = 0; mi < MT; mi++) {
+#pragma unroll
+            for (int pr = 0; pr < 3; pr++) {
+                float v[8];
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    v[r] = acc[2 * pr][mi][r] * p.alpha + L.b[pr < 2 ? 2 * pr : 4][r];
+                    v[4 + r] = pr < 2 ? acc[pr < 2 ? 2 * pr + 1 : 0][mi][r] * p.alpha + L.b[pr < 2 ? 2 * pr + 1 : 0][r] : 0.f;
+                }
+                if (RES) {
+#pragma unroll
+                    for (int e = 0; e < (pr < 2 ? 8 : 4); e++) v[e] += bf2f(L.r[mi][pr][e]);
+                }
+                if (pr < 2) {
+                    bf16x8 o;
+#pragma unroll
+                    for (int e = 0; e < 8; e++) o[e] = f2bf(v[e]);
+                    st8(tb + li * LDT + 32 * pr + lg * 8, o);
+                } else {
+                    bf16x4 o = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
+                    *reinterpret_cast<bf16x4*>(tb + li * LDT + 64 + lg * 4) = o;
+                }
+            }
+            // wave-private buffer: the LDS counter orders the writes above before the reads below (and the reads before
+            // the next block's writes)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+                const int c = lane + 64 * j;                    // 16 rows x 10 chunks of 16 bytes
+                const int row = c / 10, col = (c - row * 10) * 8;
+                const int m = m0 + wm0 + mi * 16 + row;
+                const bool ok = c < 160 && m < p.M;
+                const bf16x8 val = *reinterpret_cast<const bf16x8*>(tb + (c < 160 ? row * LDT + col : 0));
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, val), rc,
+                                                       ok ? ((unsigned)m * (unsigned)p.ldc + (unsigned)(n0 + wn0 + col)) * 2u : OOB, 0, 0);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+#pragma unroll
+        for (int i = 0; i < NT; i++)
+#pragma unroll
+            for (int j = 0; j < MT; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    };
+
+#pragma unroll
+    for (int i = 0; i < NT; i++)
+#pragma unroll
+        for (int j = 0; j < MT; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    bf16x8 fa0[MT], fw0[NT], fa1[MT], fw1[NT];
+    // the A panel and chunk 0 have landed when at most chunks 1 and 2 (10 DMAs) are outstanding
+    asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    read_frags(0, 0, 0, fa0, fw0);
+
+    // One W chunk (step s = t * NKT + kc).  WAIT = number of vector-memory operations issued AFTER the DMAs of chunk s+1
+    // at the point of the wait: chunk s+1 has landed when no more than that many are outstanding.
+    auto step = [&](const int s, const int kc, auto wait_c) __attribute__((always_inline)) {
+        constexpr int WAIT = decltype(wait_c)::value;
+        const int slot = s % R;
+        read_frags(kc, slot, 1, fa1, fw1);
+        mfma_block(fa0, fw0);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WAIT) : "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        read_frags(kc + 1 == NKT ? 0 : kc + 1, (s + 1) % R, 0, fa0, fw0);     // chunk s+1 (a dead read after the last step)
+        issue_w(s + 3);                                                         // into the slot chunk s just vacated
+        mfma_block(fa1, fw1);
+    };
+    // Outstanding operations younger than chunk s+1's DMAs at the wait of step (t, kc) -- program order per tile:
+    //   [tile loads NLD] step 0 .. step NKT-1, each ending with 5 DMAs, [epilogue stores NST]
+    //   kc = 0: chunk s+2 (5, issued in the previous tile's last step) + previous epilogue's NST stores + this tile's NLD loads
+    //   kc = 1: previous stores + loads + chunk s+2 (5, issued in step 0)     kc >= 2: chunk s+2 only
+    // first tile of the item: no previous epilogue (kc = 0: chunk 2 + loads; kc = 1: loads + chunk 3)
+    using std::integral_constant;
+    AsLoads L;
+    auto tile = [&](const int t, auto first) __attribute__((always_inline)) {
+        constexpr bool FIRST = decltype(first)::value;
+        const int n0 = (nt0 + t) * BN;
+        tile_loads(n0, L);
+        const int s0 = t * NKT;
+        step(s0, 0, integral_constant<int, 5 + NLD + (FIRST ? 0 : NST)>{});
+        if constexpr (NKT > 1) step(s0 + 1, 1, integral_constant<int, 5 + NLD + (FIRST ? 0 : NST)>{});
+#pragma unroll
+        for (int kc = 2; kc < NKT; kc++) step(s0 + kc, kc, integral_constant<int, 5>{});
+        epilogue(n0, L);
+    };
+    tile(0, std::true_type{});
+    for (int t = 1; t < ntl; t++) tile(t, std::false_type{});
+}
+
+template <int NKT>
+static int launch_gemm_as(const GemmParams& p, hipStream_t s) {
+    constexpr size_t lds = (size_t)(NKT * 128 * BK + 3 * 160 * BK + 4 * 16 * 80) * sizeof(bf16);
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_as_kernel<NKT, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_as_kernel<NKT, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_done = true;
+    }
+    const int panels = (p.M + 127) / 128, tiles_n = p.N / 160;
+    // work item = (panel, range of column tiles): whole panels when they fill the chip, else split the column range so that
+    // ~512 items exist (an item re-loads its A panel: keep ranges >= 2 tiles when N allows)
+    int tpi = tiles_n;
+    while (tpi > 2 && (long long)panels * ((tiles_n + tpi - 1) / tpi) < 512) tpi = (tpi + 1) / 2;
+    GemmParams q = p;
+    q.group_m = tpi;
+    const int items = panels * ((tiles_n + tpi - 1) / tpi);
+    if (p.res) hipLaunchKernelGGL((gemm_as_kernel<NKT, true>), dim3(items), dim3(NTHREADS), lds, s, q);
+    else hipLaunchKernelGGL((gemm_as_kernel<NKT, false>), dim3(items), dim3(NTHREADS), lds, s, q);
+    return sidlsg_last_error();
+}
+
 template <int BM, int BN, int MODE>
 static int launch_gemm(const GemmParams& p, hipStream_t s) {
     const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
@@ -1071,6 +1335,13 @@ static int dispatch_gemm(const GemmParams& p, hipStream_t s) {
     // -> 64-wide.  Small pixel counts (8x8 / 16x16 stages, small batches) would give < 256 tiles = idle CUs: split K when
     // the contraction is long, else fall back to 64-row and then 64x64 tiles until the grid covers the chip.
     if (p.N <= 64) return launch_gemm<128, 64, MODE>(p, s);
+    if constexpr (MODE == 0) {
+        static const bool as_on = !(getenv("SIDLSG_GEMM_AS") && atoi(getenv("SIDLSG_GEMM_AS")) == 0);   // A/B switch
+        static const int as_min_n = getenv("SIDLSG_GEMM_AS_MIN_N") ? atoi(getenv("SIDLSG_GEMM_AS_MIN_N")) : 2560;   // measured break-even
+        if (as_on && p.K == 320 && p.N % 160 == 0 && p.N >= as_min_n && p.M >= 8192 && !p.rowvec && !p.flags && !p.kt_per_split && (p.ldc & 7) == 0 &&
+            (!p.res || (p.ldres & 7) == 0) && (long long)p.M * p.ldc < (1ll << 30) && (!p.res || (long long)p.M * p.ldres < (1ll << 30)))
+            return launch_gemm_as<5>(p, s);
+    }
     auto tiles = [&](int bm, int bn) { return (long long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn); };
     const bool n160 = p.N % 160 == 0;
     static const bool v3_on = !(getenv("SIDLSG_GEMM_V3") && atoi(getenv("SIDLSG_GEMM_V3")) == 0);   // A/B switch

@@ -6,6 +6,8 @@ Tolerances (stated per SURVEY.md section 8 / the task's floating-point rule): op
     intermediate activations where a kernel chain is involved)
   * bf16 outputs:                                |err| <= 1.2e-2 * max|ref|  (one bf16 rounding = 2^-8 rel)
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -57,6 +59,20 @@ def test_gemm(dev, M, N, K):
     full = ref + bias + res.float() + rv.repeat_interleave(rpb, 0)
     got = ops.gemm(a.to(dev), w.to(dev), bias=bias.to(dev), res=res.to(dev), rowvec=rv.to(dev), rows_per_batch=rpb, out_f32=True)
     close(got, full, 2e-3, 'epilogue')
+
+
+def test_gemm_short_k_a_stationary(dev):
+    """K = 320 with N % 160 == 0 and M >= 8192 can take the A-stationary kernel (gemm_as_kernel: A panel resident in LDS, W tiles
+    streamed as one continuous chunk sequence, counted vmcnt waits).  Production dispatches it from N = 2560 (the measured
+    break-even); tests/gemm_as_check.py runs in a fresh process with SIDLSG_GEMM_AS_MIN_N=160 so that every shape class goes
+    through it: plain, + bias, + bias + residual, alpha, strided A / C, ragged last panel, against the fp32 product."""
+    import subprocess
+    import sys
+    env = dict(os.environ, SIDLSG_GEMM_AS_MIN_N='160')
+    res = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'gemm_as_check.py')], env=env,
+                         capture_output=True, text=True, timeout=600)
+    print(res.stdout[-2000:])
+    assert res.returncode == 0 and 'all shapes ok' in res.stdout, res.stdout[-2000:] + res.stderr[-3000:]
 
 
 CONV_CASES = [(2, 16, 16, 64, 160, 1, 0), (2, 16, 16, 64, 128, 2, 0), (1, 8, 8, 128, 64, 1, 1), (2, 12, 20, 8, 320, 1, 0),
