@@ -712,7 +712,7 @@ __global__ void gemm_finish_kernel(GemmParams p, int nsp) {      // nsp: number 
 struct WsSlot { hipStream_t stream; float* ptr; long long bytes; };
 static float* g_ws_default = nullptr;
 static long long g_ws_default_bytes = 0;
-static WsSlot g_ws_slots[4] = {};
+static WsSlot g_ws_slots[8] = {};
 static int g_ws_nslots = 0;
 struct Ws { float* ptr; long long bytes; };
 static Ws ws_for(hipStream_t s) {
@@ -1964,7 +1964,7 @@ int sidlsg_set_stream_workspace(void* stream, void* ptr, long long bytes) {
             return SIDLSG_OK;
         }
     if (!ptr) return SIDLSG_OK;
-    if (g_ws_nslots >= 4) return SIDLSG_EINVAL;
+    if (g_ws_nslots >= 8) return SIDLSG_EINVAL;
     g_ws_slots[g_ws_nslots++] = {s, (float*)ptr, bytes};
     return SIDLSG_OK;
 }

@@ -113,22 +113,37 @@ def side_stream(device):
 # the main stream (plus, through grad_streams(), the gradient-exchange stream) waits for the side stream at the end of the
 # backward pass (autograd engine callback), i.e. before anything may read .grad.  SIDLSG_WGRAD_STREAM=0 turns it off.
 _WGRAD_SIDE = os.environ.get('SIDLSG_WGRAD_STREAM', '1') != '0'
+# SIDLSG_WGRAD_STREAMS = n > 1: weight-gradient launches rotate over n streams, so that n of them can share the chip (with
+# SIDLSG_WGRAD_SLOTS = 512 / n each launch splits its pixel range for 1 / n of the chip: fewer, longer blocks and 1 / n of the
+# partial-sum slab traffic per layer).  A/B knob; default 1.
+_WGRAD_NSTREAMS = max(1, int(os.environ.get('SIDLSG_WGRAD_STREAMS', '1')))
 _wgrad_streams = {}
+_wgrad_rr = {}
 _wgrad_join_armed = set()
 
 
-def wgrad_stream(device):
+def _wgrad_stream_list(device):
     key = _dev_key(device)
     if key not in _wgrad_streams:
-        _wgrad_streams[key] = torch.cuda.Stream(device=device)
-        ensure_stream_workspace(_wgrad_streams[key])
+        lst = [torch.cuda.Stream(device=device) for _ in range(_WGRAD_NSTREAMS)]
+        for st in lst:
+            ensure_stream_workspace(st, nbytes=(256 << 20) // _WGRAD_NSTREAMS if _WGRAD_NSTREAMS > 1 else 256 << 20)
+        _wgrad_streams[key] = lst
     return _wgrad_streams[key]
+
+
+def wgrad_stream(device):
+    """The stream of the next weight-gradient launch (round robin when several are configured)."""
+    lst = _wgrad_stream_list(device)
+    key = _dev_key(device)
+    i = _wgrad_rr.get(key, 0)
+    _wgrad_rr[key] = (i + 1) % len(lst)
+    return lst[i]
 
 
 def grad_streams(device):
     """Side streams that may still be writing parameter gradients of `device` (a gradient exchange must wait for them)."""
-    key = _dev_key(device)
-    return [_wgrad_streams[key]] if key in _wgrad_streams else []
+    return list(_wgrad_streams.get(_dev_key(device), ()))
 
 
 class _OnWgradStream:
@@ -158,11 +173,12 @@ class _OnWgradStream:
         # must not leave the next one un-joined)
         key = (_dev_key(self.tensors[0].device), torch._C._current_graph_task_id())
         if key not in _wgrad_join_armed:
-            side, dev = self.side, self.tensors[0].device
+            dev = self.tensors[0].device
 
             def join():
                 _wgrad_join_armed.discard(key)
-                torch.cuda.current_stream(dev).wait_stream(side)
+                for side in grad_streams(dev):
+                    torch.cuda.current_stream(dev).wait_stream(side)
             if key[1] < 0:                       # not inside a backward pass: join right away
                 join()
             else:

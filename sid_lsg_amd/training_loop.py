@@ -97,7 +97,7 @@ def training_loop(
     pretrained_vae_model_name_or_path='runwayml/stable-diffusion-v1-5', fake_score_use_lora=False,
     dataset_prompt_text_kwargs={}, cfg_train_fake=1, cfg_eval_fake=1, cfg_eval_real=1, num_steps=1, train_mode=True,
     network_pkl=None, enable_xformers=True, gradient_checkpointing=False, resolution=512, on_iteration=None,
-    rng_device=None,
+    rng_device=None, metric_real_stats=None, metric_num_test=None,
 ):
     if not train_mode:
         raise NotImplementedError('evaluation mode (FID/CLIP metrics) is outside the hot-path scope (SURVEY.md section 8(f))')
@@ -234,6 +234,23 @@ def training_loop(
         if snapshot_ticks is not None and (done or cur_tick % snapshot_ticks == 0 or cur_tick in SNAPSHOT_EXTRA_TICKS) and rank == 0 and run_dir:
             with open(os.path.join(run_dir, f'network-snapshot-{alpha:03f}-{cur_nimg // 1000:06d}.pkl'), 'wb') as f:
                 pickle.dump(dict(ema=G_ema), f)
+        # metrics at the snapshot cadence (sid_training_loop.py:616-639): the EMA generator through the one-step sampler + VAE
+        if metrics and snapshot_ticks is not None and (done or cur_tick % snapshot_ticks == 0 or cur_tick in SNAPSHOT_EXTRA_TICKS):
+            from functools import partial
+
+            from . import metrics as metric_main
+            from .sd_util import sid_sd_sampler
+            G_eval = partial(sid_sd_sampler, unet=G_ema, noise_scheduler=noise_scheduler, text_encoder=text_encoder, tokenizer=tokenizer,
+                             resolution=resolution, dtype=torch.float32, return_images=True, vae=vae, train_sampler=False)
+            for metric in metrics:
+                extra = dict(num_test=metric_num_test) if metric_num_test is not None else {}
+                result = metric_main.calc_metric(metric, G=G_eval, prompts=getattr(dataset_obj, 'prompt_list', None) or [dataset_obj[i][1] for i in range(len(dataset_obj))], resolution=resolution,
+                                                 init_timestep=init_timestep, detector=metric_pt_path, real_stats=metric_real_stats,
+                                                 open_clip_detector=metric_open_clip_path, device=device, **extra)
+                metric_main.report_metric(result, run_dir=run_dir, alpha=alpha,
+                                          snapshot_pkl=os.path.join(run_dir, f'network-snapshot-{alpha:03f}-{cur_nimg // 1000:06d}.pkl') if run_dir else None)
+                for k, v in result.results.items():
+                    stats.report(f'Metrics/{k}', v)
         if state_dump_ticks is not None and (done or cur_tick % state_dump_ticks == 0) and cur_tick != 0 and rank == 0 and run_dir:
             torch.save(dict(fake_score=fake_score.state_dict(), G=G.state_dict(), G_ema=G_ema.state_dict(),
                             fake_score_optimizer_state=opt_f.state_dict(), g_optimizer_state=opt_g.state_dict()),

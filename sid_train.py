@@ -12,7 +12,8 @@ Differences (documented, not silent):
   * `--sd_model` must be a local diffusers-layout directory or `random:<arch>` (no network in this environment);
   * `--fp16` only selects the optimizer eps; masters are fp32 and compute is bf16 MFMA, or -- with the added option
     `--precision fp32` -- the fp32-accurate mode (the reference's own default precision, ~20x slower);
-  * `--metrics` other than none / `--train_mode 0` raise: FID/CLIP evaluation is outside the hot-path scope;
+  * `--metrics` run through sid_lsg_amd/metrics.py at the snapshot ticks and need LOCAL detector / statistics files
+    (--metric_pt_path, --data_stat); `--train_mode 0` raises;
   * `--data` is optional (it is the COCO image set used only by the metrics).
 """
 import json
@@ -96,10 +97,20 @@ def build_config(o):
     """Options -> training_loop kwargs (the reference's `c`, sid_train.py:196-330)."""
     c = EasyDict()
     if o.metrics is not None:
-        raise click.ClickException('--metrics: FID / CLIP evaluation is not part of this build (SURVEY.md section 8(f))')
+        # FID / CLIP scores at the snapshot ticks (sid_lsg_amd/metrics.py): the feature detector (--metric_pt_path: the
+        # TorchScript Inception the reference downloads) and the real-set statistics (--data_stat: a .npz with mu / sigma, or
+        # the reference's cached FeatureStats pickle) must be LOCAL files -- there is no network to fetch them from
+        from sid_lsg_amd import metrics as _metrics
+        bad = [m for m in o.metrics if not _metrics.is_valid_metric(m)]
+        if bad:
+            raise click.ClickException(f'--metrics: unknown {bad}; valid: {_metrics.list_valid_metrics()}')
+        for flag, path in (('--metric_pt_path', o.metric_pt_path), ('--data_stat', o.data_stat)):
+            if not path or not os.path.isfile(path):
+                raise click.ClickException(f'--metrics needs {flag} to be a local file (got {path!r})')
     if not o.train_mode or o.fake_score_use_lora:
         raise click.ClickException('--train_mode 0 / --fake_score_use_lora are not supported')
-    c.metrics, c.resolution = None, o.resolution
+    c.metrics, c.resolution = o.metrics, o.resolution
+    c.metric_real_stats = o.data_stat
     c.data_loader_kwargs = EasyDict(pin_memory=True, num_workers=o.workers, prefetch_factor=2)
     c.dataset_prompt_text_kwargs = EasyDict(class_name='sid_lsg_amd.data.PromptDataset', path=o.data_prompt_text,
                                             resolution=o.resolution, random_flip=o.xflip, prompt_only=True)

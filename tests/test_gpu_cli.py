@@ -60,3 +60,48 @@ def test_train_then_generate(tmp_path):
         assert np.abs(a.astype(np.int32) - b.astype(np.int32)).max() <= 4
     with open(glob.glob(str(tmp_path / 'img_b2' / '*.png'))[0], 'rb') as f:
         assert f.read(8) == b'\x89PNG\r\n\x1a\n'
+
+
+def test_train_with_fid_metric(tmp_path):
+    """`sid_train.py --metrics fid_test` -- at the snapshot ticks the EMA generator runs through the
+    one-step sampler + VAE decoder (HIP kernels), a TorchScript feature detector with the reference's calling convention
+    (`detector(uint8 NCHW, return_features=True)`, here a tiny scripted conv net standing in for inception-2015-12-05.pt) and
+    the Frechet distance against cached real-set statistics; the result lands in metric-fid_test-alpha-*.jsonl and the stats."""
+    if not torch.cuda.is_available():
+        pytest.skip('needs an MI355X')
+    import json
+
+    import numpy as np
+    from click.testing import CliRunner
+    import sid_train
+
+    class Detector(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            torch.manual_seed(0)
+            self.conv = torch.nn.Conv2d(3, 16, 8, stride=8)
+
+        def forward(self, img: torch.Tensor, return_features: bool = True) -> torch.Tensor:
+            return self.conv(img.to(torch.float32) / 255.0).mean(dim=(2, 3))
+    det_path, stat_path = str(tmp_path / 'detector.pt'), str(tmp_path / 'real_stats.npz')
+    torch.jit.script(Detector()).save(det_path)
+    np.savez(stat_path, mu=np.zeros(16), sigma=np.eye(16) * 0.01)
+    (tmp_path / 'aesthetics_6_plus.txt').write_text('\n'.join(f'prompt number {i}' for i in range(40)) + '\n')
+    runs = tmp_path / 'runs'
+    res = CliRunner().invoke(sid_train.main, [
+        '--outdir', str(runs), '--data_prompt_text', str(tmp_path), '--sd_model', 'random:tiny', '--seed', '1', '--batch', '4',
+        '--batch-gpu', '2', '--duration', '0.00002', '--ema', '0.00001', '--tick', '1', '--snap', '1', '--dump', '50',
+        '--resolution', '128', '--metrics', 'fid_test', '--metric_pt_path', det_path, '--data_stat', stat_path], catch_exceptions=False)
+    assert res.exit_code == 0, res.output
+    run_dir = glob.glob(str(runs / '00000-*'))[0]
+    files = glob.glob(os.path.join(run_dir, 'metric-fid_test-alpha-*.jsonl'))
+    assert files, os.listdir(run_dir)
+    rows = [json.loads(ln) for ln in open(files[0])]
+    assert rows and all(np.isfinite(r['results']['fid30k_full']) and r['results']['fid30k_full'] > 0 for r in rows)
+    assert all(r['snapshot_pkl'].startswith('network-snapshot-') for r in rows)
+    stats = [json.loads(ln) for ln in open(glob.glob(os.path.join(run_dir, 'stats_*.jsonl'))[0])]
+    assert any('Metrics/fid30k_full' in r for r in stats)
+    # missing files are refused up front
+    bad = CliRunner().invoke(sid_train.main, ['--outdir', str(runs), '--data_prompt_text', str(tmp_path), '--sd_model', 'random:tiny',
+                                              '--metrics', 'fid30k_full', '--metric_pt_path', '/nonexistent.pt', '-n'])
+    assert bad.exit_code != 0 and '--metric_pt_path' in bad.output

@@ -1,5 +1,6 @@
 """CPU tests (`-m "not gpu"`): the C ABI loads and exports what the header declares, the host-side mirrors of the
 reference interfaces behave like the reference, and the product path refuses to run without a GPU / library."""
+import json
 import os
 import re
 import subprocess
@@ -326,3 +327,95 @@ def test_prompt_stream_matches_reference_rng_order(golden_dir, tmp_path, golden)
                 assert torch.equal(embed(ps), ref['cond']), f'prompts / dropout flags differ at iteration {it} phase {ph} round {r}'
                 ndrop += sum(p == '' for p in ps)
     print(golden, 'dropped prompts in the stream:', ndrop)
+
+
+def test_frechet_distance_and_feature_stats():
+    """sid_lsg_amd.metrics: the Frechet distance against the reference's formula
+    (metrics/sid_fid_and_clip.py:65-67, `scipy.linalg.sqrtm`), incl. rank-deficient covariances (fewer samples than
+    features); FeatureStats against numpy (sid_metric_utils.py:135-176) incl. the max_items cut; the CLIP score."""
+    import scipy.linalg
+    from sid_lsg_amd import metrics
+    rng = np.random.default_rng(0)
+    for n, f in ((500, 64), (40, 64), (300, 96)):
+        a = rng.normal(size=(n, f)) @ rng.normal(size=(f, f)) * 0.3 + rng.normal(size=f)
+        b = rng.normal(size=(n + 7, f)) @ rng.normal(size=(f, f)) * 0.25 - 0.1
+        mu_a, mu_b = a.mean(0), b.mean(0)
+        s_a, s_b = np.cov(a, rowvar=False, bias=True), np.cov(b, rowvar=False, bias=True)
+        m = np.square(mu_a - mu_b).sum()
+        sq, _ = scipy.linalg.sqrtm(np.dot(s_a, s_b), disp=False)
+        ref = float(np.real(m + np.trace(s_a + s_b - sq * 2)))
+        got = metrics.frechet_distance(mu_a, s_a, mu_b, s_b)
+        assert abs(got - ref) <= 1e-6 * max(1.0, abs(ref)), (n, f, got, ref)
+        assert abs(metrics.frechet_distance(mu_a, s_a, mu_a, s_a)) < 1e-6 * np.trace(s_a)
+    x = rng.normal(size=(257, 33)).astype(np.float32)
+    st = metrics.FeatureStats(capture_mean_cov=True, capture_all=True, max_items=200)
+    for i in range(0, 257, 50):
+        st.append(torch.from_numpy(x[i:i + 50]))
+    assert st.is_full() and st.num_items == 200 and st.get_all().shape == (200, 33)
+    mu, sigma = st.get_mean_cov()
+    x64 = x[:200].astype(np.float64)
+    assert np.allclose(mu, x64.mean(0), atol=1e-12) and np.allclose(sigma, x64.T @ x64 / 200 - np.outer(x64.mean(0), x64.mean(0)), atol=1e-10)
+    img, txt = rng.normal(size=(10, 8)), rng.normal(size=(10, 8))
+    assert abs(metrics.clip_score_from_features(np.concatenate([img, txt], 1)) - (img * txt).sum(-1).mean()) < 1e-9
+
+
+def test_metric_registry_and_report(tmp_path):
+    """calc_metric / report_metric with the reference's metric names and jsonl file names (sid_metric_main.py:25-123), on a
+    CPU stand-in generator and detector; two ranks must merge their statistics to the one-rank result."""
+    from sid_lsg_amd import metrics
+    assert set(metrics.list_valid_metrics()) >= {'fid30k_full', 'fid_clip_30k_full', 'fid_test', 'fid_clip_test'}
+    torch.manual_seed(0)
+    proj = torch.randn(3 * 16 * 16, 24) * 0.01
+    seen = []
+
+    def G(latents, contexts, init_timesteps):
+        assert len(contexts) == latents.shape[0] and init_timesteps.shape[0] == latents.shape[0]
+        return torch.tanh(torch.nn.functional.interpolate(latents[:, :3], scale_factor=8.0))       # [-1, 1] images at 8x the latent size
+
+    def detector(img, return_features=True):
+        assert img.dtype == torch.uint8 and img.shape[1:] == (3, 16, 16)
+        f = img.float().flatten(1) @ proj
+        seen.append(f)
+        return f
+
+    def oc(img, texts, div255):
+        f = torch.nn.functional.normalize(img.float().flatten(1)[:, :8], dim=1)
+        return torch.cat([f, f], 1)                                                                # cosine 1 with "its text"
+    real = (np.zeros(24), np.eye(24))
+    res = metrics.calc_metric('fid_clip_test', G=G, prompts=['a', 'b', 'c'], resolution=16, detector=detector, real_stats=real,
+                              open_clip_detector=oc, device='cpu', num_test=12, detector_size=16, batch_gen=5)
+    feats = torch.cat(seen).double().numpy()
+    assert feats.shape == (12, 24)
+    ref = metrics.frechet_distance(feats.mean(0), np.cov(feats, rowvar=False, bias=True), *real)
+    assert abs(res.results.fid30k_full - ref) < 1e-8 * max(1.0, abs(ref)) and abs(res.results.open_clipscore_30k - 1.0) < 1e-6
+    assert np.isnan(res.results.clipscore30k) and res.metric == 'fid_clip_test' and res.num_gpus == 1
+    run = tmp_path / 'run'
+    run.mkdir()
+    metrics.report_metric(res, run_dir=str(run), snapshot_pkl=str(run / 'network-snapshot-1.000000-000010.pkl'), alpha=1.0)
+    line = json.loads((run / 'metric-fid_clip_test-alpha-1.000000.jsonl').read_text())
+    assert line['snapshot_pkl'] == 'network-snapshot-1.000000-000010.pkl' and line['results']['fid30k_full'] == res.results.fid30k_full
+    with pytest.raises(FileNotFoundError):
+        metrics.load_detector('/nonexistent/inception-2015-12-05.pt', 'cpu')
+    # two gloo ranks: rank-strided samples, statistics merged with one all_reduce
+    script = tmp_path / 'm.py'
+    script.write_text(f'''
+import sys, numpy as np, torch
+sys.path.insert(0, {ROOT!r})
+from sid_lsg_amd import distributed as dist, metrics
+dist.init(backend="gloo")
+torch.manual_seed(0)
+proj = torch.randn(3 * 16 * 16, 24) * 0.01
+G = lambda latents, contexts, init_timesteps: torch.tanh(torch.nn.functional.interpolate(latents[:, :3], scale_factor=8.0))
+det = lambda img, return_features=True: img.float().flatten(1) @ proj
+o = metrics.MetricOptions(G=G, prompts=["a", "b", "c"], resolution=16, detector=det, real_stats=(np.zeros(24), np.eye(24)), device="cpu",
+                          detector_size=16, batch_gen=3)
+stats, _, _ = metrics.generator_feature_stats(o, 10)
+assert stats.num_items == 10, stats.num_items
+mu, sigma = stats.get_mean_cov()
+assert np.isfinite(mu).all() and np.allclose(sigma, sigma.T)
+dist.print0("METRICS_OK", dist.get_world_size(), float(metrics.frechet_distance(mu, sigma, np.zeros(24), np.eye(24))))
+''')
+    out = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr',
+                          '127.0.0.1', '--master-port', '29633', str(script)], capture_output=True, text=True,
+                         env=dict(os.environ, MASTER_ADDR='127.0.0.1'), timeout=300)
+    assert out.returncode == 0 and 'METRICS_OK 2' in out.stdout, out.stdout[-1000:] + out.stderr[-2000:]
