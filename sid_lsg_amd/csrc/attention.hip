@@ -161,6 +161,86 @@ struct TileRegs {
     }
 };
 
+// The same tile staged by LDS-DMA (buffer_load_dwordx4 ... lds): no staging registers, no ds_write pass.  A wave's DMA
+// instruction moves 64 consecutive 16-byte chunks of the (row-major, stride LD) LDS image; chunk q = (row q / (LD/8), column
+// chunk q % (LD/8)).  Lanes whose column chunk lies past D are masked off: the pad chunks are written ONCE per block
+// (tile_pad_init: zeros, or the forward's ones column) and survive every refill.  Rows past the sequence end read zeros
+// through the descriptor's range check.  `wait()` = this wave's DMAs have landed (the caller's barrier publishes them).
+#ifndef SIDLSG_ATTN_DMA
+#define SIDLSG_ATTN_DMA 1      // A/B switch (0: register staging everywhere)
+#endif
+typedef __attribute__((address_space(3))) void* at_lptr_t;
+template <int DP, int ROWS>
+struct TileDma {
+    static constexpr int LD = tile_ld<DP>();
+    static constexpr int NCH = LD / 8;
+    static constexpr int TCH = ROWS * NCH;
+    static constexpr int PER = (TCH + 255) / 256;
+    static_assert(TCH % 64 == 0, "whole waves");
+    unsigned voff[PER];
+    bool on[PER];
+    int wave;
+    DEVFN void init(int ld, int D) {
+        wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+#pragma unroll
+        for (int j = 0; j < PER; j++) {
+            const int idx = threadIdx.x + 256 * j;
+            const int r = idx / NCH, c = (idx - r * NCH) * 8;
+            on[j] = idx < TCH && c < D;
+            voff[j] = (unsigned)((r * ld + c) * 2);
+        }
+    }
+    DEVFN void load(__amdgpu_buffer_rsrc_t rs, int ld, int row0, bf16* dst) {
+        const unsigned soff = (unsigned)row0 * (unsigned)ld * 2u;
+#pragma unroll
+        for (int j = 0; j < PER; j++) {
+            if (256 * j + 64 * wave >= TCH) continue;                   // wave-uniform
+            if (on[j]) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (at_lptr_t)(dst + (256 * j + 64 * wave) * 8), 16, voff[j], soff, 0, 0);
+        }
+    }
+    DEVFN void wait() const { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+};
+// pad chunks (columns D .. LD) of a tile buffer: zeros, with 1.0 at column `ones_col` when >= 0 (see TileRegs::store)
+template <int DP, int ROWS>
+DEVFN void tile_pad_init(bf16* tile, int D, int ones_col) {
+    constexpr int LD = tile_ld<DP>();
+    const int npad = (LD - D) / 8;
+    for (int i = threadIdx.x; i < ROWS * npad; i += 256) {
+        const int r = i / npad, c = D + (i - r * npad) * 8;
+        bf16x8 x = zero8();
+        if (c == ones_col) x[0] = f2bf(1.0f);
+        st8(tile + r * LD + c, x);
+    }
+}
+
+// One interface over both staging schemes: load(..., dst) starts fetching a tile that will live in LDS buffer `dst`,
+// commit(dst, ...) completes it (register staging: the ds_write pass; DMA: wait for this wave's transfers).
+template <int DP, int ROWS, bool DMA>
+struct Tile;
+template <int DP, int ROWS>
+struct Tile<DP, ROWS, false> {
+    TileRegs<DP, ROWS> t;
+    DEVFN void init(int ld, int D, bf16* b0, bf16* b1, int ones_col) { (void)b0; (void)b1; (void)ones_col; t.init(ld, D); }
+    DEVFN void load(__amdgpu_buffer_rsrc_t rs, int ld, int row0, bf16* dst) { (void)dst; t.load(rs, ld, row0); }
+    DEVFN void commit(bf16* dst, int LD, int ones_col = -1) { t.store(dst, LD, ones_col); }
+};
+template <int DP, int ROWS>
+struct Tile<DP, ROWS, true> {
+    TileDma<DP, ROWS> t;
+    DEVFN void init(int ld, int D, bf16* b0, bf16* b1, int ones_col) {
+        t.init(ld, D);
+        tile_pad_init<DP, ROWS>(b0, D, ones_col);
+        tile_pad_init<DP, ROWS>(b1, D, ones_col);
+    }
+    DEVFN void load(__amdgpu_buffer_rsrc_t rs, int ld, int row0, bf16* dst) { t.load(rs, ld, row0, dst); }
+    DEVFN void commit(bf16* dst, int LD, int ones_col = -1) { (void)dst; (void)LD; (void)ones_col; t.wait(); }
+};
+// Measured (MI355X, in-session A/B, N = 4096, B = 16): DMA staging speeds the backward kernels up at every head size (d = 40:
+// 1685 -> 1578 us, d = 64: 1282 -> 1244 us, d = 80 at N = 1024: 219 -> 199 us) and the d = 40 forward (483 -> 466 us), but slows
+// the d = 64 / 80 forward down (390 -> 435 us, 65 -> 70 us: padded rows, masked lanes) -> forward: DP == 48 only.
+template <int DP, int MODE>
+constexpr bool attn_q_dma() { return SIDLSG_ATTN_DMA && (MODE == 1 || DP == 48); }
+
 // max of three: pattern-matched to v_max3_f32.  attention.hip is compiled with -fno-honor-nans so that llvm.maxnum
 // does not put a canonicalising v_max x,x on every MFMA output.  (Do NOT use inline asm on MFMA results: the
 // compiler cannot see the operands of an asm statement when it inserts the MFMA->VALU wait states, and short
@@ -251,13 +331,13 @@ __global__ __launch_bounds__(256, (DP <= 48 && MODE == 0) ? 4 : ((DP <= 48 && MO
         seed_dp[qt] = (f32x4){c, c, c, c};
     }
 
-    TileRegs<DP, AT_KT> tk, tv;
-    tk.init(p.ldk, p.D);
-    tv.init(p.ldv, p.D);
-    tk.load(rk, p.ldk, 0);
-    tv.load(rv, p.ldv, 0);
-    tk.store(Ks[0], LD);
-    tv.store(Vs[0], LD, ones_col);
+    Tile<DP, AT_KT, attn_q_dma<DP, MODE>()> tk, tv;
+    tk.init(p.ldk, p.D, Ks[0], Ks[1], -1);
+    tv.init(p.ldv, p.D, Vs[0], Vs[1], ones_col);
+    tk.load(rk, p.ldk, 0, Ks[0]);
+    tv.load(rv, p.ldv, 0, Vs[0]);
+    tk.commit(Ks[0], LD);
+    tv.commit(Vs[0], LD, ones_col);
     __syncthreads();
     int buf = 0;
     // The tile body is instantiated several times: full tiles (no masking code at all; the compiler otherwise if-converts
@@ -268,7 +348,8 @@ __global__ __launch_bounds__(256, (DP <= 48 && MODE == 0) ? 4 : ((DP <= 48 && MO
     auto tile = [&](const int k0, auto ragged, auto has_next, auto first) {
         const bool more = MODE == 0 ? decltype(has_next)::value : (k0 + AT_KT < p.Nk);
         constexpr bool FIRST = decltype(first)::value;
-        if (more) { tk.load(rk, p.ldk, k0 + AT_KT); tv.load(rv, p.ldv, k0 + AT_KT); }
+        // next tile -> registers, or by DMA straight into the other buffer (last read before the previous barrier)
+        if (more) { tk.load(rk, p.ldk, k0 + AT_KT, Ks[buf ^ 1]); tv.load(rv, p.ldv, k0 + AT_KT, Vs[buf ^ 1]); }
         const bf16* Kt = Ks[buf];
         const bf16* Vt = Vs[buf];
         f32x4 s[4][QT];
@@ -411,8 +492,8 @@ __global__ __launch_bounds__(256, (DP <= 48 && MODE == 0) ? 4 : ((DP <= 48 && MO
             }
         }
         if (more) {                      // the other buffer was last read before the previous barrier
-            tk.store(Ks[buf ^ 1], LD);
-            tv.store(Vs[buf ^ 1], LD, ones_col);
+            tk.commit(Ks[buf ^ 1], LD);
+            tv.commit(Vs[buf ^ 1], LD, ones_col);
             __syncthreads();
             buf ^= 1;
         }
@@ -502,13 +583,14 @@ __global__ __launch_bounds__(256) void attn_dkdv_kernel(AttnParams p) {
 #pragma unroll
         for (int i = 0; i < DT; i++) { dk[kt][i] = (f32x4){0, 0, 0, 0}; dv[kt][i] = (f32x4){0, 0, 0, 0}; }
 
-    TileRegs<DP, AK_QT> tq, tdo;
-    tq.init(p.ldq, p.D);
-    tdo.init(p.ldo, p.D);
+    Tile<DP, AK_QT, SIDLSG_ATTN_DMA != 0> tq, tdo;
+    tq.init(p.ldq, p.D, Qs2[0], Qs2[1], -1);
+    tdo.init(p.ldo, p.D, dOs2[0], dOs2[1], -1);
     float lse_r = 0.f, dl_r = 0.f;
-    auto prefetch = [&](int q0) {
-        tq.load(rq, p.ldq, q0);
-        tdo.load(rdo, p.ldo, q0);
+    int pb_ = 0;
+    auto prefetch = [&](int q0, int into) {
+        tq.load(rq, p.ldq, q0, Qs2[into]);
+        tdo.load(rdo, p.ldo, q0, dOs2[into]);
         if (threadIdx.x < AK_QT) {
             const int q = q0 + threadIdx.x;
             lse_r = q < p.Nq ? LSEb[q] : INFINITY;   // padded query rows contribute p = exp2(-inf) = 0
@@ -516,14 +598,13 @@ __global__ __launch_bounds__(256) void attn_dkdv_kernel(AttnParams p) {
             if (PS) { lse_r = -lse_r; dl_r = -dl_r; }
         }
     };
-    prefetch(0);
-    tq.store(Qs2[0], LD); tdo.store(dOs2[0], LD);
+    prefetch(0, 0);
+    tq.commit(Qs2[0], LD); tdo.commit(dOs2[0], LD);
     if (threadIdx.x < AK_QT) { lse_s[0][threadIdx.x] = lse_r; dl_s[0][threadIdx.x] = dl_r; }
     __syncthreads();
-    int pb_ = 0;
     auto qtile = [&](const int q0, auto has_next) {       // (run-time `more`: the compile-time split measured slower here)
         const bool more = q0 + AK_QT < p.Nq;
-        if (more) prefetch(q0 + AK_QT);
+        if (more) prefetch(q0 + AK_QT, pb_ ^ 1);
         const bf16* Qs = Qs2[pb_];
         const bf16* dOs = dOs2[pb_];
         f32x4 pp[KT][4], ds[KT][4];
@@ -576,7 +657,7 @@ __global__ __launch_bounds__(256) void attn_dkdv_kernel(AttnParams p) {
             }
         if (more) {          // the other buffer was last read in the previous stage, i.e. before the previous barrier
             pb_ ^= 1;
-            tq.store(Qs2[pb_], LD); tdo.store(dOs2[pb_], LD);
+            tq.commit(Qs2[pb_], LD); tdo.commit(dOs2[pb_], LD);
             if (threadIdx.x < AK_QT) { lse_s[pb_][threadIdx.x] = lse_r; dl_s[pb_][threadIdx.x] = dl_r; }
             __syncthreads();
         }
@@ -605,15 +686,41 @@ __global__ __launch_bounds__(256) void attn_dkdv_kernel(AttnParams p) {
     }
 }
 
-template <int DP, int QT, int KT, bool PS>
-static int launch_attn(const AttnParams& p, int mode, hipStream_t s) {
-    const int qb = 4 * QT * 16, kb = 4 * KT * 16;
+// Explicit instantiations of every kernel specialisation the dispatcher can launch: hipcc 7.2 has left individual host stubs
+// (__device_stub__...) of implicitly instantiated kernel templates out of the object in some builds of this file (undefined
+// symbol at dlopen); a definition request pins them all.
+#define ATTN_INST(DP, PS)                                                            \
+    template __global__ void attn_q_kernel<DP, 2, 0, true, PS>(AttnParams);           \
+    template __global__ void attn_q_kernel<DP, 2, 0, false, PS>(AttnParams);          \
+    template __global__ void attn_q_kernel<DP, 2, 1, false, PS>(AttnParams);          \
+    template __global__ void attn_dkdv_kernel<DP, 1, PS>(AttnParams);
+#define ATTN_INST2(DP) ATTN_INST(DP, false) ATTN_INST(DP, true)
+ATTN_INST2(16) ATTN_INST2(32) ATTN_INST2(48) ATTN_INST2(64) ATTN_INST2(80) ATTN_INST2(96) ATTN_INST2(128) ATTN_INST2(160)
+template __global__ void attn_dkdv_kernel<48, 2, false>(AttnParams);
+template __global__ void attn_dkdv_kernel<48, 2, true>(AttnParams);
+#undef ATTN_INST
+#undef ATTN_INST2
+
+// (the forward / dQ launches are not templated on KT: with two KT instantiations per head size hipcc 7.2's host pass rejected
+// the SECOND use of the same attn_q_kernel specialisation -- "no matching function", substitution failure without a reason)
+template <int DP, int QT, bool PS>
+static int launch_attn_q(const AttnParams& p, int mode, hipStream_t s) {
+    const int qb = 4 * QT * 16;
     if (mode == 0) {
         if (p.D == DP - 8) hipLaunchKernelGGL((attn_q_kernel<DP, QT, 0, true, PS>), dim3((p.Nq + qb - 1) / qb, p.H, p.B), dim3(256), 0, s, p);
         else hipLaunchKernelGGL((attn_q_kernel<DP, QT, 0, false, PS>), dim3((p.Nq + qb - 1) / qb, p.H, p.B), dim3(256), 0, s, p);
-    } else if (mode == 1) hipLaunchKernelGGL((attn_q_kernel<DP, QT, 1, false, PS>), dim3((p.Nq + qb - 1) / qb, p.H, p.B), dim3(256), 0, s, p);
-    else hipLaunchKernelGGL((attn_dkdv_kernel<DP, KT, PS>), dim3((p.Nk + kb - 1) / kb, p.H, p.B), dim3(256), 0, s, p);
+    } else hipLaunchKernelGGL((attn_q_kernel<DP, QT, 1, false, PS>), dim3((p.Nq + qb - 1) / qb, p.H, p.B), dim3(256), 0, s, p);
     return sidlsg_last_error();
+}
+template <int DP, int KT, bool PS>
+static int launch_attn_dkdv(const AttnParams& p, hipStream_t s) {
+    const int kb = 4 * KT * 16;
+    hipLaunchKernelGGL((attn_dkdv_kernel<DP, KT, PS>), dim3((p.Nk + kb - 1) / kb, p.H, p.B), dim3(256), 0, s, p);
+    return sidlsg_last_error();
+}
+template <int DP, int QT, int KT, bool PS>
+static int launch_attn(const AttnParams& p, int mode, hipStream_t s) {
+    return mode == 2 ? launch_attn_dkdv<DP, KT, PS>(p, s) : launch_attn_q<DP, QT, PS>(p, mode, s);
 }
 template <bool PS>
 static int dispatch_attn(const AttnParams& p, int mode, hipStream_t s) {
