@@ -27,10 +27,11 @@ def per_kernel(path, counter):
 
 def main():
     fpath, wpath, out = sys.argv[1:4]
+    what = sys.argv[4] if len(sys.argv) > 4 else 'conv'          # 'gemm': the dense-GEMM micro-benchmark (bench_kernels.py gemm)
     f, w = per_kernel(fpath, 'FETCH_SIZE'), per_kernel(wpath, 'WRITE_SIZE')
     conv = [k for k in f if ('gemm' in k and 'GemmParams' in k and 'finish' not in k)]
-    res = {'source': 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on `python tools/bench_kernels.py conv` '
-                     '(SD1.5 conv3x3 shapes, batch 16)',
+    res = {'source': f'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on `python tools/bench_kernels.py {what}` '
+                     + ('(SD1.5 conv3x3 shapes, batch 16)' if what == 'conv' else '(SD1.5 dense GEMM shapes: Linear / 1x1 conv over tokens, batch 16)'),
            'correction': 'bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024  (FETCH_SIZE x2: gfx950 counts 128-B requests as 64 B)',
            'per_kernel': {}}
     tot_b, tot_n = 0.0, 0
@@ -44,10 +45,10 @@ def main():
         if k in conv:
             tot_b += (2 * fk + wk) * 1024.0
             tot_n += n
-    res['conv_launches'] = tot_n
+    res[what + '_launches'] = tot_n
     res['avg_hbm_side_bytes_per_launch'] = tot_b / max(tot_n, 1)
     json.dump(res, open(out, 'w'), indent=1)
-    print(json.dumps({k: res[k] for k in ('conv_launches', 'avg_hbm_side_bytes_per_launch')}))
+    print(json.dumps({k: res[k] for k in (what + '_launches', 'avg_hbm_side_bytes_per_launch')}))
 
 
 if __name__ == '__main__':
