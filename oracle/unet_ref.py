@@ -8,7 +8,7 @@ architecture of that class for the SD1.5 / SD2.1-base `unet/config.json`
  with the same module tree, parameter names and shapes, so
 `state_dict()` keys equal the diffusers ones.  parity unpinned vs. diffusers itself
 (package absent offline); pinned structurally by the exact parameter totals
-asserted in tests/test_oracle_unet.py.
+asserted in tests/test_oracle_pinned.py and tests/test_host_logic.py::test_unet_structure_matches_diffusers_contract.
 
 Everything here is plain torch.nn.functional on NCHW fp32 tensors; autograd gives the
 reference gradients the HIP backward kernels are checked against.
