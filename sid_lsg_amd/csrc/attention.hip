@@ -549,18 +549,22 @@ __global__ __launch_bounds__(256, (DP <= 48 && MODE == 0) ? 4 : ((DP <= 48 && MO
 constexpr int AK_QT = 64;
 // PS: Q pre-scaled (see attn_q_kernel): lse_s / dl_s hold -LSE / -delta and seed the S and dP accumulators, so the
 // probability is exp2(acc) and dS = P * acc' with no further arithmetic.
+#ifndef SIDLSG_DKDV_SUB
+#define SIDLSG_DKDV_SUB 1      // 64-query sub-tiles per LDS stage (one barrier per stage); A/B knob
+#endif
 template <int DP, int KT, bool PS>
 __global__ __launch_bounds__(256) void attn_dkdv_kernel(AttnParams p) {
     constexpr int LD = tile_ld<DP>();
     constexpr int DT = DP / 16;
+    constexpr int SUB = DP <= 96 ? SIDLSG_DKDV_SUB : 1, ST = SUB * AK_QT;      // (the 160-wide heads would not fit the LDS with two sub-tiles)
     // Q / dO tiles double-buffered (2 x 2 x 7 KiB at d = 40): the next tile is written while other waves still read the
     // current one -> ONE barrier per 64-query stage
-    constexpr int TE = lds_tile_elems<DP, AK_QT>();
+    constexpr int TE = lds_tile_elems<DP, ST>();
     __shared__ __attribute__((aligned(16))) bf16 Qs2[2][TE];
     __shared__ __attribute__((aligned(16))) bf16 dOs2[2][TE];
-    __shared__ __attribute__((aligned(16))) float lse_s[2][AK_QT], dl_s[2][AK_QT];
+    __shared__ __attribute__((aligned(16))) float lse_s[2][ST], dl_s[2][ST];
 #pragma unroll
-    for (int i = 0; i < 2; i++) { lds_tile_init<DP, AK_QT>(Qs2[i]); lds_tile_init<DP, AK_QT>(dOs2[i]); }
+    for (int i = 0; i < 2; i++) { lds_tile_init<DP, ST>(Qs2[i]); lds_tile_init<DP, ST>(dOs2[i]); }
     const int b = blockIdx.z, h = blockIdx.y;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lg = lane >> 4;
     const int key0 = (blockIdx.x * 4 + wave) * (KT * 16);
@@ -583,7 +587,7 @@ __global__ __launch_bounds__(256) void attn_dkdv_kernel(AttnParams p) {
 #pragma unroll
         for (int i = 0; i < DT; i++) { dk[kt][i] = (f32x4){0, 0, 0, 0}; dv[kt][i] = (f32x4){0, 0, 0, 0}; }
 
-    Tile<DP, AK_QT, SIDLSG_ATTN_DMA != 0> tq, tdo;
+    Tile<DP, ST, SIDLSG_ATTN_DMA != 0> tq, tdo;
     tq.init(p.ldq, p.D, Qs2[0], Qs2[1], -1);
     tdo.init(p.ldo, p.D, dOs2[0], dOs2[1], -1);
     float lse_r = 0.f, dl_r = 0.f;
@@ -591,7 +595,7 @@ __global__ __launch_bounds__(256) void attn_dkdv_kernel(AttnParams p) {
     auto prefetch = [&](int q0, int into) {
         tq.load(rq, p.ldq, q0, Qs2[into]);
         tdo.load(rdo, p.ldo, q0, dOs2[into]);
-        if (threadIdx.x < AK_QT) {
+        if (threadIdx.x < ST) {
             const int q = q0 + threadIdx.x;
             lse_r = q < p.Nq ? LSEb[q] : INFINITY;   // padded query rows contribute p = exp2(-inf) = 0
             dl_r = q < p.Nq ? DLb[q] : 0.f;
@@ -600,13 +604,18 @@ __global__ __launch_bounds__(256) void attn_dkdv_kernel(AttnParams p) {
     };
     prefetch(0, 0);
     tq.commit(Qs2[0], LD); tdo.commit(dOs2[0], LD);
-    if (threadIdx.x < AK_QT) { lse_s[0][threadIdx.x] = lse_r; dl_s[0][threadIdx.x] = dl_r; }
+    if (threadIdx.x < ST) { lse_s[0][threadIdx.x] = lse_r; dl_s[0][threadIdx.x] = dl_r; }
     __syncthreads();
     auto qtile = [&](const int q0, auto has_next) {       // (run-time `more`: the compile-time split measured slower here)
-        const bool more = q0 + AK_QT < p.Nq;
-        if (more) prefetch(q0 + AK_QT, pb_ ^ 1);
-        const bf16* Qs = Qs2[pb_];
-        const bf16* dOs = dOs2[pb_];
+        const bool more = q0 + ST < p.Nq;
+        if (more) prefetch(q0 + ST, pb_ ^ 1);
+#pragma unroll
+        for (int sub = 0; sub < SUB; sub++) {
+        if (sub && q0 + sub * AK_QT >= p.Nq) break;
+        const bf16* Qs = Qs2[pb_] + sub * AK_QT * LD;
+        const bf16* dOs = dOs2[pb_] + sub * AK_QT * LD;
+        const float* lse_c = lse_s[pb_] + sub * AK_QT;
+        const float* dl_c = dl_s[pb_] + sub * AK_QT;
         f32x4 pp[KT][4], ds[KT][4];
 #pragma unroll
         for (int qt = 0; qt < 4; qt++) {
@@ -616,8 +625,8 @@ __global__ __launch_bounds__(256) void attn_dkdv_kernel(AttnParams p) {
 #pragma unroll
             for (int kt = 0; kt < KT; kt++) {
                 if constexpr (PS) {
-                    const f32x4 nl = *reinterpret_cast<const f32x4*>(&lse_s[pb_][qt * 16 + lg * 4]);
-                    const f32x4 nd = *reinterpret_cast<const f32x4*>(&dl_s[pb_][qt * 16 + lg * 4]);
+                    const f32x4 nl = *reinterpret_cast<const f32x4*>(&lse_c[qt * 16 + lg * 4]);
+                    const f32x4 nd = *reinterpret_cast<const f32x4*>(&dl_c[qt * 16 + lg * 4]);
                     const f32x4 s = mma_d<DP>(nl, fq, fk[kt]);       // S[q][key] - LSE[q]: lane col=key li, rows q = lg*4+r
                     const f32x4 dp = mma_d<DP>(nd, fdo, fv[kt]);     // dP - delta
 #pragma unroll
@@ -634,9 +643,9 @@ __global__ __launch_bounds__(256) void attn_dkdv_kernel(AttnParams p) {
                     const int ql = qt * 16 + lg * 4 + r;
                     // padded queries (q >= Nq) carry lse = +inf (set at prefetch) -> exp2(-inf) = 0; padded keys are
                     // never stored.  The d^-1/2 factor of dS is applied to dK in the epilogue.
-                    const float pr = __builtin_amdgcn_exp2f(fmaf(s[r], p.scale2, -lse_s[pb_][ql]));
+                    const float pr = __builtin_amdgcn_exp2f(fmaf(s[r], p.scale2, -lse_c[ql]));
                     pp[kt][qt][r] = pr;
-                    ds[kt][qt][r] = pr * (dp[r] - dl_s[pb_][ql]);
+                    ds[kt][qt][r] = pr * (dp[r] - dl_c[ql]);
                 }
                 }
             }
@@ -655,16 +664,17 @@ __global__ __launch_bounds__(256) void attn_dkdv_kernel(AttnParams p) {
                     dk[kt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb, dsb, dk[kt][dt], 0, 0, 0);
                 }
             }
+        }
         if (more) {          // the other buffer was last read in the previous stage, i.e. before the previous barrier
             pb_ ^= 1;
             tq.commit(Qs2[pb_], LD); tdo.commit(dOs2[pb_], LD);
-            if (threadIdx.x < AK_QT) { lse_s[pb_][threadIdx.x] = lse_r; dl_s[pb_][threadIdx.x] = dl_r; }
+            if (threadIdx.x < ST) { lse_s[pb_][threadIdx.x] = lse_r; dl_s[pb_][threadIdx.x] = dl_r; }
             __syncthreads();
         }
     };
     {
         int q0 = 0;
-        for (; q0 < p.Nq; q0 += AK_QT) qtile(q0, std::true_type{});
+        for (; q0 < p.Nq; q0 += ST) qtile(q0, std::true_type{});
     }
 #pragma unroll
     for (int kt = 0; kt < KT; kt++) {
