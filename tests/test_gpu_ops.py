@@ -470,6 +470,45 @@ def test_adam_ema(dev):
         assert torch.equal(w16, p.to(BF16)), 'bf16 compute copy = RNE(bf16) of the updated master'
 
 
+@pytest.mark.parametrize('variant', ['adamw', 'adam_l2_beta1', 'clip_scale'])
+def test_adam_branches_match_torch_optim(dev, variant):
+    """The optimizer kernel's other branches against torch's own single-tensor optimizers on the CPU: AdamW (`--optimizer adamw`,
+    sid_train.py:223-226: decoupled weight decay), Adam with L2 weight decay and beta1 != 0 (first-moment buffer), and the
+    fp16-recipe gradient clip (`clip_grad_value_`, sid_training_loop.py:546-547) together with the 1/world gradient scale."""
+    from sid_lsg_amd.optim import FusedAdamEMA, FusedAdamWEMA
+    g = torch.Generator().manual_seed(1)
+    n, lr = 50021, 3e-3
+    p0 = torch.randn(n, generator=g)
+    p = p0.to(dev).clone()
+    grad = torch.zeros(n, device=dev)
+    pr = torch.nn.Parameter(p0.clone())
+    if variant == 'adamw':
+        opt = FusedAdamWEMA.__new__(FusedAdamWEMA)
+        opt._setup(p, grad, lr, (0.0, 0.999), 1e-8, 0.05, True, None)
+        ref = torch.optim.AdamW([pr], lr=lr, betas=(0.0, 0.999), eps=1e-8, weight_decay=0.05)
+        clip, scale = None, 1.0
+    elif variant == 'adam_l2_beta1':
+        opt = FusedAdamEMA.from_flat(p, grad, lr=lr, betas=(0.9, 0.99), eps=1e-6, weight_decay=0.02)
+        ref = torch.optim.Adam([pr], lr=lr, betas=(0.9, 0.99), eps=1e-6, weight_decay=0.02)
+        clip, scale = None, 1.0
+    else:
+        opt = FusedAdamEMA.from_flat(p, grad, lr=lr, betas=(0.0, 0.999), eps=1e-6, clip_value=0.25)
+        opt.grad_scale = 0.5                                   # e.g. 1 / world after a summed all-reduce
+        ref = torch.optim.Adam([pr], lr=lr, betas=(0.0, 0.999), eps=1e-6)
+        clip, scale = 0.25, 0.5
+    for step in range(5):
+        gr = torch.randn(n, generator=g) * 10 ** (step - 2)
+        grad.copy_(gr.to(dev))
+        opt.step()
+        gg = gr * scale
+        if clip is not None:
+            gg = gg.clamp(-clip, clip)
+        pr.grad = gg.clone()
+        ref.step()
+        close(p, pr.detach(), 2e-6, f'{variant} step {step}')
+        assert float(grad.abs().max()) == 0.0
+
+
 def test_bias_act_matches_reference_golden(dev, golden_dir):
     """Reference plugin op through the reference's own seams: `custom_ops.get_plugin('bias_act_plugin', sources=...)` builds /
     loads the HIP plugin and returns a module; `bias_act(...)` calls `_plugin.bias_act(x, b, xref, yref, dy, grad, ...)` for
