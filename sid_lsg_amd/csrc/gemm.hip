@@ -760,6 +760,9 @@ extern "C" int sidlsg_exp_set_trace(void* ptr) { return hipMemcpyToSymbol(HIP_SY
 #define TRACE_HWID()
 #define WTRACE(i)
 #endif
+#ifndef SIDLSG_CONV_TAP_INNER
+#define SIDLSG_CONV_TAP_INNER 1
+#endif
 #ifndef SIDLSG_V3_SCHED_FENCE
 #define SIDLSG_V3_SCHED_FENCE 1
 #endif
@@ -818,11 +821,24 @@ DEVFN void gemm_v3_body(const GemmParams& p) {
     // swizzled chunk; the K position of the tile is the wave-uniform soffset.  Invalid rows (m >= M, n >= N, conv halo)
     // carry an out-of-range offset and the buffer unit writes zeros: no pointer arithmetic, selects or zero page in the
     // steady state (the 64-bit global_load_lds version issued ~150 VALU+SALU per 40 MFMAs).
-    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(p.A), 0, (int)p.a_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(p.W), 0, (int)p.w_bytes, 0x00020000);
     const int Hs = p.ups ? (p.H >> 1) : p.H, Ws = p.ups ? (p.Wd >> 1) : p.Wd;
+    // conv, K-tile order "channel chunk outer, tap inner" (`lin`): the 9 taps of a chunk re-read the same 3 image rows shifted
+    // by a pixel; visited back to back the re-reads hit the XCD's L2 (FETCH_SIZE 291 -> 123 MB per launch at 64x64x320 -> 320,
+    // 713 -> 143 MB at 640 channels; with the tap-major order the reuse distance was Cin * 256 B = 80-330 KB per block, times
+    // ~64 resident blocks per XCD = 5-20 MB against 4 MB of L2).  The weight matrix stays tap-major, only the visiting order
+    // changes.  Addressing: the byte offset of tap (dh, dw) is LINEAR in (dh, dw) with wave-uniform strides, so the per-row
+    // VGPR holds the CENTRE pixel's offset, the tap goes into the scalar soffset (against a buffer base moved one row + one
+    // pixel below A, so soffset >= 0), and the halo is a 9-bit validity mask per row: 3 VALU per row and K-tile instead of a
+    // recomputation of the row offsets (which cost 5 % when done per K-tile).  Not with the fused nearest x2 upsampling
+    // ((h + dh) >> 1 is not linear): that keeps the tap-major order.
+    const unsigned tap_rs = (unsigned)Ws * (unsigned)p.lda * 2u, tap_ps = (unsigned)p.lda * 2u;
+    const bool lin = MODE == 1 && SIDLSG_CONV_TAP_INNER && !p.ups && (unsigned long long)p.a_bytes + tap_rs + tap_ps < 0x80000000ull;
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<bf16*>(p.A) - (lin ? (size_t)(tap_rs + tap_ps) / 2 : 0), 0, (int)(p.a_bytes + (lin ? tap_rs + tap_ps : 0u)), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(p.W), 0, (int)p.w_bytes, 0x00020000);
     unsigned abase[4], aoff[4];
     int ahi[4], awi[4];
+    unsigned cen[4], tmask[4];
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         const int r = wave * 32 + j * 8 + lrow;
@@ -841,7 +857,19 @@ DEVFN void gemm_v3_body(const GemmParams& p) {
             ahi[j] = ok ? ho * p.stride - 1 : -100000;
             awi[j] = wo * p.stride - 1;
             aoff[j] = OOB;
+            cen[j] = abase[j] + (unsigned)((ahi[j] + 1) * Ws + awi[j] + 1) * tap_ps;
+            unsigned mk = 0;
+#pragma unroll
+            for (int tp = 0; tp < 9; tp++) {
+                const int hi = ahi[j] + tp / 3, wi = awi[j] + tp % 3;
+                if (hi >= 0 && hi < p.H && wi >= 0 && wi < p.Wd) mk |= 1u << tp;
+            }
+            tmask[j] = mk;
         }
+    }
+    if (MODE == 0) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) cen[j] = tmask[j] = 0;
     }
     unsigned boff[5];
 #pragma unroll
@@ -859,11 +887,22 @@ DEVFN void gemm_v3_body(const GemmParams& p) {
     auto issue = [&](int t, int buf) {          // 9 buffer_load ... lds per wave
         bf16* sa = ring + buf * STAGE;
         bf16* sb = sa + BM * BK;
-        const int k0 = t * BK;
+        int k0 = t * BK;
         int asoff = k0 * 2;
         if (MODE == 1) {
-            const int tap = k0 / p.Cin;
-            asoff = (k0 - tap * p.Cin) * 2;
+            if (lin) {
+                const int cc = t / 9;
+                const int tap = t - cc * 9;
+                const int dh = tap / 3, dw = tap - dh * 3;
+                asoff = cc * BK * 2 + dh * (int)tap_rs + dw * (int)tap_ps;
+                k0 = tap * p.Cin + cc * BK;
+                const unsigned bit = 1u << tap;
+#pragma unroll
+                for (int j = 0; j < 4; j++) aoff[j] = (tmask[j] & bit) ? cen[j] : OOB;
+                cur_tap = tap;
+            }
+            const int tap = lin ? cur_tap : k0 / p.Cin;
+            if (!lin) asoff = (k0 - tap * p.Cin) * 2;
             if (tap != cur_tap) {               // every Cin/64 tiles: new tap -> new row offsets / halo mask
                 cur_tap = tap;
                 const int dh = tap / 3, dw = tap - dh * 3;
