@@ -78,7 +78,7 @@ int sidlsg_adam_ema(float* p, float* g, float* m, float* v, float* ema, void* w_
     if (!p || !g || !v || !hyper || n <= 0) return SIDLSG_EINVAL;
     if (((uintptr_t)p | (uintptr_t)g | (uintptr_t)v) & 15) return SIDLSG_EINVAL;
     size_t blocks = ((size_t)n / 4 + 255) / 256;
-    if (blocks > 256 * 16) blocks = 256 * 16;   // 16 blocks/CU, grid-stride the rest
+    if (blocks > 256 * 16) blocks = 256 * 16;   // 16 blocks/CU, grid-stride the rest (1 / 2 / 4 per CU measured the same in the step)
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(adam_ema_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, ema, (bf16*)w_bf16,
                        hyper, (size_t)n, zero_grad);

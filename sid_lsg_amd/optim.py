@@ -93,6 +93,19 @@ class FusedAdamEMA:
                             ops._p(self.ema) if use_ema else None, ops._p(self.w16), self.hyper.data_ptr(), self.flat.numel(),
                             1 if zero_grad else 0, ops._s())
 
+    def launch_range(self, lo, hi, use_ema=True, zero_grad=True):
+        """The same kernel on elements [lo, hi) of the flat buffers (the update is elementwise: any partition of the buffer
+        into ranges gives bit-identical results).  SiDStep updates a segment of a network as soon as the backward has
+        finished with it, on its own stream beside the rest of the backward."""
+        if hi <= lo:
+            return
+        if lo % 4:
+            raise ValueError('range start must be a multiple of 4 elements (16-byte vector accesses)')
+        off = lambda t, sz: None if t is None else t.data_ptr() + sz * lo      # noqa: E731
+        lib.sidlsg_adam_ema(off(self.flat, 4), off(self.grad, 4), off(self.exp_avg, 4), off(self.exp_avg_sq, 4),
+                            off(self.ema, 4) if use_ema else None, off(self.w16, 2), self.hyper.data_ptr(), hi - lo,
+                            1 if zero_grad else 0, ops._s())
+
     def begin_step(self, ema_beta=None):
         """Host half of a step: advance the step counter and put the step's scalars (bias corrections, EMA beta, 1/world) in
         device memory.  step() does this itself unless `external_scalars` is set -- the captured HIP graph of the training

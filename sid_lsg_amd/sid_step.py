@@ -22,6 +22,51 @@ from . import ops
 from .sd_util import hip_denoise, hip_generate, hip_prepare_denoise
 
 
+class _SegmentedUpdate:
+    """Optimizer step of one network, issued segment by segment from inside its backward (HipUNet2DCondition.grad_segments:
+    up blocks + head, mid block, the rest).  As soon as the backward has passed a segment, that segment's gradient exchange
+    (world > 1) and its slice of the fused nan_to_num + Adam (+ EMA) + bf16-copy kernel run on the optimizer stream beside the
+    MFMA-bound backward of the earlier layers: the HBM-bound optimizer (25 GB of traffic per network, ~5.5 ms on an MI355X)
+    leaves the critical path except for the last segment.  Elementwise kernel, disjoint ranges: bit-identical to one launch
+    over the whole buffer after the backward."""
+
+    def __init__(self, step, net, opt):
+        self.step, self.net, self.opt = step, net, opt
+        self.segs = net.grad_segments()
+        self.use_ema = False
+
+    def arm(self, ema_beta):
+        """Before the FORWARD of the last accumulation round (the markers are placed by the forward)."""
+        if not self.opt.external_scalars:
+            self.opt.begin_step(ema_beta)
+        self.use_ema = ema_beta is not None and self.opt.ema is not None
+        self.net.set_grad_ready_callback(self._ready)
+
+    def _ready(self, k):
+        st, net = self.step, self.net
+        lo, hi = self.segs[k]
+        cur = torch.cuda.current_stream()
+        if st.exchange:
+            st.reducer.start_range(net.flat_grads, lo, hi)            # communication stream, after cur + weight-gradient streams
+        st.opt_stream.wait_stream(cur)
+        for s in ops.grad_streams(net.flat_grads.device):
+            st.opt_stream.wait_stream(s)
+        with torch.cuda.stream(st.opt_stream):
+            if st.exchange:
+                st.reducer.wait()                                     # orders the optimizer stream after the collectives
+            self.opt.launch_range(lo, hi, use_ema=self.use_ema)
+
+    def start_last(self):
+        """After the backward: the remaining segment (still on the optimizer stream: it runs beside whatever the caller
+        enqueues next on the compute stream)."""
+        self.net.set_grad_ready_callback(None)
+        self._ready(2)
+
+    def join(self):
+        torch.cuda.current_stream().wait_stream(self.step.opt_stream)
+        self.net.refresh_compute_weights(cast=False)                  # backward-data operands (transposed bf16 weights)
+
+
 class SiDStep:
     def __init__(self, G, fake_score, true_score, G_ema, scheduler, opt_fake, opt_G, *, alpha=1.0, cfg_train_fake=1.0,
                  cfg_eval_fake=1.0, cfg_eval_real=1.0, loss_scaling=1.0, loss_scaling_G=1.0, batch_gpu_total=1,
@@ -42,6 +87,14 @@ class SiDStep:
         self.side = None
         if os.environ.get('SIDLSG_TEACHER_STREAM', '1') != '0' and torch.cuda.is_available():     # A/B switch (+2 % images/s on MI355X)
             self.side = ops.side_stream(G.flat_params.device)
+        # opt-in: optimizer steps issued segment-wise from inside the backward, on their own stream (_SegmentedUpdate).  Same
+        # results; measured NEUTRAL on one MI355X (221.5 / 220.9 vs 221.7 / 220.8 ms per iteration): the trace shows 3.2 of
+        # the 4.8-5.5 ms of each optimizer kernel moving under the backward, and the kernels it then shares HBM with
+        # (weight gradients, split-K reductions, GroupNorm backward) slowing down by as much.  Off by default.
+        self.seg_opt = False
+        self.opt_stream = None
+        if os.environ.get('SIDLSG_SEG_OPT', '0') == '1' and torch.cuda.is_available():
+            self.enable_segmented_optimizer()
         self._graphs, self._graph_warm = {}, False
         opt_fake.grad_scale = opt_G.grad_scale = 1.0 / world_size     # DDP mean, folded into the optimizer kernel
         opt_fake.attach(ema=None, w16=fake_score.flat_w16)
@@ -49,6 +102,10 @@ class SiDStep:
         if not (G.compute_dtype == fake_score.compute_dtype == true_score.compute_dtype):
             raise ValueError('G, fake_score and true_score must share one compute dtype (they share the noisy CFG batch)')
         self.phi.requires_grad_(False)
+
+    def enable_segmented_optimizer(self, on=True):
+        self.seg_opt = bool(on)
+        self.opt_stream = torch.cuda.Stream(self.G.flat_params.device) if on else None
 
     def _init_t(self, n, device):
         return torch.full((n,), self.init_timestep, device=device, dtype=torch.long)
@@ -65,17 +122,26 @@ class SiDStep:
         loss.backward()                                                             # :449-450
         return loss.detach()
 
-    def fake_backward(self, rounds):
-        """Forward/backward of phase A over all accumulation rounds; leaves the gradients in psi.flat_grads."""
+    def fake_backward(self, rounds, seg=None):
+        """Forward/backward of phase A over all accumulation rounds; leaves the gradients in psi.flat_grads (seg: the
+        segments the backward of the last round has passed are already being exchanged / updated)."""
         self.G.requires_grad_(False)
         self.psi.requires_grad_(True)                                               # :389
         loss = None
-        for r in rounds:
+        for i, r in enumerate(rounds):
+            if seg is not None and i == len(rounds) - 1:
+                seg.arm(None)
             loss = self.fake_round(r)
         self.psi.requires_grad_(False)                                              # :455
         return loss
 
     def fake_update(self, rounds):
+        if self.seg_opt:
+            seg = _SegmentedUpdate(self, self.psi, self.opt_fake)
+            loss = self.fake_backward(rounds, seg)
+            seg.start_last()
+            seg.join()
+            return loss
         loss = self.fake_backward(rounds)
         self._optimizer_step(self.psi, self.opt_fake, ema_beta=None)                # :458-462
         return loss
@@ -113,6 +179,16 @@ class SiDStep:
         self.G.requires_grad_(True)                                                 # :468
         self.psi.requires_grad_(False)
         loss = None
+        if self.seg_opt:
+            seg = _SegmentedUpdate(self, self.G, self.opt_G)
+            for i, r in enumerate(rounds):
+                if i == len(rounds) - 1:
+                    seg.arm(ema_beta)
+                loss = self.generator_round(r, before_fake_eval if i == 0 else None)
+            self.G.requires_grad_(False)                                            # :538
+            seg.start_last()                                                        # :541-565
+            seg.join()
+            return loss
         overlap = self.exchange and self.overlap_g
         segs = self.G.grad_segments() if overlap else None
         for i, r in enumerate(rounds):
@@ -143,6 +219,14 @@ class SiDStep:
         Same result as fake_update(); generator_update(), but the psi gradient all-reduce + optimizer step are issued
         after phase A's backward and only WAITED for right before psi is evaluated in phase B, i.e. they overlap with
         the generator forward and the teacher forward of the first phase-B round."""
+        if self.seg_opt:
+            # psi: segments 0 / 1 are exchanged + updated during its backward, the last one right after it on the optimizer
+            # stream -- beside the generator forward and the teacher forward; joined right before psi is evaluated
+            seg = _SegmentedUpdate(self, self.psi, self.opt_fake)
+            lf = self.fake_backward(inputs['A'], seg)
+            seg.start_last()
+            lg = self.generator_update(inputs['B'], ema_beta=ema_beta, before_fake_eval=seg.join)
+            return lf, lg
         lf = self.fake_backward(inputs['A'])
         overlap = self.exchange
         if overlap:

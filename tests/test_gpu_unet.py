@@ -710,7 +710,8 @@ def test_weight_gradient_stream_changes_nothing(dev):
 
 def test_side_streams_change_nothing_in_the_step(dev):
     """The teacher runs on a second stream beside the fake-score network (SiDStep.side) and the weight gradients on a third
-    (ops._OnWgradStream); tensors cross streams through autograd's saved-tensor handling + record_stream.  Three iterations
+    (ops._OnWgradStream), the optimizer segment by segment on a fourth from inside the backward (sid_step._SegmentedUpdate);
+    tensors cross streams through autograd's saved-tensor handling + record_stream.  Three iterations
     with both switches ON must give the losses and weights of the single-stream run, up to the fp32-atomics ordering noise
     that exists on one stream already (Adam with beta1 = 0 turns a sign flip of a ~0 gradient into a 2 lr step)."""
     from sid_lsg_amd import ops
@@ -733,6 +734,7 @@ def test_side_streams_change_nothing_in_the_step(dev):
             step = SiDStep(G, psi, phi, G_ema, DDPMScheduler().to(dev), opt_f, opt_g, alpha=1.0, cfg_train_fake=1.5, cfg_eval_fake=1.5,
                            cfg_eval_real=1.5, batch_gpu_total=b, init_timestep=625)
             step.side = ops.side_stream(dev) if on else None
+            step.enable_segmented_optimizer(on)  # off: ONE optimizer launch after each backward, on the compute stream
             gen = torch.Generator().manual_seed(3)
             losses = []
             for it in range(iters):
