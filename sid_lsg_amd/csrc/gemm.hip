@@ -985,6 +985,9 @@ DEVFN void gemm_v3_body(const GemmParams& p) {
     asm volatile("" ::: "memory");
     TRACE(1);
     read_frags(0, 0, fa0, fw0);
+#ifdef SIDLSG_EXP_NOLDS
+    read_frags(0, 1, fa1, fw1);
+#endif
     if (kt_begin + 1 < nk) issue(kt_begin + 1, 1);
     // One K-tile.  The steady state, the last-but-one tile (nothing left to fetch) and the last tile are separate
     // STRAIGHT-LINE instantiations: with `if (more)` / `if (kt + 2 < nk)` inside one loop body the waitcnt pass has to merge
@@ -992,19 +995,27 @@ DEVFN void gemm_v3_body(const GemmParams& p) {
     // of ~9), i.e. the prefetch of the next tile's fragments was serialised in front of the MFMAs meant to cover it.
     auto ktile = [&](const int kt, auto has_next, auto fetch) {
         const int buf = (kt - kt_begin) & 1;
+#ifndef SIDLSG_EXP_NOLDS
         read_frags(buf, 1, fa1, fw1);                          // A
+#endif
         mfma_block(fa0, fw0);
         // The MFMAs are register-only, so neither the "memory" clobber nor the barrier orders them: without this fence the
         // scheduler hoists the wait + barrier to right behind the FIRST kk=0 MFMA (seen in the ISA), which halves the MFMA
         // time covering the DMA of tile kt+1 (issued in the previous D) and serialises the wait in front of 19 MFMAs.
         if (SCHED_FENCE) __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // C: my share of tile kt+1 is in LDS
+#ifndef SIDLSG_EXP_NOBAR
         __builtin_amdgcn_s_barrier();
+#endif
         asm volatile("" ::: "memory");
         if (SCHED_FENCE) __builtin_amdgcn_sched_barrier(0);
         if constexpr (decltype(has_next)::value) {             // D
+#ifndef SIDLSG_EXP_NOLDS
             read_frags(buf ^ 1, 0, fa0, fw0);
+#endif
+#ifndef SIDLSG_EXP_NODMA
             if constexpr (decltype(fetch)::value) issue(kt + 2, buf);
+#endif
         }
         mfma_block(fa1, fw1);                                  // E
     };
