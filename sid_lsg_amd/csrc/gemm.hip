@@ -763,12 +763,6 @@ extern "C" int sidlsg_exp_set_trace(void* ptr) { return hipMemcpyToSymbol(HIP_SY
 #ifndef SIDLSG_CONV_TAP_INNER
 #define SIDLSG_CONV_TAP_INNER 1
 #endif
-#ifndef SIDLSG_V3_EARLY_DMA
-#define SIDLSG_V3_EARLY_DMA 0
-#endif
-#ifndef SIDLSG_V3_EARLY_N
-#define SIDLSG_V3_EARLY_N 2
-#endif
 #ifndef SIDLSG_V3_SCHED_FENCE
 #define SIDLSG_V3_SCHED_FENCE 1
 #endif
@@ -999,44 +993,10 @@ DEVFN void gemm_v3_body(const GemmParams& p) {
     // STRAIGHT-LINE instantiations: with `if (more)` / `if (kt + 2 < nk)` inside one loop body the waitcnt pass has to merge
     // the paths and makes the kk=1 MFMAs of E wait for the fragment reads D has just issued (lgkmcnt(4..0) in the ISA instead
     // of ~9), i.e. the prefetch of the next tile's fragments was serialised in front of the MFMAs meant to cover it.
-    auto mfma_part = [&](const bf16x8 (&fa)[MT], const bf16x8 (&fw)[NT], const int n_lo, const int n_hi) {
-#pragma unroll
-        for (int ni = n_lo; ni < n_hi; ni++)
-#pragma unroll
-            for (int mi = 0; mi < MT; mi++)
-                acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[ni], fa[mi], acc[ni][mi], 0, 0, 0);
-    };
     auto ktile = [&](const int kt, auto has_next, auto fetch) {
         const int buf = (kt - kt_begin) & 1;
 #ifndef SIDLSG_EXP_NOLDS
         read_frags(buf, 1, fa1, fw1);                          // A
-#endif
-#if SIDLSG_V3_EARLY_DMA
-        // The DMA of tile kt+2 goes into THIS tile's buffer.  It used to be issued in D, after the barrier that also
-        // publishes tile kt+1 -- one K-tile (40 MFMAs) ahead of its use, less than the ~1.1 us a 37 KB stage takes to land
-        // (ablation: 25 % of the kernel is that wait).  The buffer is free as soon as every wave holds its kk=1 fragments
-        // in registers: a second barrier EARLY_N MFMA columns into the kk=0 block publishes that, and the DMA starts
-        // 20 - 4 * EARLY_N MFMAs earlier.  C then waits with vmcnt(9): the 9 DMAs of tile kt+2 may stay in flight.
-        constexpr bool FETCH = decltype(has_next)::value && decltype(fetch)::value;
-        mfma_part(fa0, fw0, 0, SIDLSG_V3_EARLY_N);
-        __builtin_amdgcn_sched_barrier(0);
-        if constexpr (FETCH) {
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-            issue(kt + 2, buf);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        mfma_part(fa0, fw0, SIDLSG_V3_EARLY_N, NT);
-        __builtin_amdgcn_sched_barrier(0);
-        if constexpr (FETCH) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        if constexpr (decltype(has_next)::value) read_frags(buf ^ 1, 0, fa0, fw0);
-        mfma_block(fa1, fw1);
-        return;
 #endif
         mfma_block(fa0, fw0);
         // The MFMAs are register-only, so neither the "memory" clobber nor the barrier orders them: without this fence the
