@@ -85,7 +85,7 @@ def test_unet_forward_backward(dev, cfg_name, lat):
 
 def test_glue_matches_reference_golden(dev, golden_dir):
     """sid_sd_sampler / sid_sd_denoise through the HIP path vs the golden vectors captured from the REFERENCE's own
-    functions (oracle/make_goldens.py).  bf16 UNet => 3e-2 of max."""
+    functions (oracle/make_goldens.py).  bf16 UNet => 3e-2 of max for the sampler; kappa-dependent bound for the guided output."""
     from oracle import fixtures
     from sid_lsg_amd.scheduler import DDPMScheduler
     from sid_lsg_amd.sd_util import sid_sd_denoise, sid_sd_sampler
@@ -112,8 +112,13 @@ def test_glue_matches_reference_golden(dev, golden_dir):
                 for px0 in (True, False):
                     with torch.no_grad():
                         y = sid_sd_denoise(hip2, xh, noise, prompts, t, sched, te, tok, 64, dtype=F32, predict_x0=px0, guidance_scale=kappa)
-                    e, _ = rel_err(y, torch.from_numpy(g[f'b{b}_k{kappa}_x0{int(px0)}']))
-                    assert e < 4e-2, f'denoise {cfg} b{b} k{kappa} x0{px0}: {e}'
+                    e, e2 = rel_err(y, torch.from_numpy(g[f'b{b}_k{kappa}_x0{int(px0)}']))
+                    # one bf16 UNet pass is within 1.2e-2 of max / 1e-2 in l2 of the fp32 reference (kappa = 1: observed 7-8e-3);
+                    # guidance combines two passes as (1 - kappa) u + kappa c, so their rounding errors (independent) add
+                    # in quadrature with those weights: x 1.58 at kappa 1.5, x 5.7 at 4.5 (observed max 0.9-1.3e-2 / 2.5-4.1e-2)
+                    amp = ((1 - kappa) ** 2 + kappa ** 2) ** 0.5
+                    print(f'denoise {cfg} b{b} kappa {kappa} x0 {px0}: max {e:.4f} l2 {e2:.4f}  (bounds {1.2e-2 * amp:.4f} / {1e-2 * amp:.4f})')
+                    assert e < 1.2e-2 * amp and e2 < 1e-2 * amp, f'denoise {cfg} b{b} k{kappa} x0{px0}: {e} {e2}'
 
 
 # Loss tolerances of the bf16 production path against the fp32 oracle.  north_star's 1e-3 is asserted in the fp32 mode
