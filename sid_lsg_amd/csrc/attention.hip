@@ -263,6 +263,11 @@ constexpr int AT_KT = 64;   // keys per LDS tile
 // was built and measured neutral, commit 2bea052: the MFMA + VALU core alone runs the
 // d = 40 forward in 333 us, LDS fragment reads add ~100 us and tile staging + barrier ~110 us: the loop is bound by those
 // stalls, not by MFMA/VALU overlap.)
+// Ablation builds of the final PS forward (-DSIDLSG_EXP_ATTN_NOSTAGE / _NOLDS / _NOEXP; N = 4096, d = 40, B = 16, MI355X, after a
+// long warm-up): all 457 us; no exponentials 398; no K/V tile staging + barrier 376; fragments from registers instead of LDS 311;
+// neither staging nor LDS reads 233; none of the three 197 (= the MFMA + remaining VALU floor).  64 instead of 32 queries per
+// wave (half the fragment reads per MFMA, 2 instead of 4 waves per SIMD, 256 VGPRs) measured 465 vs 479 us in one session: the
+// cost of the fragment reads is their latency in front of the MFMAs, which occupancy hides and the larger tile does not.
 // PS ("pre-scaled"): Q arrives already multiplied by D^-0.5 * log2(e) (the caller folds the factor into the q rows of the
 // projection weight, see sidlsg_attn_fwd_ps), so the QK^T MFMA yields the scores in log2 units and its C operand is seeded
 // with -m (forward: the running maximum; dQ pass: -LSE): the accumulators come out as s - m and go straight into
@@ -349,14 +354,20 @@ __global__ __launch_bounds__(256, (DP <= 48 && MODE == 0) ? 4 : ((DP <= 48 && MO
         const bool more = MODE == 0 ? decltype(has_next)::value : (k0 + AT_KT < p.Nk);
         constexpr bool FIRST = decltype(first)::value;
         // next tile -> registers, or by DMA straight into the other buffer (last read before the previous barrier)
+#ifndef SIDLSG_EXP_ATTN_NOSTAGE
         if (more) { tk.load(rk, p.ldk, k0 + AT_KT, Ks[buf ^ 1]); tv.load(rv, p.ldv, k0 + AT_KT, Vs[buf ^ 1]); }
+#endif
         const bf16* Kt = Ks[buf];
         const bf16* Vt = Vs[buf];
         f32x4 s[4][QT];
 #pragma unroll
         for (int kt = 0; kt < 4; kt++) {
             Frag<DP> fk;
+#ifdef SIDLSG_EXP_ATTN_NOLDS
+            fk = fq[kt % QT];
+#else
             frag_from_lds<DP>(fk, Kt + (kt * 16 + li) * LD, lg);
+#endif
             // slice-major order: the two MFMAs of one accumulator's chain are QT instructions apart (back to back they
             // serialise on the 16x16x32 result latency)
 #pragma unroll
@@ -417,7 +428,11 @@ __global__ __launch_bounds__(256, (DP <= 48 && MODE == 0) ? 4 : ((DP <= 48 && MO
                     for (int kt = 0; kt < 4; kt++)
 #pragma unroll
                         for (int r = 0; r < 4; r++) {
+#ifdef SIDLSG_EXP_ATTN_NOEXP
+                            const float e = s[kt][qt][r];
+#else
                             const float e = __builtin_amdgcn_exp2f(s[kt][qt][r]);
+#endif
                             s[kt][qt][r] = e;
                             if (!ONES) sum += e;
                         }
@@ -486,17 +501,23 @@ __global__ __launch_bounds__(256, (DP <= 48 && MODE == 0) ? 4 : ((DP <= 48 && MO
             for (int qt = 0; qt < QT; qt++) pb[qt] = pack_p(s[2 * kb][qt], s[2 * kb + 1][qt]);
 #pragma unroll
             for (int dt = 0; dt < DT; dt++) {
+#ifdef SIDLSG_EXP_ATTN_NOLDS
+                const bf16x8 fa = fq[dt % QT].w[kb % N32];
+#else
                 const bf16x8 fa = tr_frag32(T2, LD, kb * 32, dt * 16, li, lg);
+#endif
 #pragma unroll
                 for (int qt = 0; qt < QT; qt++) o[dt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, pb[qt], o[dt][qt], 0, 0, 0);
             }
         }
+#ifndef SIDLSG_EXP_ATTN_NOSTAGE
         if (more) {                      // the other buffer was last read before the previous barrier
             tk.commit(Ks[buf ^ 1], LD);
             tv.commit(Vs[buf ^ 1], LD, ones_col);
             __syncthreads();
             buf ^= 1;
         }
+#endif
     };
     using T_ = std::true_type;
     using F_ = std::false_type;
