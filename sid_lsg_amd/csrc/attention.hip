@@ -199,6 +199,12 @@ struct TileDma {
         }
     }
     DEVFN void wait() const { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+    // (ISA note: the compiler's waitcnt pass puts its own s_waitcnt vmcnt(0) in front of the first LDS read that may alias an
+    // LDS-DMA in flight -- for ds_read_b64_tr_b16 always, for plain reads of the same __shared__ variable too -- so the
+    // prefetch of the next tile is waited for before the current tile's first fragment reads.  Issuing the DMA as inline
+    // assembly (untracked) and forcing the pre-loop global loads to complete in the compiler's bookkeeping removed those
+    // waits from the loop, and measured +-1 % on forward and backward at d = 40 / 64: with 3-4 waves per SIMD the other
+    // waves cover that wait.  Not kept.)
 };
 // pad chunks (columns D .. LD) of a tile buffer: zeros, with 1.0 at column `ones_col` when >= 0 (see TileRegs::store)
 template <int DP, int ROWS>
