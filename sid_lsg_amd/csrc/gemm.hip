@@ -728,6 +728,23 @@ static Ws ws_for(hipStream_t s) {
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
+// buffer_load_dwordx4 ... lds as inline assembly (64 lanes x 16 bytes -> LDS at `dst` + 16 * lane; dst wave-uniform).
+// Measurement switch (-DSIDLSG_WGRAD_ASM_DMA=1), off in the build.  Background: the compiler's waitcnt pass tracks every
+// LDS-DMA issued through __builtin_amdgcn_raw_ptr_buffer_load_lds and puts s_waitcnt vmcnt(0) in front of the next
+// ds_read_b64_tr_b16 (always) or aliasing plain LDS read -- in the weight-gradient kernel that is the kk=1 fragment reads of
+// the NEXT stage, half a stage after the DMA was issued, so the prefetch distance is half of what the schedule intends (seen
+// in the ISA).  With the DMA invisible to the compiler the only wait is the explicit one at the publish barrier: measured
+// +2-4 % on the dense weight gradients, -1-2 % on the conv ones (the asm statements pin the address arithmetic between them)
+// -- like the early-DMA experiment in gemm_v3_kernel, more prefetch distance buys nothing.  (M0 is reserved: the compiler
+// keeps nothing live in it.)
+DEVFN void dma16_asm(__amdgpu_buffer_rsrc_t rs, const void* dst, unsigned voff, unsigned soff) {
+    const unsigned la = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lptr_t)dst);
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(la), "v"(voff), "s"(rs), "s"(soff) : "memory");
+}
+#ifndef SIDLSG_WGRAD_ASM_DMA
+#define SIDLSG_WGRAD_ASM_DMA 0
+#endif
+
 // ---------------------------------------------------------------------------------------------
 // "v3": the 128 x 160 x 64 tile / 4 waves / 2 blocks per CU structure of gemm_bf16_kernel, but tiles are staged by
 // direct-to-LDS loads (global_load_lds_dwordx4 + zero page, source-side swizzle as in v2): the ds_write commit phase --
@@ -1722,13 +1739,15 @@ DEVFN void wgrad_v2_body(const WgradParams& p) {
 #pragma unroll
         for (int j = 0; j < YI; j++) {
             const bool mok = !tail || (mb + ((wave * YI + j) * 64 + lane) / YC < mend);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(ry, (lptr_t)(ys + (wave * YI + j) * 512), 16, mok ? yoff[j] : OOB, ysoff, 0, 0);
+            if (SIDLSG_WGRAD_ASM_DMA) dma16_asm(ry, ys + (wave * YI + j) * 512, mok ? yoff[j] : OOB, ysoff);
+            else __builtin_amdgcn_raw_ptr_buffer_load_lds(ry, (lptr_t)(ys + (wave * YI + j) * 512), 16, mok ? yoff[j] : OOB, ysoff, 0, 0);
         }
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             const bool mok = !tail || (mb + r0 + 16 * i < mend);
             if (MODE == 0) {
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lptr_t)(xs + (4 * wave + 16 * i) * WG_T), 16, mok ? xoff[i] : OOB, xsoff, 0, 0);
+                if (SIDLSG_WGRAD_ASM_DMA) dma16_asm(rx, xs + (4 * wave + 16 * i) * WG_T, mok ? xoff[i] : OOB, xsoff);
+                else __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lptr_t)(xs + (4 * wave + 16 * i) * WG_T), 16, mok ? xoff[i] : OOB, xsoff, 0, 0);
             } else {
                 bool ok = kok && mok;
                 const int b = pb[i], ho = pho[i], wo = pwo[i];
@@ -1736,7 +1755,8 @@ DEVFN void wgrad_v2_body(const WgradParams& p) {
                 ok = ok && hi >= 0 && hi < p.H && wi >= 0 && wi < p.Wd;
                 if (p.ups) { hi >>= 1; wi >>= 1; }
                 const unsigned o = ok ? (((unsigned)(b * Hs + hi) * (unsigned)Ws + (unsigned)wi) * (unsigned)p.lda + (unsigned)cA) * 2u : OOB;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lptr_t)(xs + (4 * wave + 16 * i) * WG_T), 16, o, 0, 0, 0);
+                if (SIDLSG_WGRAD_ASM_DMA) dma16_asm(rx, xs + (4 * wave + 16 * i) * WG_T, o, 0);
+                else __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lptr_t)(xs + (4 * wave + 16 * i) * WG_T), 16, o, 0, 0, 0);
                 int nwo = wo + d_wo, nho = ho + d_ho, nb = b + d_b;
                 if (nwo >= p.Wo) { nwo -= p.Wo; nho += 1; }
                 if (nho >= p.Ho) { nho -= p.Ho; nb += 1; }
