@@ -266,6 +266,10 @@ def main():
     dt = time.time() - t0
     for tm in timers.values():
         tm.__exit__()
+    if world > 1:      # max over ranks, BEFORE anything rank-dependent: every collective below is executed by every rank
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        dt = float(tt)
     t_host = None
     if use_graph:                  # per-kernel events cannot see inside a graph launch: sample eager iterations now
         hs = time.time()
@@ -274,8 +278,9 @@ def main():
         t_host = (time.time() - hs) / 3 * 1e3          # host time to enqueue one graphed iteration (inputs + text encode + replay)
         torch.cuda.synchronize()
         use_graph = False
-        if not args.no_kernel_timing and rank == 0:
-            timers = make_timers()
+        if not args.no_kernel_timing:                 # (iterations contain the gradient exchange: every rank runs them)
+            if rank == 0:
+                timers = make_timers()
             for tm in timers.values():
                 tm.__enter__()
             for it in range(args.warmup + args.steps + 3, args.warmup + args.steps + 6):
@@ -289,11 +294,11 @@ def main():
     # reports for the same command) is longer than the kernel's own.  A few extra iterations AFTER the timed region, with that
     # overlap switched off, give each family's stand-alone figure (`isolated` in the roofline objects).
     iso = {}
-    if timers and step.side is not None:
+    if not args.no_kernel_timing and step.side is not None:          # rank-independent condition: the iterations exchange gradients
         from sid_lsg_amd import ops as _ops
         side, step.side = step.side, None
         wgrad_side, _ops._WGRAD_SIDE = _ops._WGRAD_SIDE, False      # weight gradients back on the main stream as well
-        tms = make_timers()
+        tms = make_timers() if rank == 0 else {}
         for tm in tms.values():
             tm.__enter__()
         for it in range(args.warmup + args.steps, args.warmup + args.steps + 3):
@@ -323,11 +328,8 @@ def main():
             e1.record()
             torch.cuda.synchronize()
             teacher = e0.elapsed_time(e1) / 5.0
-    if world > 1:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
-        dt = float(tt)
     if rank != 0:
+        _shutdown(world)
         return
     value = args.steps * batch_size / dt
     f_gmac = F_GMAC.get(args.arch, 0.0)
@@ -402,6 +404,14 @@ def main():
         # 32 threads is the measured sweet spot class for one fp32 conv-heavy forward -> cores = threads actually used
         out['cpu_baseline'] = cpu_baseline(args.arch, min(os.cpu_count() or 1, 32), kappa=args.kappa)
     print(json.dumps(out), flush=True)
+    _shutdown(world)
+
+
+def _shutdown(world):
+    """All ranks leave together: the others wait here while rank 0 finishes its rank-local measurements (teacher pass)."""
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
 
 
 if __name__ == '__main__':

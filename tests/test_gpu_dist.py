@@ -110,3 +110,37 @@ def test_rccl_collectives_inside_the_captured_iteration(dev, tmp_path):
     print(f"eager {r['eager']} graph {r['graph']} max weight difference G {float(r['dG']):.2e} psi {float(r['dpsi']):.2e}")
     assert int(r['ngraphs']) == 1 and rel.max() < 2e-4
     assert max(float(r['dG']), float(r['dpsi'])) <= 2.01 * float(r['lr']) * int(r['iters'])
+
+
+def _run_bench(nproc, *flags, env_extra=None, timeout=1500):
+    import json
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', **(env_extra or {}))
+    root = os.path.dirname(HERE)
+    if nproc == 1:
+        cmd = [sys.executable, os.path.join(root, 'bench.py'), '--gpus', '1', *flags]
+    else:
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(nproc), '--master-addr', '127.0.0.1',
+               '--master-port', str(free_port()), os.path.join(root, 'bench.py'), '--gpus', str(nproc), *flags]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout, cwd=root)
+    assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, f'exactly ONE JSON line from rank 0, got {len(lines)}'
+    return json.loads(lines[0])
+
+
+def test_bench_under_torchrun_two_ranks(dev):
+    """The driver's scaling run: `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`.  Two ranks share
+    the one GPU of this box (SIDLSG_BENCH_SHARE_GPU=1: gloo carries the exchange), DEFAULT flags otherwise -- per-family
+    kernel timing on, i.e. including the extra `isolated` iterations after the timed region, which exchange gradients and
+    therefore must be executed by every rank (a rank-0-only version of them paired rank 0's gradient all-reduce with the
+    other ranks' timing all-reduce).  One JSON line, whole-job images/s, all ranks exit cleanly."""
+    # (a small network: gloo moves the 2 x 3.4 GB of SD1.5 gradients through the host at ~40 s per iteration)
+    out = _run_bench(2, '--steps', '2', '--warmup', '1', '--batch-gpu', '2', '--arch', 'tiny40', '--resolution', '128',
+                     env_extra=dict(SIDLSG_BENCH_SHARE_GPU='1'))
+    print({k: out[k] for k in ('value', 'n_gpus', 'ms_per_step', 'config')})
+    assert out['n_gpus'] == 2 and out['steps'] == 2 and out['config']['global_batch'] == 4 and out['config']['parallelism'] == 'dp2'
+    assert abs(out['value'] - 2 * 4 / (2 * out['ms_per_step'] / 1e3)) < 1e-6 * out['value']
+    assert 'cpu_baseline' not in out                    # rank 0 at N = 1 only
+    assert out['roofline']['launches'] > 0 and out['roofline']['isolated']['launches'] > 0 and out['teacher_pass']['ms'] > 0
+    for k in ('loss_fake', 'loss_G'):
+        assert np.isfinite(out[k])
