@@ -122,16 +122,25 @@ class SiDStep:
         loss.backward()                                                             # :449-450
         return loss.detach()
 
-    def fake_backward(self, rounds, seg=None):
+    def fake_backward(self, rounds, seg=None, overlap_exchange=False):
         """Forward/backward of phase A over all accumulation rounds; leaves the gradients in psi.flat_grads (seg: the
         segments the backward of the last round has passed are already being exchanged / updated)."""
         self.G.requires_grad_(False)
         self.psi.requires_grad_(True)                                               # :389
         loss = None
+        overlap = seg is None and overlap_exchange and self.exchange and self.overlap_g
+        segs = self.psi.grad_segments() if overlap else None
         for i, r in enumerate(rounds):
             if seg is not None and i == len(rounds) - 1:
                 seg.arm(None)
+            if overlap and i == len(rounds) - 1:
+                # last accumulation round: a segment of psi's flat gradient is exchanged as soon as the backward has passed it
+                # (the same scheme as for the generator in generator_update)
+                self.psi.set_grad_ready_callback(lambda k: self.reducer.start_range(self.psi.flat_grads, *segs[k]))
             loss = self.fake_round(r)
+        if overlap:
+            self.psi.set_grad_ready_callback(None)
+            self.reducer.start_range(self.psi.flat_grads, *segs[2])
         self.psi.requires_grad_(False)                                              # :455
         return loss
 
@@ -227,9 +236,9 @@ class SiDStep:
             seg.start_last()
             lg = self.generator_update(inputs['B'], ema_beta=ema_beta, before_fake_eval=seg.join)
             return lf, lg
-        lf = self.fake_backward(inputs['A'])
+        lf = self.fake_backward(inputs['A'], overlap_exchange=True)
         overlap = self.exchange
-        if overlap:
+        if overlap and not self.overlap_g:
             self.reducer.start(self.psi.flat_grads)
 
         def finish_fake():
