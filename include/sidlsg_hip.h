@@ -183,6 +183,18 @@ int sidlsg_gemm_fp8w(const void* A, int lda, const void* W8, const float* wscale
 int sidlsg_conv3x3_fp8w(const void* X, int ldx, const void* W8, const float* wscale, void* Y, int ldc, const float* bias,
                         const void* res, int ldres, const float* rowvec, int ld_rowvec, int B, int H, int Wd, int Cin, int Cout,
                         int stride, int ups, float alpha, int flags, void* stream);
+/* Both operands e4m3 (MX MFMA v_mfma_scale_f32_16x16x128_f8f6f4 with unit block scales: twice the bf16 rate on gfx950).
+ * A8: e4m3 bytes [M][lda] at unit scale -- what the GroupNorm / LayerNorm kernels write with an e4m3 output
+ * (sidlsg_cast_fp8 converts a bf16 matrix: clamp to +-448, round to nearest even); W8 / wscale as above.  N % 160 == 0,
+ * K % 16 == 0, lda % 16 == 0; the epilogue arguments are those of sidlsg_gemm_bf16. */
+int sidlsg_cast_fp8(const void* src_bf16, void* dst_fp8, long long n, void* stream);
+int sidlsg_layernorm_fwd_fp8(const void* x, const float* gamma, const float* beta, void* y8, float* stats, int rows, int C,
+                             float eps, void* stream);
+int sidlsg_groupnorm_fwd_fp8(const void* x, const float* gamma, const float* beta, void* y8, float* stats, float* ws, int B,
+                             int HW, int C, int G, float eps, int silu, void* stream);
+int sidlsg_gemm_mx8(const void* A8, int lda, const void* W8, const float* wscale, void* C, int ldc, const float* bias, const void* res,
+                    int ldres, const float* rowvec, int ld_rowvec, int rows_per_batch, int M, int N, int K, float alpha,
+                    int flags, void* stream);
 
 /* ---- fp32-accurate compute mode ------------------------------------------------------------------------------
  * The reference's default precision is fp32 (training/sid_training_loop.py:205 `dtype = float16 if use_fp16 else float32`,

@@ -105,6 +105,27 @@ template <> DEVFN void stv8<float>(float* p, const float (&v)[8]) {
     *reinterpret_cast<f32x4*>(p) = (f32x4){v[0], v[1], v[2], v[3]};
     *reinterpret_cast<f32x4*>(p + 4) = (f32x4){v[4], v[5], v[6], v[7]};
 }
+
+// ---- OCP e4m3 output (frozen networks: activations written as e4m3 at unit scale for the MX-fp8 contractions) ----
+// explicit clamp to the e4m3 range (v_med3_f32): whether v_cvt_pk_fp8_f32 saturates or returns NaN past +-448 depends on a
+// mode bit this library does not own; NaN inputs stay NaN
+DEVFN float clamp_e4m3(float x) { return __builtin_amdgcn_fmed3f(x, -448.f, 448.f); }
+DEVFN unsigned cvt4_fp8(float a, float b, float c, float d) {
+    a = clamp_e4m3(a); b = clamp_e4m3(b); c = clamp_e4m3(c); d = clamp_e4m3(d);
+    int r = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
+    r = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, r, true);
+    return (unsigned)r;
+}
+// 8 consecutive outputs at element index `idx` of y: T elements, or (F8) e4m3 bytes in the same [..][C] geometry
+template <typename T, bool F8>
+DEVFN void st8_out(T* y, size_t idx, const float (&v)[8]) {
+    if constexpr (F8) {
+        u32x2 q = {cvt4_fp8(v[0], v[1], v[2], v[3]), cvt4_fp8(v[4], v[5], v[6], v[7])};
+        *reinterpret_cast<u32x2*>(reinterpret_cast<unsigned char*>(y) + idx) = q;
+    } else {
+        stv8<T>(y + idx, v);
+    }
+}
 template <typename T> DEVFN void zerov8(T* p) {
     const float z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     stv8<T>(p, z);

@@ -508,15 +508,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_kernel(GemmParams p) { 
 typedef long i64_t;
 constexpr int F8_T = 128, F8_LD = 80;     // tile edge; LDS row stride in bytes
 
-// explicit clamp to the e4m3 range (v_med3_f32): whether v_cvt_pk_fp8_f32 saturates or returns NaN past +-448 depends on a
-// mode bit this library does not own; NaN inputs stay NaN
-DEVFN float clamp_e4m3(float x) { return __builtin_amdgcn_fmed3f(x, -448.f, 448.f); }
-DEVFN unsigned cvt4_fp8(float a, float b, float c, float d) {
-    a = clamp_e4m3(a); b = clamp_e4m3(b); c = clamp_e4m3(c); d = clamp_e4m3(d);
-    int r = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
-    r = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, r, true);
-    return (unsigned)r;
-}
+// (clamp_e4m3 / cvt4_fp8: common.h)
 
 template <int MODE>   // 0 dense rows, 2 conv3x3 (any Cin % 8 == 0)
 __global__ __launch_bounds__(NTHREADS, 2) void gemm_fp8w_kernel(GemmParams p) {
@@ -1108,6 +1100,186 @@ static int launch_gemm_v3(const GemmParams& p, hipStream_t s) {
         const size_t n4 = ((size_t)p.M * p.N + 3) / 4;
         hipLaunchKernelGGL(gemm_finish_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, p, splits);
     }
+    return sidlsg_last_error();
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// MX-fp8 dense GEMM for FROZEN networks:  C[m][n] = wscale[n] * sum_k A8[m][k] * W8[n][k]  (+ the shared epilogue)
+// with BOTH operands OCP e4m3 bytes (A8: activations the producing GroupNorm / LayerNorm kernel wrote as e4m3 at unit
+// scale; W8 + wscale: sidlsg_quantize_fp8_rows) on v_mfma_scale_f32_16x16x128_f8f6f4 with unit E8M0 block scales -- the only
+// 8-bit MFMA form that runs at twice the bf16 rate on gfx950 (tools/ubench/mfma_f8.hip: 4.27 vs 1.83 PFLOP/s register-only;
+// the non-scaled 16x16x32 fp8 form of gemm_fp8w_kernel has the bf16 instruction rate).
+// A K-tile of 128 e4m3 elements is byte-identical to gemm_v3_kernel's 64 bf16 elements: same 128 x 160 tile, 128-byte LDS
+// rows, direct-to-LDS loader with one 32-bit offset per row, the same conflict-free swizzles and the same one-barrier
+// schedule.  The MFMA wants 32 consecutive K bytes per lane and operand; which 32 is free as long as both operands agree, so
+// lane group lg takes the 16-byte chunks lg and 4 + lg of its row -- exactly the two ds_read_b128 patterns of the bf16 kernel
+// (chunks 2 lg, 2 lg + 1 would be 2-way bank conflicted with these swizzles).  Schedule per K-tile, halves by output column:
+//   A: reads of the W fragments ni = 2..4 of the current tile; MFMAs ni = 0..1    C: vmcnt(0); s_barrier
+//   D: reads of the next tile's A fragments + W fragments ni = 0..1; DMA of tile kt+2    E: MFMAs ni = 2..4
+// Requires N % 160 == 0, K % 16 == 0, lda % 16 == 0, bf16 or fp32 output through the shared epilogue.
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+typedef int i32x4v __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(NTHREADS, 2) void gemm_mx8_kernel(GemmParams p) {
+    constexpr int BM = 128, BN = 160, MT = 4, NT = 5, KB = 128;      // KB: bytes (= e4m3 elements) per K-tile
+    constexpr int STAGE = (BM + BN) * KB;                            // bytes
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const unsigned char* A8 = reinterpret_cast<const unsigned char*>(p.A);
+    const unsigned char* W8 = reinterpret_cast<const unsigned char*>(p.W);
+    const int tiles_n = p.N / BN, tiles_m = (p.M + BM - 1) / BM;
+    const int ntile = tiles_n * tiles_m;
+    int bid = blockIdx.x;
+    {
+        const int q = ntile >> 3, r = ntile & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    int mt, nt;
+    {
+        const int per_group = p.group_m * tiles_n;
+        const int g = bid / per_group, first_m = g * p.group_m;
+        const int gm = min(p.group_m, tiles_m - first_m);
+        const int in_g = bid - g * per_group;
+        mt = first_m + in_g % gm;
+        nt = in_g / gm;
+    }
+    const int m0 = mt * BM, n0 = nt * BN;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 80;
+    const int li = lane & 15, lg = lane >> 4;
+    const int lrow = lane >> 3, lslot = lane & 7;
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(A8), 0, (int)p.a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(W8), 0, (int)p.w_bytes, 0x00020000);
+    unsigned aoff[4], boff[5];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int r = wave * 32 + j * 8 + lrow;
+        const int kcs = lslot ^ ((r >> 1) & 7);
+        const int m = m0 + r;
+        aoff[j] = m < p.M ? (unsigned)m * (unsigned)p.lda + kcs * 16u : OOB;
+    }
+#pragma unroll
+    for (int j = 0; j < 5; j++) {
+        const int r = (wave + 4 * j) * 8 + lrow;
+        const int kcs = lslot ^ wsw(r);
+        boff[j] = (unsigned)(n0 + r) * (unsigned)p.K + kcs * 16u;       // N % 160 == 0: every row exists
+    }
+    const int nk = (p.K + KB - 1) / KB;
+    auto issue = [&](int t, int buf) {          // 9 buffer_load ... lds per wave
+        char* sa = smem + buf * STAGE;
+        char* sb = sa + BM * KB;
+        const int k0 = t * KB;
+        if (k0 + KB > p.K) {                    // ragged K tail: chunks past K read zeros
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int kcs = lslot ^ (((wave * 32 + j * 8 + lrow) >> 1) & 7);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lptr_t)(sa + (wave * 32 + j * 8) * KB), 16, (k0 + kcs * 16 < p.K) ? aoff[j] : OOB, k0, 0, 0);
+            }
+#pragma unroll
+            for (int j = 0; j < 5; j++) {
+                const int kcs = lslot ^ wsw((wave + 4 * j) * 8 + lrow);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lptr_t)(sb + (wave + 4 * j) * 8 * KB), 16, (k0 + kcs * 16 < p.K) ? boff[j] : OOB, k0, 0, 0);
+            }
+            return;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lptr_t)(sa + (wave * 32 + j * 8) * KB), 16, aoff[j], k0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 5; j++) __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lptr_t)(sb + (wave + 4 * j) * 8 * KB), 16, boff[j], k0, 0, 0);
+    };
+    f32x4 acc[NT][MT];
+#pragma unroll
+    for (int i = 0; i < NT; i++)
+#pragma unroll
+        for (int j = 0; j < MT; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    int wrow[NT];
+#pragma unroll
+    for (int ni = 0; ni < NT; ni++) {
+        const bool paired = (ni | 1) < NT;
+        wrow[ni] = wn0 + (paired ? 32 * (ni >> 1) + (li >> 2) * 8 + (ni & 1) * 4 + (li & 3) : 16 * ni + li);
+    }
+    auto frag = [&](const char* rowp, int sw) -> i32x8 {     // chunks lg and 4 + lg of the row (swizzled positions)
+        const i32x4v lo = *reinterpret_cast<const i32x4v*>(rowp + ((lg ^ sw) << 4));
+        const i32x4v hi = *reinterpret_cast<const i32x4v*>(rowp + (((4 + lg) ^ sw) << 4));
+        return (i32x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    };
+    auto read_a = [&](int buf, i32x8 (&fa)[MT]) {
+        const char* a = smem + buf * STAGE;
+#pragma unroll
+        for (int mi = 0; mi < MT; mi++) {
+            const int r = wm0 + mi * 16 + li;
+            fa[mi] = frag(a + r * KB, (r >> 1) & 7);
+        }
+    };
+    auto read_w = [&](int buf, int ni) -> i32x8 {
+        const char* b = smem + buf * STAGE + BM * KB;
+        const int r = wrow[ni];
+        return frag(b + r * KB, wsw(r));
+    };
+    auto mfma_col = [&](const i32x8 (&fa)[MT], const i32x8& fw, int ni) {
+#pragma unroll
+        for (int mi = 0; mi < MT; mi++)
+            acc[ni][mi] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(fw, fa[mi], acc[ni][mi], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+    };
+    // K loop: tile kt lives in buffer kt & 1.  Top of a tile: my DMA share of it has landed (vmcnt(0)), the barrier publishes
+    // it and tells that every wave is done reading the other buffer, whose refill with tile kt+1 starts right away; the
+    // fragment reads of the tile start behind the barrier (their latency is covered by the co-resident block's waves: the
+    // double-buffered register version of gemm_v3_kernel's schedule needs two 32-register A-fragment sets and spilled).
+    i32x8 fa[MT], fw01[2], fw24[3];
+    issue(0, 0);
+    for (int kt = 0; kt < nk; kt++) {
+        const int buf = kt & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (kt + 1 < nk) issue(kt + 1, buf ^ 1);
+        read_a(buf, fa);
+        fw01[0] = read_w(buf, 0);
+        fw01[1] = read_w(buf, 1);
+        fw24[0] = read_w(buf, 2);
+        fw24[1] = read_w(buf, 3);
+        fw24[2] = read_w(buf, 4);
+        mfma_col(fa, fw01[0], 0);
+        mfma_col(fa, fw01[1], 1);
+        mfma_col(fa, fw24[0], 2);
+        mfma_col(fa, fw24[1], 3);
+        mfma_col(fa, fw24[2], 4);
+    }
+    // (the bias is fetched here, not before the loop as in gemm_v3_kernel: its 24 registers would spill the two A-fragment sets)
+    EpiPre<NT> pre;
+    epilogue_prefetch<NT>(p, pre, n0 + wn0, lg);
+    // per-output-channel dequantisation scale (accumulator layout: see gemm_v3_kernel's split-K store)
+#pragma unroll
+    for (int ni = 0; ni < NT; ni++) {
+        const bool paired = (ni | 1) < NT;
+        const int nb = n0 + wn0 + (paired ? 32 * (ni >> 1) + lg * 8 + (ni & 1) * 4 : 16 * ni + lg * 4);
+        const f32x4 sc = *reinterpret_cast<const f32x4*>(p.wscale + nb);
+#pragma unroll
+        for (int mi = 0; mi < MT; mi++) acc[ni][mi] *= sc;
+    }
+    if (!(p.flags & (F_OUT_F32 | F_ACCUM))) {
+        constexpr int LDR = BN + 8;
+        bf16* ring = reinterpret_cast<bf16*>(smem);
+        __syncthreads();
+        gemm_epilogue<MT, NT>(p, acc, m0 + wm0, n0 + wn0, li, lg, pre, ring, m0, n0, LDR);
+        __syncthreads();
+        gemm_store_rows<BM, BN>(p, ring, m0, n0, LDR, tid);
+        return;
+    }
+    gemm_epilogue<MT, NT, false>(p, acc, m0 + wm0, n0 + wn0, li, lg, pre);
+}
+
+static int launch_gemm_mx8(const GemmParams& p, hipStream_t s) {
+    const int tiles = ((p.M + 127) / 128) * (p.N / 160);
+    const size_t lds = (size_t)2 * (128 + 160) * 128;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_mx8_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_done = true;
+    }
+    GemmParams q = p;
+    q.group_m = 4;
+    hipLaunchKernelGGL(gemm_mx8_kernel, dim3(tiles), dim3(NTHREADS), lds, s, q);
     return sidlsg_last_error();
 }
 
@@ -2130,6 +2302,41 @@ int sidlsg_gemm_fp8w(const void* A, int lda, const void* W8, const float* wscale
     p.a_bytes = (unsigned)ab; p.w_bytes = (unsigned)wb;
     const int tiles = ((M + F8_T - 1) / F8_T) * ((N + F8_T - 1) / F8_T);
     hipLaunchKernelGGL((gemm_fp8w_kernel<0>), dim3(tiles), dim3(NTHREADS), 0, (hipStream_t)stream, p);
+    return sidlsg_last_error();
+}
+
+int sidlsg_gemm_mx8(const void* A8, int lda, const void* W8, const float* wscale, void* C, int ldc, const float* bias, const void* res,
+                    int ldres, const float* rowvec, int ld_rowvec, int rows_per_batch, int M, int N, int K, float alpha,
+                    int flags, void* stream) {
+    GemmParams p{};
+    p.A = (const bf16*)A8; p.W = (const bf16*)W8; p.wscale = wscale; p.C = C; p.bias = bias; p.res = (const bf16*)res; p.rowvec = rowvec;
+    p.ldrv = ld_rowvec > 0 ? ld_rowvec : N;
+    p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldc = ldc; p.ldres = ldres; p.rows_per_batch = rows_per_batch;
+    p.alpha = alpha; p.flags = flags;
+    if (M <= 0 || N <= 0 || K <= 0 || !A8 || !W8 || !C || !wscale) return SIDLSG_EINVAL;
+    if ((K & 15) || (lda & 15) || (N % 160) || lda < K) return SIDLSG_EINVAL;
+    if (rowvec && rows_per_batch <= 0) return SIDLSG_EINVAL;
+    if ((flags & F_ACCUM) && !(flags & F_OUT_F32)) return SIDLSG_EINVAL;
+    const unsigned long long ab = (unsigned long long)(M - 1) * lda + K, wb = (unsigned long long)N * K;
+    if (!fits31(ab) || !fits31(wb)) return SIDLSG_EINVAL;
+    p.a_bytes = (unsigned)ab; p.w_bytes = (unsigned)wb;
+    return launch_gemm_mx8(p, (hipStream_t)stream);
+}
+
+__global__ __launch_bounds__(256) void cast_fp8_kernel(const bf16* __restrict__ src, unsigned char* __restrict__ dst, size_t n8) {
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += stride) {
+        const bf16x8 v = *reinterpret_cast<const bf16x8*>(src + i * 8);
+        u32x2 q = {cvt4_fp8(bf2f(v[0]), bf2f(v[1]), bf2f(v[2]), bf2f(v[3])), cvt4_fp8(bf2f(v[4]), bf2f(v[5]), bf2f(v[6]), bf2f(v[7]))};
+        *reinterpret_cast<u32x2*>(dst + i * 8) = q;
+    }
+}
+int sidlsg_cast_fp8(const void* src_bf16, void* dst_fp8, long long n, void* stream) {
+    if (!src_bf16 || !dst_fp8 || n <= 0 || (n & 7)) return SIDLSG_EINVAL;
+    const size_t n8 = (size_t)n / 8;
+    size_t blocks = (n8 + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(cast_fp8_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const bf16*)src_bf16, (unsigned char*)dst_fp8, n8);
     return sidlsg_last_error();
 }
 

@@ -98,7 +98,7 @@ DEVFN void gn_fold_partials(const float* __restrict__ p, const GnGeom& g, float*
     __syncthreads();
 }
 
-template <typename T>
+template <typename T, bool F8 = false>      // F8: y receives e4m3 bytes (same [B][HW][C] geometry)
 __global__ void gn_apply_kernel(const T* __restrict__ x, const float* __restrict__ part,
                                 const float* __restrict__ gamma, const float* __restrict__ beta,
                                 T* __restrict__ y, float* __restrict__ stats, GnGeom g, float eps, int act) {
@@ -140,7 +140,7 @@ __global__ void gn_apply_kernel(const T* __restrict__ x, const float* __restrict
                 if (act) f = silu_t<T>(f);
                 v[u][e] = f;
             }
-            stv8<T>(y + base + (size_t)(p + u * g.rows) * g.C, v[u]);
+            st8_out<T, F8>(y, base + (size_t)(p + u * g.rows) * g.C, v[u]);
         }
     }
     for (; p < p1; p += g.rows) {
@@ -152,7 +152,7 @@ __global__ void gn_apply_kernel(const T* __restrict__ x, const float* __restrict
             if (act) f = silu_t<T>(f);
             v[e] = f;
         }
-        stv8<T>(y + base + (size_t)p * g.C, v);
+        st8_out<T, F8>(y, base + (size_t)p * g.C, v);
     }
 }
 
@@ -306,7 +306,7 @@ static dim3 reduce_grid(int n, int P) {
 // the first reduction).  (The generic 4-chunk version held 160 VGPRs and one row per wave in flight: 2.8 TB/s.)
 constexpr int LN_MAXCH = 4;   // chunks of 8 per lane -> C <= 2048
 
-template <typename T, int NCH, int R>
+template <typename T, int NCH, int R, bool F8 = false>      // F8: y receives e4m3 bytes
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, T* __restrict__ y,
                                                      float* __restrict__ stats, int rows, int C, float eps, int rpw) {
@@ -375,7 +375,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
                     float o[8];
 #pragma unroll
                     for (int e = 0; e < 8; e++) o[e] = (v[r][i][e] - mean[r]) * rstd[r] * ga[i][e] + be[i][e];
-                    stv8<T>(y + (size_t)row * C + cc * 8, o);
+                    st8_out<T, F8>(y, (size_t)row * C + cc * 8, o);
                 }
             }
         }
@@ -510,7 +510,7 @@ int sidlsg_groupnorm_nchunks(int B, int HW, int C, int G) {
 }  // extern "C" (reopened below)
 
 // y = act(GroupNorm(x)); x,y: [B][HW][C]; stats: [B][G][2] fp32 (mean, rstd) saved for backward
-template <typename T>
+template <typename T, bool F8 = false>
 static int groupnorm_fwd_t(const void* x, const float* gamma, const float* beta, void* y, float* stats, float* ws,
                            int B, int HW, int C, int G, float eps, int silu, void* stream) {
     GnGeom g; if (int e = gn_geom(g, B, HW, C, G)) return e;
@@ -518,7 +518,7 @@ static int groupnorm_fwd_t(const void* x, const float* gamma, const float* beta,
     const int threads = g.C8 * g.rows;
     hipLaunchKernelGGL(gn_stats_kernel<T>, dim3(g.nch, B), dim3(threads), (size_t)g.rows * C * 2 * sizeof(float), s,
                        (const T*)x, ws, g);
-    hipLaunchKernelGGL(gn_apply_kernel<T>, dim3(g.nch, B), dim3(threads), (size_t)2 * G * (1 + GN_FOLD) * sizeof(float), s,
+    hipLaunchKernelGGL((gn_apply_kernel<T, F8>), dim3(g.nch, B), dim3(threads), (size_t)2 * G * (1 + GN_FOLD) * sizeof(float), s,
                        (const T*)x, ws, gamma, beta, (T*)y, stats, g, eps, silu);
     return sidlsg_last_error();
 }
@@ -543,7 +543,7 @@ static int groupnorm_bwd_t(const void* x, const void* dy, const float* stats, co
 }
 
 // y = LayerNorm(x) over C; x,y [rows][C]; stats [rows][2]
-template <typename T>
+template <typename T, bool F8 = false>
 static int layernorm_fwd_t(const void* x, const float* gamma, const float* beta, void* y, float* stats, int rows, int C,
                            float eps, void* stream) {
     if (C % 8 || C > 8 * 64 * LN_MAXCH || rows <= 0) return SIDLSG_EINVAL;
@@ -552,7 +552,7 @@ static int layernorm_fwd_t(const void* x, const float* gamma, const float* beta,
     // rows per wave: enough waves to fill the chip (>= ~4096), at most 16 rows (amortises the gamma/beta loads)
     int rpw = rows / 4096; rpw = rpw < R ? R : (rpw > 16 ? 16 : rpw); rpw = (rpw + R - 1) / R * R;
     const dim3 grid((rows + 4 * rpw - 1) / (4 * rpw));
-#define LN_FWD(NCH, RR) hipLaunchKernelGGL((ln_fwd_kernel<T, NCH, RR>), grid, dim3(256), 0, (hipStream_t)stream, (const T*)x, gamma, \
+#define LN_FWD(NCH, RR) hipLaunchKernelGGL((ln_fwd_kernel<T, NCH, RR, F8>), grid, dim3(256), 0, (hipStream_t)stream, (const T*)x, gamma, \
                                            beta, (T*)y, stats, rows, C, eps, rpw)
     if (nch == 1) LN_FWD(1, 4); else if (nch == 2) LN_FWD(2, 2); else if (nch == 3) LN_FWD(3, 2); else LN_FWD(4, 2);
 #undef LN_FWD
@@ -599,6 +599,14 @@ SIDLSG_BOTH(sidlsg_layernorm_fwd, layernorm_fwd_t,
             (const void* x, const float* gamma, const float* beta, void* y, float* stats, int rows, int C, float eps, void* stream),
             (x, gamma, beta, y, stats, rows, C, eps, stream))
 int sidlsg_layernorm_bwd_nblocks(int rows) { return layernorm_bwd_nblocks(rows); }
+// e4m3 outputs (bf16 inputs): y8 holds rows * C (B * HW * C) bytes
+int sidlsg_layernorm_fwd_fp8(const void* x, const float* gamma, const float* beta, void* y8, float* stats, int rows, int C, float eps, void* stream) {
+    return layernorm_fwd_t<bf16, true>(x, gamma, beta, y8, stats, rows, C, eps, stream);
+}
+int sidlsg_groupnorm_fwd_fp8(const void* x, const float* gamma, const float* beta, void* y8, float* stats, float* ws, int B, int HW, int C, int G,
+                             float eps, int silu, void* stream) {
+    return groupnorm_fwd_t<bf16, true>(x, gamma, beta, y8, stats, ws, B, HW, C, G, eps, silu, stream);
+}
 SIDLSG_BOTH(sidlsg_layernorm_bwd, layernorm_bwd_t,
             (const void* x, const void* dy, const float* stats, const float* gamma, const void* dres, void* dx, float* dgamma, float* dbeta, float* ws, int rows, int C, void* stream),
             (x, dy, stats, gamma, dres, dx, dgamma, dbeta, ws, rows, C, stream))

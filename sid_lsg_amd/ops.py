@@ -482,6 +482,101 @@ def layer_norm(x, gamma, beta, eps=1e-5, fork=False):
     return _LayerNorm.apply(x, gamma, beta, eps, fork)
 
 
+def gemm_mx8(a8, w8, out=None, bias=None, res=None, out_f32=False):
+    """C[M,N] = wscale[n] * A8[M,K] W8[N,K]^T + bias + res with BOTH operands e4m3 (sidlsg_gemm_mx8: MX MFMA).
+    a8: uint8 [M,K] e4m3 bytes at unit scale; w8: Fp8Weight with N % 160 == 0."""
+    if not isinstance(w8, Fp8Weight) or a8.dtype != torch.uint8:
+        raise RuntimeError('gemm_mx8: e4m3 activations (uint8) and an Fp8Weight')
+    M, K = a8.shape
+    N = w8.shape[0]
+    if out is None:
+        out = torch.empty((M, N), device=a8.device, dtype=F32 if out_f32 else BF16)
+    lib.sidlsg_gemm_mx8(_p(a8), a8.stride(0), _p(w8.q), _p(w8.scale), _p(out), out.stride(0), _p(bias), _p(res),
+                        res.stride(0) if res is not None else 0, None, 0, 1, M, N, K, 1.0, 1 if out_f32 else 0, _s())
+    return out
+
+
+def cast_fp8(x):
+    """bf16 [.., K] -> e4m3 bytes (uint8, same shape): clamp to +-448, round to nearest even, unit scale."""
+    _chk(x, BF16)
+    y = torch.empty(x.shape, device=x.device, dtype=torch.uint8)
+    lib.sidlsg_cast_fp8(_p(x), _p(y), x.numel(), _s())
+    return y
+
+
+def mx8_ok(w):
+    """Can this forward weight take e4m3 activations through sidlsg_gemm_mx8?"""
+    return isinstance(w, Fp8Weight) and w.shape[0] % 160 == 0 and w.shape[1] % 16 == 0
+
+
+class _NormLinearMX8(torch.autograd.Function):
+    """FROZEN networks with e4m3 weights: y = Linear(Norm(x)) as ONE autograd node -- the GroupNorm / LayerNorm kernel writes
+    its output as e4m3 bytes (half the bytes of the bf16 output it replaces), the contraction runs on the MX-fp8 MFMA
+    (sidlsg_gemm_mx8).  One node because the e4m3 intermediate is an integer tensor autograd cannot carry.  Backward (the data
+    gradient the generator's update needs through the frozen networks): dnorm_out = dy W through the bf16 backward-data
+    operand, then the ordinary norm backward on the saved input.  fork: as in _GroupNorm / _LayerNorm."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps, groups, silu, fork, w8, bias, w16t, weight):
+        _chk(x, BF16)
+        if _wants_grad(weight) or _wants_grad(gamma):
+            raise RuntimeError('the MX-fp8 path is for frozen networks')
+        C = x.shape[-1]
+        y8 = torch.empty(x.shape, device=x.device, dtype=torch.uint8)
+        if groups:
+            B = x.shape[0]
+            HW = x.numel() // (B * C)
+            n = lib.sidlsg_groupnorm_ws_floats.raw(B, HW, C, groups)
+            if n < 0:
+                raise RuntimeError(f'groupnorm: unsupported shape B={B} HW={HW} C={C} G={groups}')
+            ws = torch.empty(n, device=x.device, dtype=F32)
+            stats = torch.empty((B, groups, 2), device=x.device, dtype=F32)
+            lib.sidlsg_groupnorm_fwd_fp8(_p(x), _p(gamma), _p(beta), _p(y8), _p(stats), _p(ws), B, HW, C, groups, float(eps), int(silu), _s())
+            ctx.cfg = (B, HW, C, groups, int(silu), n)
+        else:
+            rows = x.numel() // C
+            stats = torch.empty((rows, 2), device=x.device, dtype=F32)
+            lib.sidlsg_layernorm_fwd_fp8(_p(x), _p(gamma), _p(beta), _p(y8), _p(stats), rows, C, float(eps), _s())
+            ctx.cfg = None
+        y = gemm_mx8(y8.view(-1, C), w8, bias=bias)
+        ctx.save_for_backward(x, gamma, beta, stats, w16t)
+        if fork:
+            return y, x.view(x.shape)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy, dkeep=None):
+        x, gamma, beta, stats, w16t = ctx.saved_tensors
+        none = (None,) * 10
+        if dy is None:
+            return (dkeep,) + none
+        dy = dy.contiguous()
+        if dy.dtype != BF16:
+            dy = dy.to(BF16)
+        dn = gemm(dy, w16t)                                        # gradient at the norm's output, [M, C]
+        if dkeep is not None:
+            dkeep = dkeep.contiguous()
+            if dkeep.dtype != BF16:
+                dkeep = dkeep.to(BF16)
+        dx = torch.empty_like(x)
+        C = x.shape[-1]
+        if ctx.cfg is not None:
+            B, HW, C, groups, silu, n = ctx.cfg
+            ws = torch.empty(n, device=x.device, dtype=F32)
+            lib.sidlsg_groupnorm_bwd(_p(x), _p(dn), _p(stats), _p(gamma), _p(beta), _p(dkeep) if dkeep is not None else None, _p(dx),
+                                     None, None, _p(ws), B, HW, C, groups, silu, _s())
+        else:
+            rows = x.numel() // C
+            lib.sidlsg_layernorm_bwd(_p(x), _p(dn), _p(stats), _p(gamma), _p(dkeep) if dkeep is not None else None, _p(dx), None, None, None,
+                                     rows, C, _s())
+        return (dx,) + none
+
+
+def norm_linear_mx8(x, gamma, beta, eps, w8, bias, w16t, weight, groups=0, silu=False, fork=False):
+    """Linear(GroupNorm(x)) (groups > 0) or Linear(LayerNorm(x)) (groups = 0) for a frozen network, e4m3 in between."""
+    return _NormLinearMX8.apply(x, gamma, beta, eps, groups, silu, fork, w8, bias, w16t, weight)
+
+
 class _Attention(torch.autograd.Function):
     """q: [B,Nq,*] view with heads*D channels starting at column qoff of a row of width ldq; same for k, v."""
 

@@ -187,3 +187,101 @@ def test_fp8_policy_keeps_unnormalised_inputs_in_bf16(dev):
     assert 0 < out['normalized'][1] < out['all'][1]
     with pytest.raises(ValueError):
         U.HipUNet2DCondition(cfg).materialize(dev, seed=3, with_grad_buffers=False).requires_grad_(False).enable_fp8_weights('some')
+
+
+@pytest.mark.parametrize('M,N,K', [(300, 160, 128), (1232, 640, 768), (4096, 960, 320), (2048, 320, 1280), (130, 480, 48)])
+def test_gemm_mx8_contract(dev, M, N, K):
+    """sidlsg_gemm_mx8: both operands e4m3 on the MX MFMA (unit block scales), per-output-channel weight scale in the epilogue.
+    Exact to its contract: fp64 on the SAME quantised operands, up to the fp32 accumulation order and the bf16 output
+    rounding (2^-9 relative).  Ragged M and K tails (K = 320, 48: the last 128-byte K-tile is partly past the row)."""
+    from sid_lsg_amd import ops
+    g = torch.Generator().manual_seed(M + N + K)
+    a = torch.randn(M, K, generator=g).to(dev).to(BF16)
+    w = (torch.randn(N, K, generator=g) * 0.05).to(dev).to(BF16)
+    bias = torch.randn(N, generator=g).to(dev)
+    res = torch.randn(M, N, generator=g).to(dev).to(BF16)
+    a8 = ops.cast_fp8(a)
+    # the cast: round to nearest within half an e4m3 ulp (2^-4 relative for normals), saturating at +-448
+    av, a8v = a.float(), a8.view(torch.float8_e4m3fn).float()
+    assert float(((a8v - av).abs() / av.abs().clamp_min(2.0 ** -6)).max()) <= 2.0 ** -4 + 1e-6
+    big = ops.cast_fp8(torch.tensor([[1e4, -1e4, 448.0, -500.0, 0.0, 1.0, -1.0, 3e38]], device=dev, dtype=BF16)).view(torch.float8_e4m3fn).float()
+    assert big.tolist() == [[448.0, -448.0, 448.0, -448.0, 0.0, 1.0, -1.0, 448.0]]
+    w8 = ops.Fp8Weight(w)
+    ref = a8v.double() @ w8.dequantize().double().t() + bias.double()
+    got = ops.gemm_mx8(a8, w8, bias=bias, out_f32=True)
+    assert float((got.double() - ref).abs().max()) <= 2e-5 * float(ref.abs().max()) * max(1.0, (K / 256) ** 0.5)
+    got16 = ops.gemm_mx8(a8, w8, bias=bias, res=res)
+    ref16 = ref + res.double()
+    assert float((got16.double() - ref16).abs().max()) <= 2.0 ** -8 * float(ref16.abs().max())
+    with pytest.raises(RuntimeError):
+        ops.gemm_mx8(a8, ops.Fp8Weight(torch.zeros(128, K, device=dev, dtype=BF16)))        # N % 160
+
+
+def test_norm_linear_mx8_matches_the_unfused_ops(dev):
+    """ops.norm_linear_mx8 (norm writes e4m3, MX GEMM, one autograd node) against the same computation spelled out: forward
+    = gemm_mx8(cast_fp8(norm(x))) up to the rounding of the bf16 intermediate the fused op does not have; backward = the
+    plain norm + linear backward (bf16 backward-data operand), fork gradient included."""
+    from sid_lsg_amd import ops
+    g = torch.Generator().manual_seed(5)
+    for groups, shape, N in ((0, (512, 320), 960), (32, (2, 16, 16, 320), 320)):
+        C = shape[-1]
+        x = torch.randn(*shape, generator=g).to(dev).to(BF16)
+        gamma, beta = (1 + 0.2 * torch.randn(C, generator=g)).to(dev), (0.1 * torch.randn(C, generator=g)).to(dev)
+        weight = (torch.randn(N, C, generator=g) * 0.05).to(dev)
+        w16 = weight.to(BF16)
+        w16t = w16.t().contiguous()
+        bias = torch.randn(N, generator=g).to(dev)
+        w8 = ops.Fp8Weight(w16)
+        dy = torch.randn(x.numel() // C, N, generator=g).to(dev).to(BF16)
+        dk = torch.randn(*shape, generator=g).to(dev).to(BF16)
+        xa = x.clone().requires_grad_()
+        y, keep = ops.norm_linear_mx8(xa, gamma, beta, 1e-5, w8, bias, w16t, weight, groups=groups, silu=False, fork=True)
+        torch.autograd.backward([y, keep], [dy, dk])
+        xb = x.clone().requires_grad_()
+        if groups:
+            hn, keep_b = ops.group_norm(xb, gamma, beta, groups, 1e-5, False, fork=True)
+        else:
+            hn, keep_b = ops.layer_norm(xb, gamma, beta, 1e-5, fork=True)
+        yb8 = ops.gemm_mx8(ops.cast_fp8(hn.detach().view(-1, C)), w8, bias=bias)
+        rel = float((y.detach().float() - yb8.float()).norm() / yb8.float().norm())
+        print(f'groups {groups}: forward deviation fused vs (bf16 norm -> cast -> mx8) {rel:.2e}')
+        assert rel < 2e-2          # double rounding (fp32 -> bf16 -> e4m3) flips a few e4m3 roundings
+        yb = ops.linear(hn.view(-1, C), weight, bias, w16, w16t)
+        torch.autograd.backward([yb, keep_b], [dy, dk])
+        assert torch.equal(xa.grad, xb.grad)                     # the backward IS the bf16 one
+        dev8 = float((y.detach().float() - yb.detach().float()).norm() / yb.detach().float().norm())
+        print(f'groups {groups}: e4m3 x e4m3 projection vs bf16 projection {dev8:.2e}')
+        assert 0 < dev8 < 6e-2
+
+
+def test_fp8_teacher_data_gradient_with_mx8_activations(dev, monkeypatch):
+    """Phase B differentiates THROUGH the frozen teacher (data gradient only).  With e4m3 weights the normalised activations
+    travel as e4m3 too where the shapes allow (tiny40: the 160- and 320-channel stages): output and input gradient must stay
+    close to the bf16 network's, and the MX path must actually be in use (and removable with SIDLSG_MX8=0)."""
+    from sid_lsg_amd import unet as U
+    cfg = U.CONFIGS['tiny40']
+    torch.manual_seed(0)
+    B, lat = 4, 16
+    x = torch.zeros(B, lat, lat, 8, device=dev)
+    x[..., :cfg.in_channels] = torch.randn(B, lat, lat, cfg.in_channels, device=dev)
+    x = x.to(BF16)
+    t = torch.tensor([999, 500, 250, 20], device=dev)
+    ctx = torch.randn(B, cfg.text_len, cfg.cross_attention_dim, device=dev).to(BF16)
+    dy = torch.randn(B, lat * lat, 8, device=dev)
+    res = {}
+    for mode in ('bf16', 'mx8', 'fp8w'):
+        monkeypatch.setenv('SIDLSG_MX8', '0' if mode == 'fp8w' else '1')
+        net = U.HipUNet2DCondition(cfg).materialize(dev, seed=3, with_grad_buffers=False).requires_grad_(False)
+        if mode != 'bf16':
+            net.enable_fp8_weights()
+        n_mx = sum(int(getattr(m, 'mx8', False)) for m in net.modules())
+        xa = x.clone().requires_grad_()
+        y = net.forward_nhwc(xa, t, ctx)
+        y.backward(dy)
+        res[mode] = (y.detach().float(), xa.grad.float(), n_mx)
+    assert res['bf16'][2] == 0 and res['fp8w'][2] == 0 and res['mx8'][2] > 4
+    for mode in ('mx8', 'fp8w'):
+        ry = float((res[mode][0] - res['bf16'][0]).norm() / res['bf16'][0].norm())
+        rg = float((res[mode][1] - res['bf16'][1]).norm() / res['bf16'][1].norm())
+        print(f'{mode}: {res[mode][2]} MX ops; output deviation from bf16 {ry:.3e}, input-gradient deviation {rg:.3e}')
+        assert 0 < ry < 0.15 and 0 < rg < 0.15
