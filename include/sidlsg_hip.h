@@ -188,6 +188,11 @@ int sidlsg_conv3x3_fp8w(const void* X, int ldx, const void* W8, const float* wsc
  * (sidlsg_cast_fp8 converts a bf16 matrix: clamp to +-448, round to nearest even); W8 / wscale as above.  N % 160 == 0,
  * K % 16 == 0, lda % 16 == 0; the epilogue arguments are those of sidlsg_gemm_bf16. */
 int sidlsg_cast_fp8(const void* src_bf16, void* dst_fp8, long long n, void* stream);
+/* conv3x3, pad 1, stride 1 on an e4m3 NHWC image (X8: [B][H][Wd][ldx] bytes); W8: [Cout][9 * Cin] e4m3; Cin % 16 == 0,
+ * Cout % 160 == 0; rowvec: the per-image row vector (time-embedding broadcast), one row per image. */
+int sidlsg_conv3x3_mx8(const void* X8, int ldx, const void* W8, const float* wscale, void* Y, int ldc, const float* bias, const void* res,
+                       int ldres, const float* rowvec, int ld_rowvec, int B, int H, int Wd, int Cin, int Cout, float alpha, int flags,
+                       void* stream);
 int sidlsg_layernorm_fwd_fp8(const void* x, const float* gamma, const float* beta, void* y8, float* stats, int rows, int C,
                              float eps, void* stream);
 int sidlsg_groupnorm_fwd_fp8(const void* x, const float* gamma, const float* beta, void* y8, float* stats, float* ws, int B,

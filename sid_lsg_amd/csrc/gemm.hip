@@ -1120,6 +1120,7 @@ static int launch_gemm_v3(const GemmParams& p, hipStream_t s) {
 typedef int i32x8 __attribute__((ext_vector_type(8)));
 typedef int i32x4v __attribute__((ext_vector_type(4)));
 
+template <int MODE>      // 0: dense rows.  1: conv3x3, pad 1, stride 1, no upsampling, Cin % 16 == 0 (NHWC e4m3 image)
 __global__ __launch_bounds__(NTHREADS, 2) void gemm_mx8_kernel(GemmParams p) {
     constexpr int BM = 128, BN = 160, MT = 4, NT = 5, KB = 128;      // KB: bytes (= e4m3 elements) per K-tile
     constexpr int STAGE = (BM + BN) * KB;                            // bytes
@@ -1148,15 +1149,39 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_mx8_kernel(GemmParams p) {
     const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 80;
     const int li = lane & 15, lg = lane >> 4;
     const int lrow = lane >> 3, lslot = lane & 7;
-    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(A8), 0, (int)p.a_bytes, 0x00020000);
+    // conv: K-tiles in the order "channel chunk outer, tap inner" with the tap as a wave-uniform soffset against a buffer base one
+    // row + one pixel below the image and a 9-bit halo mask per row (see gemm_v3_kernel).  A chunk is 128 channels of one tap;
+    // when Cin is not a multiple of 128 (320: 128 + 128 + 64) the lanes whose 16 channels lie past Cin read zeros from A -- W's
+    // over-read then meets zeros (it runs into the next tap's weights, finite numbers; past the matrix the buffer returns zeros).
+    const unsigned tap_rs = (unsigned)p.Wd * (unsigned)p.lda, tap_ps = (unsigned)p.lda;
+    const unsigned shift = MODE == 1 ? tap_rs + tap_ps : 0u;
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(A8) - shift, 0, (int)(p.a_bytes + shift), 0x00020000);
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(W8), 0, (int)p.w_bytes, 0x00020000);
     unsigned aoff[4], boff[5];
+    unsigned cen[4], tmask[4], akb[4];
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         const int r = wave * 32 + j * 8 + lrow;
         const int kcs = lslot ^ ((r >> 1) & 7);
         const int m = m0 + r;
         aoff[j] = m < p.M ? (unsigned)m * (unsigned)p.lda + kcs * 16u : OOB;
+        cen[j] = tmask[j] = akb[j] = 0;
+        if (MODE == 1) {
+            const bool ok = m < p.M;
+            const int mm = ok ? m : 0, hw = p.H * p.Wd;
+            const int b = mm / hw, rem = mm - b * hw;
+            const int ho = rem / p.Wd, wo = rem - ho * p.Wd;
+            cen[j] = (unsigned)((b * p.H + ho) * p.Wd + wo) * (unsigned)p.lda + kcs * 16u;
+            akb[j] = kcs * 16u;
+            unsigned mk = 0;
+#pragma unroll
+            for (int tp = 0; tp < 9; tp++) {
+                const int hi = ho - 1 + tp / 3, wi = wo - 1 + tp % 3;
+                if (ok && hi >= 0 && hi < p.H && wi >= 0 && wi < p.Wd) mk |= 1u << tp;
+            }
+            tmask[j] = mk;
+            aoff[j] = OOB;
+        }
     }
 #pragma unroll
     for (int j = 0; j < 5; j++) {
@@ -1164,10 +1189,24 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_mx8_kernel(GemmParams p) {
         const int kcs = lslot ^ wsw(r);
         boff[j] = (unsigned)(n0 + r) * (unsigned)p.K + kcs * 16u;       // N % 160 == 0: every row exists
     }
-    const int nk = (p.K + KB - 1) / KB;
+    const int nch = (p.Cin + KB - 1) / KB;                          // conv: 128-channel chunks per tap
+    const int nk = MODE == 1 ? 9 * nch : (p.K + KB - 1) / KB;
     auto issue = [&](int t, int buf) {          // 9 buffer_load ... lds per wave
         char* sa = smem + buf * STAGE;
         char* sb = sa + BM * KB;
+        if (MODE == 1) {
+            const int cc = t / 9, tap = t - cc * 9;
+            const int dh = tap / 3, dw = tap - dh * 3;
+            const unsigned sa_off = (unsigned)cc * KB + dh * tap_rs + dw * tap_ps;
+            const unsigned sw_off = (unsigned)(tap * p.Cin + cc * KB);
+            const unsigned lim = (unsigned)(p.Cin - cc * KB), bit = 1u << tap;
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lptr_t)(sa + (wave * 32 + j * 8) * KB), 16, ((tmask[j] & bit) && akb[j] < lim) ? cen[j] : OOB, sa_off, 0, 0);
+#pragma unroll
+            for (int j = 0; j < 5; j++) __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lptr_t)(sb + (wave + 4 * j) * 8 * KB), 16, boff[j], sw_off, 0, 0);
+            return;
+        }
         const int k0 = t * KB;
         if (k0 + KB > p.K) {                    // ragged K tail: chunks past K read zeros
 #pragma unroll
@@ -1269,17 +1308,18 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_mx8_kernel(GemmParams p) {
     gemm_epilogue<MT, NT, false>(p, acc, m0 + wm0, n0 + wn0, li, lg, pre);
 }
 
+template <int MODE>
 static int launch_gemm_mx8(const GemmParams& p, hipStream_t s) {
     const int tiles = ((p.M + 127) / 128) * (p.N / 160);
     const size_t lds = (size_t)2 * (128 + 160) * 128;
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_mx8_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_mx8_kernel<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done = true;
     }
     GemmParams q = p;
     q.group_m = 4;
-    hipLaunchKernelGGL(gemm_mx8_kernel, dim3(tiles), dim3(NTHREADS), lds, s, q);
+    hipLaunchKernelGGL((gemm_mx8_kernel<MODE>), dim3(tiles), dim3(NTHREADS), lds, s, q);
     return sidlsg_last_error();
 }
 
@@ -2320,7 +2360,26 @@ int sidlsg_gemm_mx8(const void* A8, int lda, const void* W8, const float* wscale
     const unsigned long long ab = (unsigned long long)(M - 1) * lda + K, wb = (unsigned long long)N * K;
     if (!fits31(ab) || !fits31(wb)) return SIDLSG_EINVAL;
     p.a_bytes = (unsigned)ab; p.w_bytes = (unsigned)wb;
-    return launch_gemm_mx8(p, (hipStream_t)stream);
+    return launch_gemm_mx8<0>(p, (hipStream_t)stream);
+}
+
+int sidlsg_conv3x3_mx8(const void* X8, int ldx, const void* W8, const float* wscale, void* Y, int ldc, const float* bias, const void* res,
+                       int ldres, const float* rowvec, int ld_rowvec, int B, int H, int Wd, int Cin, int Cout, float alpha, int flags,
+                       void* stream) {
+    if (B <= 0 || H <= 0 || Wd <= 0 || Cin <= 0 || Cout <= 0 || !X8 || !W8 || !Y || !wscale) return SIDLSG_EINVAL;
+    if ((Cin & 15) || (ldx & 15) || (Cout % 160) || ldx < Cin) return SIDLSG_EINVAL;
+    if ((flags & F_ACCUM) && !(flags & F_OUT_F32)) return SIDLSG_EINVAL;
+    GemmParams p{};
+    p.A = (const bf16*)X8; p.W = (const bf16*)W8; p.wscale = wscale; p.C = Y; p.bias = bias; p.res = (const bf16*)res; p.rowvec = rowvec;
+    p.ldrv = ld_rowvec > 0 ? ld_rowvec : Cout;
+    p.M = B * H * Wd; p.N = Cout; p.K = 9 * Cin; p.lda = ldx; p.ldc = ldc; p.ldres = ldres; p.rows_per_batch = H * Wd;
+    p.H = H; p.Wd = Wd; p.Cin = Cin; p.Ho = H; p.Wo = Wd; p.stride = 1; p.ups = 0;
+    p.alpha = alpha; p.flags = flags;
+    const unsigned long long ab = ((unsigned long long)B * H * Wd - 1) * ldx + Cin + (unsigned long long)(Wd + 1) * ldx;
+    const unsigned long long wb = (unsigned long long)Cout * 9 * Cin;
+    if (!fits31(ab) || !fits31(wb)) return SIDLSG_EINVAL;
+    p.a_bytes = (unsigned)(ab - (unsigned long long)(Wd + 1) * ldx); p.w_bytes = (unsigned)wb;
+    return launch_gemm_mx8<1>(p, (hipStream_t)stream);
 }
 
 __global__ __launch_bounds__(256) void cast_fp8_kernel(const bf16* __restrict__ src, unsigned char* __restrict__ dst, size_t n8) {

@@ -496,6 +496,18 @@ def gemm_mx8(a8, w8, out=None, bias=None, res=None, out_f32=False):
     return out
 
 
+def conv3x3_mx8(x8, w8, bias=None, res=None, rowvec=None, out_f32=False):
+    """3x3 conv, pad 1, stride 1, on an e4m3 NHWC image x8 [B,H,W,Cin] (uint8) with an Fp8Weight [Cout, 9*Cin] (Cout % 160 == 0)."""
+    if not isinstance(w8, Fp8Weight) or x8.dtype != torch.uint8:
+        raise RuntimeError('conv3x3_mx8: e4m3 activations (uint8) and an Fp8Weight')
+    B, H, W, Cin = x8.shape
+    Cout = w8.shape[0]
+    out = torch.empty((B, H, W, Cout), device=x8.device, dtype=F32 if out_f32 else BF16)
+    lib.sidlsg_conv3x3_mx8(_p(x8), x8.stride(2), _p(w8.q), _p(w8.scale), _p(out), Cout, _p(bias), _p(res), res.stride(2) if res is not None else 0,
+                           _p(rowvec), rowvec.stride(0) if rowvec is not None else 0, B, H, W, Cin, Cout, 1.0, 1 if out_f32 else 0, _s())
+    return out
+
+
 def cast_fp8(x):
     """bf16 [.., K] -> e4m3 bytes (uint8, same shape): clamp to +-448, round to nearest even, unit scale."""
     _chk(x, BF16)
@@ -570,6 +582,59 @@ class _NormLinearMX8(torch.autograd.Function):
             lib.sidlsg_layernorm_bwd(_p(x), _p(dn), _p(stats), _p(gamma), _p(dkeep) if dkeep is not None else None, _p(dx), None, None, None,
                                      rows, C, _s())
         return (dx,) + none
+
+
+class _NormConvMX8(torch.autograd.Function):
+    """FROZEN networks: y = conv3x3(SiLU(GroupNorm(x))) + bias + rowvec (+ res) as one autograd node with the e4m3 image in
+    between (see _NormLinearMX8).  Backward: data gradient of the conv through the bf16 backward-data operand (flipped taps),
+    then the GroupNorm + SiLU backward on the saved input; res receives dy."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps, groups, fork, w8, bias, w16t, weight, res, rowvec):
+        _chk(x, BF16)
+        if _wants_grad(weight) or _wants_grad(gamma):
+            raise RuntimeError('the MX-fp8 path is for frozen networks')
+        B, H, W, C = x.shape
+        HW = H * W
+        n = lib.sidlsg_groupnorm_ws_floats.raw(B, HW, C, groups)
+        if n < 0:
+            raise RuntimeError(f'groupnorm: unsupported shape B={B} HW={HW} C={C} G={groups}')
+        ws = torch.empty(n, device=x.device, dtype=F32)
+        stats = torch.empty((B, groups, 2), device=x.device, dtype=F32)
+        y8 = torch.empty(x.shape, device=x.device, dtype=torch.uint8)
+        lib.sidlsg_groupnorm_fwd_fp8(_p(x), _p(gamma), _p(beta), _p(y8), _p(stats), _p(ws), B, HW, C, groups, float(eps), 1, _s())
+        y = conv3x3_mx8(y8, w8, bias=bias, res=res, rowvec=rowvec)
+        ctx.save_for_backward(x, gamma, beta, stats, w16t)
+        ctx.cfg = (B, HW, C, groups, n, res is not None)
+        if fork:
+            return y, x.view(x.shape)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy, dkeep=None):
+        x, gamma, beta, stats, w16t = ctx.saved_tensors
+        B, HW, C, groups, n, has_res = ctx.cfg
+        if dy is None:
+            return (dkeep,) + (None,) * 11
+        dy = dy.contiguous()
+        if dy.dtype != BF16:
+            dy = dy.to(BF16)
+        dn = conv3x3(dy, w16t)                                     # gradient at the conv's input, [B,H,W,C]
+        if dkeep is not None:
+            dkeep = dkeep.contiguous()
+            if dkeep.dtype != BF16:
+                dkeep = dkeep.to(BF16)
+        dx = torch.empty_like(x)
+        ws = torch.empty(n, device=x.device, dtype=F32)
+        lib.sidlsg_groupnorm_bwd(_p(x), _p(dn), _p(stats), _p(gamma), _p(beta), _p(dkeep) if dkeep is not None else None, _p(dx),
+                                 None, None, _p(ws), B, HW, C, groups, 1, _s())
+        dres = dy if (has_res and ctx.needs_input_grad[10]) else None
+        return (dx,) + (None,) * 9 + (dres, None)
+
+
+def norm_conv_mx8(x, gamma, beta, eps, groups, w8, bias, w16t, weight, res=None, rowvec=None, fork=False):
+    """conv3x3(SiLU(GroupNorm(x))) for a frozen network, e4m3 in between."""
+    return _NormConvMX8.apply(x, gamma, beta, eps, groups, fork, w8, bias, w16t, weight, res, rowvec)
 
 
 def norm_linear_mx8(x, gamma, beta, eps, w8, bias, w16t, weight, groups=0, silu=False, fork=False):

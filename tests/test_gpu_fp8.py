@@ -285,3 +285,29 @@ def test_fp8_teacher_data_gradient_with_mx8_activations(dev, monkeypatch):
         rg = float((res[mode][1] - res['bf16'][1]).norm() / res['bf16'][1].norm())
         print(f'{mode}: {res[mode][2]} MX ops; output deviation from bf16 {ry:.3e}, input-gradient deviation {rg:.3e}')
         assert 0 < ry < 0.15 and 0 < rg < 0.15
+
+
+@pytest.mark.parametrize('B,H,W,cin,cout', [(2, 16, 16, 320, 320), (1, 8, 12, 128, 160), (2, 9, 7, 48, 160), (1, 32, 32, 640, 320)])
+def test_conv3x3_mx8_contract(dev, B, H, W, cin, cout):
+    """sidlsg_conv3x3_mx8: implicit GEMM on an e4m3 NHWC image, K-tiles = 128 channels of one tap (Cin = 320 / 48: the last
+    chunk of every tap is partly past Cin), halo, time-embedding row vector and residual in the epilogue.  fp64 on the same
+    quantised operands."""
+    from sid_lsg_amd import ops
+    g = torch.Generator().manual_seed(B * H + cin + cout)
+    x = torch.randn(B, H, W, cin, generator=g).to(dev).to(BF16)
+    w = (torch.randn(cout, cin, 3, 3, generator=g) * 0.05).to(dev)
+    w16 = w.permute(0, 2, 3, 1).reshape(cout, 9 * cin).to(BF16).contiguous()
+    bias = torch.randn(cout, generator=g).to(dev)
+    rowvec = torch.randn(B, cout, generator=g).to(dev)
+    res = torch.randn(B, H, W, cout, generator=g).to(dev).to(BF16)
+    x8 = ops.cast_fp8(x)
+    w8 = ops.Fp8Weight(w16)
+    wd = w8.dequantize().view(cout, 3, 3, cin).permute(0, 3, 1, 2).double()
+    xin = x8.view(torch.float8_e4m3fn).double().permute(0, 3, 1, 2)
+    ref = torch.nn.functional.conv2d(xin, wd, bias.double(), padding=1).permute(0, 2, 3, 1) + rowvec.double()[:, None, None, :]
+    got = ops.conv3x3_mx8(x8, w8, bias=bias, rowvec=rowvec, out_f32=True)
+    assert got.shape == ref.shape
+    assert float((got.double() - ref).abs().max()) <= 2e-5 * float(ref.abs().max()) * max(1.0, (9 * cin / 256) ** 0.5)
+    got16 = ops.conv3x3_mx8(x8, w8, bias=bias, rowvec=rowvec, res=res)
+    ref16 = ref + res.double()
+    assert float((got16.double() - ref16).abs().max()) <= 2.0 ** -8 * float(ref16.abs().max())
