@@ -1129,17 +1129,22 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_mx8_kernel(GemmParams p) {
     const unsigned char* W8 = reinterpret_cast<const unsigned char*>(p.W);
     const int tiles_n = p.N / BN, tiles_m = (p.M + BM - 1) / BM;
     const int ntile = tiles_n * tiles_m;
+    const int nk_all = MODE == 1 ? 9 * ((p.Cin + KB - 1) / KB) : (p.K + KB - 1) / KB;
+    const int nsplit = p.kt_per_split ? (nk_all + p.kt_per_split - 1) / p.kt_per_split : 1;
     int bid = blockIdx.x;
     {
-        const int q = ntile >> 3, r = ntile & 7, xcd = bid & 7, idx = bid >> 3;
+        const int nblk = ntile * nsplit;
+        const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
+    const int split = bid / ntile;       // split-K (few-tile launches, see launch_gemm_mx8): fp32 slabs + gemm_finish_kernel
     int mt, nt;
     {
+        const int t = bid - split * ntile;
         const int per_group = p.group_m * tiles_n;
-        const int g = bid / per_group, first_m = g * p.group_m;
+        const int g = t / per_group, first_m = g * p.group_m;
         const int gm = min(p.group_m, tiles_m - first_m);
-        const int in_g = bid - g * per_group;
+        const int in_g = t - g * per_group;
         mt = first_m + in_g % gm;
         nt = in_g / gm;
     }
@@ -1189,8 +1194,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_mx8_kernel(GemmParams p) {
         const int kcs = lslot ^ wsw(r);
         boff[j] = (unsigned)(n0 + r) * (unsigned)p.K + kcs * 16u;       // N % 160 == 0: every row exists
     }
-    const int nch = (p.Cin + KB - 1) / KB;                          // conv: 128-channel chunks per tap
-    const int nk = MODE == 1 ? 9 * nch : (p.K + KB - 1) / KB;
+    const int kt_begin = p.kt_per_split ? split * p.kt_per_split : 0;
+    const int nk = p.kt_per_split ? min(nk_all, kt_begin + p.kt_per_split) : nk_all;
     auto issue = [&](int t, int buf) {          // 9 buffer_load ... lds per wave
         char* sa = smem + buf * STAGE;
         char* sb = sa + BM * KB;
@@ -1265,9 +1270,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_mx8_kernel(GemmParams p) {
     // fragment reads of the tile start behind the barrier (their latency is covered by the co-resident block's waves: the
     // double-buffered register version of gemm_v3_kernel's schedule needs two 32-register A-fragment sets and spilled).
     i32x8 fa[MT], fw01[2], fw24[3];
-    issue(0, 0);
-    for (int kt = 0; kt < nk; kt++) {
-        const int buf = kt & 1;
+    issue(kt_begin, 0);
+    for (int kt = kt_begin; kt < nk; kt++) {
+        const int buf = (kt - kt_begin) & 1;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
@@ -1283,6 +1288,20 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_mx8_kernel(GemmParams p) {
         mfma_col(fa, fw24[0], 2);
         mfma_col(fa, fw24[1], 3);
         mfma_col(fa, fw24[2], 4);
+    }
+    if (p.kt_per_split) {                // partial sums (already scaled per channel) -> this split's fp32 slab
+#pragma unroll
+        for (int ni = 0; ni < NT; ni++) {
+            const bool paired = (ni | 1) < NT;
+            const int nb = n0 + wn0 + (paired ? 32 * (ni >> 1) + lg * 8 + (ni & 1) * 4 : 16 * ni + lg * 4);
+            const f32x4 sc = *reinterpret_cast<const f32x4*>(p.wscale + nb);
+#pragma unroll
+            for (int mi = 0; mi < MT; mi++) {
+                const int m = m0 + wm0 + mi * 16 + li;
+                if (m < p.M) *reinterpret_cast<f32x4*>(p.ws + ((size_t)split * p.M + m) * p.N + nb) = acc[ni][mi] * sc;
+            }
+        }
+        return;
     }
     // (the bias is fetched here, not before the loop as in gemm_v3_kernel: its 24 registers would spill the two A-fragment sets)
     EpiPre<NT> pre;
@@ -1319,7 +1338,28 @@ static int launch_gemm_mx8(const GemmParams& p, hipStream_t s) {
     }
     GemmParams q = p;
     q.group_m = 4;
-    hipLaunchKernelGGL((gemm_mx8_kernel<MODE>), dim3(tiles), dim3(NTHREADS), lds, s, q);
+    // few tiles (8x8 / 16x16 stages) and a long contraction: split K so that ~512 blocks exist (as gemm_v3_kernel does)
+    const int nk = MODE == 1 ? 9 * ((p.Cin + 127) / 128) : (p.K + 127) / 128;
+    int splits = 1;
+    const Ws w = ws_for(s);
+    if (tiles < 384 && nk >= 16 && w.ptr && (long long)p.M * p.N * 8 <= w.bytes) {
+        splits = (512 + tiles - 1) / tiles;
+        const long long cap = w.bytes / ((long long)p.M * p.N * 4);
+        if (splits > cap) splits = (int)cap;
+        if (splits > nk / 4) splits = nk / 4;
+        if (splits > 16) splits = 16;
+        if (splits < 2) splits = 1;
+    }
+    if (splits > 1) {
+        q.kt_per_split = (nk + splits - 1) / splits;
+        q.ws = w.ptr;
+        splits = (nk + q.kt_per_split - 1) / q.kt_per_split;
+    }
+    hipLaunchKernelGGL((gemm_mx8_kernel<MODE>), dim3(tiles * splits), dim3(NTHREADS), lds, s, q);
+    if (splits > 1) {
+        const size_t n4 = ((size_t)p.M * p.N + 3) / 4;
+        hipLaunchKernelGGL(gemm_finish_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, q, splits);
+    }
     return sidlsg_last_error();
 }
 

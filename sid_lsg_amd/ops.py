@@ -489,6 +489,7 @@ def gemm_mx8(a8, w8, out=None, bias=None, res=None, out_f32=False):
         raise RuntimeError('gemm_mx8: e4m3 activations (uint8) and an Fp8Weight')
     M, K = a8.shape
     N = w8.shape[0]
+    ensure_workspace(a8.device)
     if out is None:
         out = torch.empty((M, N), device=a8.device, dtype=F32 if out_f32 else BF16)
     lib.sidlsg_gemm_mx8(_p(a8), a8.stride(0), _p(w8.q), _p(w8.scale), _p(out), out.stride(0), _p(bias), _p(res),
@@ -502,6 +503,7 @@ def conv3x3_mx8(x8, w8, bias=None, res=None, rowvec=None, out_f32=False):
         raise RuntimeError('conv3x3_mx8: e4m3 activations (uint8) and an Fp8Weight')
     B, H, W, Cin = x8.shape
     Cout = w8.shape[0]
+    ensure_workspace(x8.device)
     out = torch.empty((B, H, W, Cout), device=x8.device, dtype=F32 if out_f32 else BF16)
     lib.sidlsg_conv3x3_mx8(_p(x8), x8.stride(2), _p(w8.q), _p(w8.scale), _p(out), Cout, _p(bias), _p(res), res.stride(2) if res is not None else 0,
                            _p(rowvec), rowvec.stride(0) if rowvec is not None else 0, B, H, W, Cin, Cout, 1.0, 1 if out_f32 else 0, _s())
