@@ -279,6 +279,15 @@ class SiDStep:
             # 'global' capture mode that call, made by ANOTHER thread, aborts the process ("operation not permitted when
             # stream is capturing"); 'thread_local' confines the check to this thread.  Single-process runs keep 'global'.
             dist_on = torch.distributed.is_available() and torch.distributed.is_initialized()
+            if dist_on:
+                # Let the process group's watchdog retire the collectives of the eager iterations before the capture starts.
+                # They are complete (synchronize above), but the watchdog only drops them on its next pass (every ~100 ms), and
+                # until then it polls their end events -- which this HIP runtime refuses with hipErrorCapturedEvent as soon as
+                # the stream they were recorded on (the backend's own) has joined a capture, taking the process down from the
+                # watchdog thread ("operation not permitted on an event last recorded in a capturing stream"; 1-2 in 10 runs
+                # of tests/test_gpu_dist.py::test_rccl_collectives_inside_the_captured_iteration without this pause).
+                import time
+                time.sleep(0.5)
             try:
                 with torch.cuda.graph(graph, capture_error_mode='thread_local' if dist_on else 'global'):
                     lf, lg = self.iteration(static, ema_beta=ema_beta)
