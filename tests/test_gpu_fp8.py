@@ -4,6 +4,7 @@ The reference has no fp8 mode (sid_training_loop.py:205 knows fp32 / fp16), so t
 kernels are checked EXACTLY against what they are specified to compute -- e4m3 per-row weights, activations converted
 to e4m3 with unit scale, fp32 accumulation -- restated with torch's float8_e4m3fn casts in fp32, and the end-to-end
 deviation of a frozen network from its own bf16 path is bounded and printed."""
+import numpy as np
 import pytest
 import torch
 
@@ -311,3 +312,49 @@ def test_conv3x3_mx8_contract(dev, B, H, W, cin, cout):
     got16 = ops.conv3x3_mx8(x8, w8, bias=bias, rowvec=rowvec, res=res)
     ref16 = ref + res.double()
     assert float((got16.double() - ref16).abs().max()) <= 2.0 ** -8 * float(ref16.abs().max())
+
+
+def test_step_with_fp8_teacher(dev):
+    """BASELINE.json configs[4] end to end at test size: the whole SiD-LSG iteration with an e4m3 teacher (MX-fp8 activations
+    where the shapes allow), including the generator update's backward THROUGH the teacher.  The fake-score phase never sees
+    the teacher (identical losses); the generator loss moves by the teacher's quantisation noise -- phi = psi = G at the start,
+    so (y_real - y_fake) IS that noise in the first iteration: the test checks that the step runs, stays finite and that the
+    generator's update direction largely agrees with the bf16-teacher run."""
+    from sid_lsg_amd.optim import FusedAdamEMA
+    from sid_lsg_amd.scheduler import DDPMScheduler
+    from sid_lsg_amd.sid_step import SiDStep
+    from sid_lsg_amd.unet import CONFIGS, HipUNet2DCondition
+    cfg, lat, b, lr = CONFIGS['tiny40'], 16, 2, 2e-5
+    out = {}
+    for mode in ('bf16', 'fp8'):
+        phi = HipUNet2DCondition(cfg).materialize(dev, seed=1)
+        psi = HipUNet2DCondition(cfg).materialize(dev, seed=2)
+        G, G_ema = HipUNet2DCondition(cfg).materialize(dev, seed=4), None
+        G_ema = G.clone_network(with_grad_buffers=False)
+        g0 = G.flat_params.clone()
+        if mode == 'fp8':
+            phi.requires_grad_(False)
+            assert phi.enable_fp8_weights() > 10 and sum(int(getattr(m, 'mx8', False)) for m in phi.modules()) > 4
+        opt_f = FusedAdamEMA(psi.parameters(), lr=lr, betas=(0.0, 0.999), eps=1e-8)
+        opt_g = FusedAdamEMA(G.parameters(), lr=lr, betas=(0.0, 0.999), eps=1e-8)
+        step = SiDStep(G, psi, phi, G_ema, DDPMScheduler().to(dev), opt_f, opt_g, alpha=1.0, cfg_train_fake=1.5, cfg_eval_fake=1.5,
+                       cfg_eval_real=1.5, batch_gpu_total=b, init_timestep=625)
+        gen = torch.Generator().manual_seed(3)
+        losses = []
+        for it in range(2):
+            inputs = {ph: [dict(z=torch.randn(b, 4, lat, lat, generator=gen).to(dev), noise=torch.randn(b, 4, lat, lat, generator=gen).to(dev),
+                                t=torch.randint(20, 980, (b,), generator=gen).to(dev),
+                                cond=torch.randn(b, cfg.text_len, cfg.cross_attention_dim, generator=gen).to(dev).to(BF16),
+                                uncond=torch.randn(b, cfg.text_len, cfg.cross_attention_dim, generator=gen).to(dev).to(BF16))] for ph in ('A', 'B')}
+            lf, lg = step.iteration(inputs, ema_beta=0.5)
+            losses += [float(lf), float(lg)]
+        torch.cuda.synchronize()
+        out[mode] = dict(losses=np.array(losses), dG=(G.flat_params - g0).clone(), psi=psi.flat_params.clone())
+    a, f = out['bf16'], out['fp8']
+    print(f'losses bf16 teacher {a["losses"]}  fp8 teacher {f["losses"]}')
+    assert np.isfinite(f['losses']).all() and torch.isfinite(f['dG']).all()
+    assert f['losses'][0] == a['losses'][0]                                  # phase A of iteration 0 does not involve the teacher
+    rel_g = abs(f['losses'][1] - a['losses'][1]) / abs(a['losses'][1])
+    agree = float((torch.sign(a['dG']) == torch.sign(f['dG'])).float().mean())
+    print(f'generator loss deviation {rel_g:.3e}; update-sign agreement of G {agree:.4f}')
+    assert rel_g < 0.2 and agree > 0.85
