@@ -733,6 +733,9 @@ DEVFN void dma16_asm(__amdgpu_buffer_rsrc_t rs, const void* dst, unsigned voff, 
     const unsigned la = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lptr_t)dst);
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(la), "v"(voff), "s"(rs), "s"(soff) : "memory");
 }
+#ifndef SIDLSG_MX8_SPREAD_DMA
+#define SIDLSG_MX8_SPREAD_DMA 1
+#endif
 #ifndef SIDLSG_WGRAD_ASM_DMA
 #define SIDLSG_WGRAD_ASM_DMA 0
 #endif
@@ -1196,7 +1199,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_mx8_kernel(GemmParams p) {
     }
     const int kt_begin = p.kt_per_split ? split * p.kt_per_split : 0;
     const int nk = p.kt_per_split ? min(nk_all, kt_begin + p.kt_per_split) : nk_all;
-    auto issue = [&](int t, int buf) {          // 9 buffer_load ... lds per wave
+    auto issue = [&](int t, int buf, const int part = 0) {          // 9 buffer_load ... lds per wave (part 1: the 4 A pieces, 2: the 5 W pieces)
         char* sa = smem + buf * STAGE;
         char* sb = sa + BM * KB;
         if (MODE == 1) {
@@ -1205,31 +1208,43 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_mx8_kernel(GemmParams p) {
             const unsigned sa_off = (unsigned)cc * KB + dh * tap_rs + dw * tap_ps;
             const unsigned sw_off = (unsigned)(tap * p.Cin + cc * KB);
             const unsigned lim = (unsigned)(p.Cin - cc * KB), bit = 1u << tap;
+            if (part != 2) {
 #pragma unroll
-            for (int j = 0; j < 4; j++)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lptr_t)(sa + (wave * 32 + j * 8) * KB), 16, ((tmask[j] & bit) && akb[j] < lim) ? cen[j] : OOB, sa_off, 0, 0);
+                for (int j = 0; j < 4; j++)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lptr_t)(sa + (wave * 32 + j * 8) * KB), 16, ((tmask[j] & bit) && akb[j] < lim) ? cen[j] : OOB, sa_off, 0, 0);
+            }
+            if (part != 1) {
 #pragma unroll
-            for (int j = 0; j < 5; j++) __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lptr_t)(sb + (wave + 4 * j) * 8 * KB), 16, boff[j], sw_off, 0, 0);
+                for (int j = 0; j < 5; j++) __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lptr_t)(sb + (wave + 4 * j) * 8 * KB), 16, boff[j], sw_off, 0, 0);
+            }
             return;
         }
         const int k0 = t * KB;
         if (k0 + KB > p.K) {                    // ragged K tail: chunks past K read zeros
+            if (part != 2) {
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const int kcs = lslot ^ (((wave * 32 + j * 8 + lrow) >> 1) & 7);
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lptr_t)(sa + (wave * 32 + j * 8) * KB), 16, (k0 + kcs * 16 < p.K) ? aoff[j] : OOB, k0, 0, 0);
+                for (int j = 0; j < 4; j++) {
+                    const int kcs = lslot ^ (((wave * 32 + j * 8 + lrow) >> 1) & 7);
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lptr_t)(sa + (wave * 32 + j * 8) * KB), 16, (k0 + kcs * 16 < p.K) ? aoff[j] : OOB, k0, 0, 0);
+                }
             }
+            if (part != 1) {
 #pragma unroll
-            for (int j = 0; j < 5; j++) {
-                const int kcs = lslot ^ wsw((wave + 4 * j) * 8 + lrow);
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lptr_t)(sb + (wave + 4 * j) * 8 * KB), 16, (k0 + kcs * 16 < p.K) ? boff[j] : OOB, k0, 0, 0);
+                for (int j = 0; j < 5; j++) {
+                    const int kcs = lslot ^ wsw((wave + 4 * j) * 8 + lrow);
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lptr_t)(sb + (wave + 4 * j) * 8 * KB), 16, (k0 + kcs * 16 < p.K) ? boff[j] : OOB, k0, 0, 0);
+                }
             }
             return;
         }
+        if (part != 2) {
 #pragma unroll
-        for (int j = 0; j < 4; j++) __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lptr_t)(sa + (wave * 32 + j * 8) * KB), 16, aoff[j], k0, 0, 0);
+            for (int j = 0; j < 4; j++) __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lptr_t)(sa + (wave * 32 + j * 8) * KB), 16, aoff[j], k0, 0, 0);
+        }
+        if (part != 1) {
 #pragma unroll
-        for (int j = 0; j < 5; j++) __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lptr_t)(sb + (wave + 4 * j) * 8 * KB), 16, boff[j], k0, 0, 0);
+            for (int j = 0; j < 5; j++) __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lptr_t)(sb + (wave + 4 * j) * 8 * KB), 16, boff[j], k0, 0, 0);
+        }
     };
     f32x4 acc[NT][MT];
 #pragma unroll
@@ -1276,6 +1291,28 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_mx8_kernel(GemmParams p) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+#if SIDLSG_MX8_SPREAD_DMA
+        // fragment reads first; the 9 DMA pieces of the next tile are issued in two groups BETWEEN MFMA columns (a piece costs
+        // the wave 60-185 cycles of issue: behind queued MFMAs that time is covered, in front of the reads it is not)
+        const bool more = kt + 1 < nk;
+        read_a(buf, fa);
+        fw01[0] = read_w(buf, 0);
+        fw01[1] = read_w(buf, 1);
+        fw24[0] = read_w(buf, 2);
+        fw24[1] = read_w(buf, 3);
+        fw24[2] = read_w(buf, 4);
+        mfma_col(fa, fw01[0], 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) issue(kt + 1, buf ^ 1, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_col(fa, fw01[1], 1);
+        mfma_col(fa, fw24[0], 2);
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) issue(kt + 1, buf ^ 1, 2);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_col(fa, fw24[1], 3);
+        mfma_col(fa, fw24[2], 4);
+#else
         if (kt + 1 < nk) issue(kt + 1, buf ^ 1);
         read_a(buf, fa);
         fw01[0] = read_w(buf, 0);
@@ -1288,6 +1325,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_mx8_kernel(GemmParams p) {
         mfma_col(fa, fw24[0], 2);
         mfma_col(fa, fw24[1], 3);
         mfma_col(fa, fw24[2], 4);
+#endif
     }
     if (p.kt_per_split) {                // partial sums (already scaled per channel) -> this split's fp32 slab
 #pragma unroll
