@@ -14,6 +14,7 @@ Aesthetic-style captions tokenised by the offline stand-in tokenizer: `"data": "
         bench.py --gpus 8 --steps 5 --warmup 2
 """
 import argparse
+import contextlib
 import json
 import os
 import sys
@@ -221,15 +222,39 @@ def main():
     batch_size = b * world
     gen = torch.Generator(device=dev)
 
+    # The inputs of iteration it+1 (noise, timesteps, tokenisation + CLIP text encoding of both phases' prompts: ~100 one-block
+    # kernels, 2.6 ms of an otherwise serial stream) are prepared on their own stream while iteration it runs -- a data-loader
+    # prefetch: every iteration still prepares exactly one set of inputs inside the timed region.  $SIDLSG_BENCH_PREFETCH=0: serial.
+    prefetch = os.environ.get('SIDLSG_BENCH_PREFETCH', '1') != '0'
+    prep_stream = torch.cuda.Stream(dev) if prefetch else None
+    pending = {}
+
+    def prepare(it):
+        with torch.cuda.stream(prep_stream) if prefetch else contextlib.nullcontext():
+            gen.manual_seed(1000 * rank + it)
+            inputs = dict(A=[], B=[])
+            for k, ph in enumerate(('A', 'B')):
+                prompts = synth_prompts(b, seed=(it * 2 + k) * world + rank)
+                z = torch.randn(b, 4, lat, lat, device=dev, generator=gen)
+                noise = torch.randn(b, 4, lat, lat, device=dev, generator=gen)
+                t = torch.randint(20, 980, (b,), device=dev, generator=gen)
+                inputs[ph].append(dict(z=z, noise=noise, t=t, cond=cond.encode(prompts), uncond=cond.uncond(b)))
+            ev = None
+            if prefetch:
+                ev = torch.cuda.Event()
+                ev.record()
+        return inputs, ev
+
     def one_iteration(it):
-        gen.manual_seed(1000 * rank + it)
-        inputs = dict(A=[], B=[])
-        for k, ph in enumerate(('A', 'B')):
-            prompts = synth_prompts(b, seed=(it * 2 + k) * world + rank)
-            z = torch.randn(b, 4, lat, lat, device=dev, generator=gen)
-            noise = torch.randn(b, 4, lat, lat, device=dev, generator=gen)
-            t = torch.randint(20, 980, (b,), device=dev, generator=gen)
-            inputs[ph].append(dict(z=z, noise=noise, t=t, cond=cond.encode(prompts), uncond=cond.uncond(b)))
+        inputs, ev = pending.pop(it, None) or prepare(it)
+        if prefetch:
+            pending[it + 1] = prepare(it + 1)
+            cur = torch.cuda.current_stream()
+            cur.wait_event(ev)
+            for ph in ('A', 'B'):
+                for r in inputs[ph]:
+                    for v in r.values():
+                        v.record_stream(cur)
         half = min(50 * 1000, it * batch_size * 0.05)
         beta = 0.5 ** (batch_size / max(half, 1e-8))
         return (step.iteration_graphed if use_graph else step.iteration)(inputs, ema_beta=beta)

@@ -16,6 +16,7 @@ gc.collect every iteration (:384-385, a pure slowdown).  Rejected loudly rather 
 reference's own multi-step training sampler is marked unfinished, sid_sd_util.py:165).
 """
 import copy
+import contextlib
 import json
 import os
 import pickle
@@ -41,12 +42,14 @@ class Stats:
         self.acc = {}
 
     def report(self, name, value):
+        """value: a number, or a device scalar -- then the sum stays on the device and is read once per tick (as_dict): a
+        float() per iteration is a host-device synchronisation per iteration."""
         n, s = self.acc.get(name, (0, 0.0))
-        self.acc[name] = (n + 1, s + float(value))
+        self.acc[name] = (n + 1, s + (value.detach().float() if torch.is_tensor(value) else float(value)))
         return value
 
     def as_dict(self):
-        return {k: dict(num=n, mean=s / max(n, 1)) for k, (n, s) in self.acc.items()}
+        return {k: dict(num=n, mean=float(s) / max(n, 1)) for k, (n, s) in self.acc.items()}
 
     def reset(self):
         self.acc = {}
@@ -195,10 +198,33 @@ def training_loop(
     if world > 1:
         torch.distributed.barrier()
     dist.print0('Start Running')
+    # Inputs of the NEXT iteration (prompt batch, dropout flags, z / noise / t, tokenisation + text encoding: ~100 one-block
+    # kernels) are prepared on their own stream while the current iteration runs -- a data-loader prefetch.  The draws keep the
+    # reference's order (the step itself consumes no RNG); the one look-ahead set that is never used costs a prompt batch.
+    prep_stream = torch.cuda.Stream(device) if (torch.cuda.is_available() and os.environ.get('SIDLSG_PREFETCH_INPUTS', '1') != '0') else None
+
+    def build_inputs():
+        with torch.cuda.stream(prep_stream) if prep_stream is not None else contextlib.nullcontext():
+            # RNG order of the reference: all phase-A draws, then all phase-B draws (the compute in between consumes no RNG)
+            inputs = dict(A=[make_round(use_dropout) for _ in range(rounds)])
+            inputs['B'] = [make_round(False) for _ in range(rounds)]
+            ev = None
+            if prep_stream is not None:
+                ev = torch.cuda.Event()
+                ev.record()
+        return inputs, ev
+
+    upcoming = build_inputs()
     while True:
-        # RNG order of the reference: all phase-A draws, then all phase-B draws (the compute in between consumes no RNG)
-        inputs = dict(A=[make_round(use_dropout) for _ in range(rounds)])
-        inputs['B'] = [make_round(False) for _ in range(rounds)]
+        inputs, ev = upcoming
+        if prep_stream is not None:
+            upcoming = build_inputs()
+            cur_stream = torch.cuda.current_stream()
+            cur_stream.wait_event(ev)
+            for ph in ('A', 'B'):
+                for r in inputs[ph]:
+                    for v in r.values():
+                        v.record_stream(cur_stream)
         ema_beta = None
         if ema_halflife_kimg > 0:
             half = ema_halflife_kimg * 1000
@@ -206,14 +232,18 @@ def training_loop(
                 half = min(half, cur_nimg * ema_rampup_ratio)
             ema_beta = 0.5 ** (batch_size / max(half, 1e-8))
         loss_f, loss_g = step.iteration(inputs, ema_beta=ema_beta)
-        loss_f, loss_g = float(loss_f), float(loss_g)
+        # (the reference reads both losses every iteration, :452 -- a host-device synchronisation; here they stay on the device
+        # until the tick, unless a per-iteration observer wants them)
         stats.report('fake_score_Loss/loss', loss_f); stats.report('G_Loss/loss', loss_g)
         if on_iteration is not None:
-            on_iteration(cur_nimg // batch_size, loss_f, loss_g)
+            on_iteration(cur_nimg // batch_size, float(loss_f), float(loss_g))
+        if prep_stream is None:
+            upcoming = build_inputs() if cur_nimg + batch_size < total_kimg * 1000 else (None, None)
         cur_nimg += batch_size
         done = cur_nimg >= total_kimg * 1000
         if (not done) and (cur_tick != 0) and (cur_nimg < tick_start_nimg + kimg_per_tick * 1000):
             continue
+        loss_f, loss_g = float(loss_f), float(loss_g)
 
         tick_end_time = time.time()
         sec_per_kimg = (tick_end_time - tick_start_time) / (cur_nimg - tick_start_nimg) * 1e3
