@@ -45,7 +45,7 @@ tl.training_loop(**kw)
 torch.cuda.synchronize()
 for ln in open(os.path.join(kw['run_dir'], 'stats_1.000000.jsonl')):
     d = json.loads(ln)
-    print({k: round(v['mean'], 3) for k, v in d.items() if isinstance(v, dict) and k in ('Progress/tick', 'Timing/images_per_sec', 'Timing/sec_per_kimg')})
+    print({k: round(v['mean'], 3) for k, v in d.items() if isinstance(v, dict) and k in ('Progress/tick', 'Timing/images_per_sec', 'Timing/sec_per_kimg', 'Resources/peak_gpu_mem_gb')})
 if sync_every and len(marks) > 12:
     dt = (marks[-1] - marks[8]) / (len(marks) - 9)
     print(f'per-iteration observer (a host sync every iteration): {dt * 1e3:.1f} ms per iteration = {bs / dt:.2f} images/s')
