@@ -95,6 +95,8 @@ class SiDStep:
         self.opt_stream = None
         if os.environ.get('SIDLSG_SEG_OPT', '0') == '1' and torch.cuda.is_available():
             self.enable_segmented_optimizer()
+        # phase B's generator forward issued before phase A, on the side stream (_early_generator_forward); A/B switch, same results
+        self.early_gfwd = os.environ.get('SIDLSG_EARLY_GFWD', '1') != '0'
         self._graphs, self._graph_warm = {}, False
         opt_fake.grad_scale = opt_G.grad_scale = 1.0 / world_size     # DDP mean, folded into the optimizer kernel
         opt_fake.attach(ema=None, w16=fake_score.flat_w16)
@@ -122,10 +124,31 @@ class SiDStep:
         loss.backward()                                                             # :449-450
         return loss.detach()
 
-    def fake_backward(self, rounds, seg=None, overlap_exchange=False):
+    def _early_generator_forward(self, r, overlap):
+        """Phase B's generator forward x_hat = G(z) (with grad) reads nothing phase A writes -- G is only updated at the end of
+        phase B -- so it is issued on the side stream BEFORE phase A and runs beside the fake-score network's forward and
+        backward (its batch is half of theirs: alone it leaves the 16x16 / 8x8 stages even emptier than they do).  Autograd
+        runs G's backward on the same stream at the end of phase B; the caller's stream is synchronised with it by the engine
+        when loss.backward() returns (as for the teacher).  Returns (images, event)."""
+        self.G.requires_grad_(True)                                                 # :468
+        if overlap:     # the markers of the segment-wise exchange are placed by the forward
+            segs = self.G.grad_segments()
+            self.G.set_grad_ready_callback(lambda k: self.reducer.start_range(self.G.flat_grads, *segs[k]))
+        cur = torch.cuda.current_stream()
+        self.side.wait_stream(cur)
+        for t in (r['z'], r['cond']):
+            t.record_stream(self.side)
+        with torch.cuda.stream(self.side):
+            images = hip_generate(self.G, r['z'], r['cond'], self._init_t(len(r['z']), r['z'].device), self.sched)
+            ev = torch.cuda.Event()
+            ev.record()
+        return images, ev
+
+    def fake_backward(self, rounds, seg=None, overlap_exchange=False, keep_G=False):
         """Forward/backward of phase A over all accumulation rounds; leaves the gradients in psi.flat_grads (seg: the
         segments the backward of the last round has passed are already being exchanged / updated)."""
-        self.G.requires_grad_(False)
+        if not keep_G:       # (keep_G: phase B's forward of G is already in flight with grad; phase A's own G pass is under no_grad)
+            self.G.requires_grad_(False)
         self.psi.requires_grad_(True)                                               # :389
         loss = None
         overlap = seg is None and overlap_exchange and self.exchange and self.overlap_g
@@ -156,8 +179,14 @@ class SiDStep:
         return loss
 
     # ---- phase B: generator --------------------------------------------------------------------
-    def generator_round(self, r, before_fake_eval=None):
-        images = hip_generate(self.G, r['z'], r['cond'], self._init_t(len(r['z']), r['z'].device), self.sched)  # :488-491
+    def generator_round(self, r, before_fake_eval=None, pre=None):
+        if pre is not None:                                                         # issued before phase A (_early_generator_forward)
+            images, ev = pre
+            cur = torch.cuda.current_stream()
+            cur.wait_event(ev)
+            images.record_stream(cur)
+        else:
+            images = hip_generate(self.G, r['z'], r['cond'], self._init_t(len(r['z']), r['z'].device), self.sched)  # :488-491
         guided = (self.k2 != 1) or (self.k4 != 1)
         prep = hip_prepare_denoise(images, r['noise'], r['t'], r['cond'], r.get('uncond'), self.sched, guided,
                                    act_dtype=self.psi.compute_dtype)
@@ -184,7 +213,7 @@ class SiDStep:
         loss.backward()                                                             # :532-533
         return loss.detach()
 
-    def generator_update(self, rounds, ema_beta=None, before_fake_eval=None):
+    def generator_update(self, rounds, ema_beta=None, before_fake_eval=None, pre=None):
         self.G.requires_grad_(True)                                                 # :468
         self.psi.requires_grad_(False)
         loss = None
@@ -201,11 +230,11 @@ class SiDStep:
         overlap = self.exchange and self.overlap_g
         segs = self.G.grad_segments() if overlap else None
         for i, r in enumerate(rounds):
-            if overlap and i == len(rounds) - 1:
+            if overlap and i == len(rounds) - 1 and pre is None:
                 # last accumulation round (what DDP does outside no_sync): a segment of the flat gradient is exchanged as
                 # soon as the backward has passed it, while the earlier layers' backward is still running
                 self.G.set_grad_ready_callback(lambda k: self.reducer.start_range(self.G.flat_grads, *segs[k]))
-            loss = self.generator_round(r, before_fake_eval if i == 0 else None)
+            loss = self.generator_round(r, before_fake_eval if i == 0 else None, pre if i == 0 else None)
         self.G.requires_grad_(False)                                                # :538
         if overlap:
             self.G.set_grad_ready_callback(None)
@@ -236,14 +265,17 @@ class SiDStep:
             seg.start_last()
             lg = self.generator_update(inputs['B'], ema_beta=ema_beta, before_fake_eval=seg.join)
             return lf, lg
-        lf = self.fake_backward(inputs['A'], overlap_exchange=True)
+        pre = None
+        if self.early_gfwd and self.side is not None and len(inputs['B']) == 1:
+            pre = self._early_generator_forward(inputs['B'][0], self.exchange and self.overlap_g)
+        lf = self.fake_backward(inputs['A'], overlap_exchange=True, keep_G=pre is not None)
         overlap = self.exchange
         if overlap and not self.overlap_g:
             self.reducer.start(self.psi.flat_grads)
 
         def finish_fake():
             self._optimizer_step(self.psi, self.opt_fake, ema_beta=None, started=overlap)
-        lg = self.generator_update(inputs['B'], ema_beta=ema_beta, before_fake_eval=finish_fake)
+        lg = self.generator_update(inputs['B'], ema_beta=ema_beta, before_fake_eval=finish_fake, pre=pre)
         return lf, lg
 
     # ---- the same iteration as ONE HIP graph ---------------------------------------------------------------------------
