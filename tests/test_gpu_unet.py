@@ -740,6 +740,7 @@ def test_side_streams_change_nothing_in_the_step(dev):
                            cfg_eval_real=1.5, batch_gpu_total=b, init_timestep=625)
             step.side = ops.side_stream(dev) if on else None
             step.enable_segmented_optimizer(on)  # off: ONE optimizer launch after each backward, on the compute stream
+            assert step.early_gfwd               # (phase B's generator forward before phase A needs the side stream: off with it)
             gen = torch.Generator().manual_seed(3)
             losses = []
             for it in range(iters):
