@@ -89,6 +89,7 @@ int sidlsg_layernorm_bwd(const void* x, const void* dy, const float* stats, cons
 int sidlsg_attn_fwd(const void* Q, const void* K, const void* V, void* O, float* LSE, int B, int H, int Nq, int Nk, int D,
                     int ldq, int ldk, int ldv, int ldo, long long bsq, long long bsk, long long bsv, long long bso,
                     void* stream);
+/* backward: dK = dV = NULL -> only dQ (and delta) are produced. */
 int sidlsg_attn_bwd(const void* Q, const void* K, const void* V, const void* O, const void* dO, const float* LSE, void* dQ,
                     void* dK, void* dV, float* delta, int B, int H, int Nq, int Nk, int D, int ldq, int ldk, int ldv, int ldo,
                     long long bsq, long long bsk, long long bsv, long long bso, void* stream);

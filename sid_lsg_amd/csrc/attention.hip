@@ -810,6 +810,11 @@ static int attn_bwd_impl(bool ps, const void* Q, const void* K, const void* V, c
     p.scale = 1.0f / sqrtf((float)D); p.scale2 = p.scale * 1.4426950408889634f;
     p.O = const_cast<bf16*>((const bf16*)O); p.delta_out = delta;
     if (int e = ps ? dispatch_attn<true>(p, 1, s) : dispatch_attn<false>(p, 1, s)) return e;
+    // dK == dV == null: the caller needs the query gradient only (cross-attention of a FROZEN network: K / V come from the
+    // text states through frozen weights, nothing upstream wants their gradient) -- the dK/dV pass over 77 keys has only
+    // 2 blocks per (batch, head) and costs 25-100 us per layer for nothing
+    if (!dK && !dV) return SIDLSG_OK;
+    if (!dK || !dV) return SIDLSG_EINVAL;
     return ps ? dispatch_attn<true>(p, 2, s) : dispatch_attn<false>(p, 2, s);
 }
 

@@ -576,6 +576,8 @@ int sidlsg_attn_bwd_f32(const void* Q, const void* K, const void* V, const void*
     p.bsq = bsq; p.bsk = bsk; p.bsv = bsv; p.bso = bso;
     p.scale = 1.0f / sqrtf((float)D); p.scale2 = p.scale * 1.4426950408889634f;
     if (int e = dispatch_attn_f32(p, 1, s)) return e;
+    if (!dK && !dV) return SIDLSG_OK;          // query gradient only (see sidlsg_attn_bwd)
+    if (!dK || !dV) return SIDLSG_EINVAL;
     return dispatch_attn_f32(p, 2, s);
 }
 

@@ -644,6 +644,9 @@ def norm_linear_mx8(x, gamma, beta, eps, w8, bias, w16t, weight, groups=0, silu=
     return _NormLinearMX8.apply(x, gamma, beta, eps, groups, silu, fork, w8, bias, w16t, weight)
 
 
+_ATTN_ALWAYS_KV = os.environ.get('SIDLSG_ATTN_SKIP_KV', '1') == '0'      # A/B switch: compute dK / dV even when nobody wants them
+
+
 class _Attention(torch.autograd.Function):
     """q: [B,Nq,*] view with heads*D channels starting at column qoff of a row of width ldq; same for k, v."""
 
@@ -679,12 +682,15 @@ class _Attention(torch.autograd.Function):
         if do.dtype != qbuf.dtype:
             do = do.to(qbuf.dtype)
         same = qbuf.data_ptr() == kvbuf.data_ptr()
+        # cross-attention whose keys / values nobody differentiates (frozen k|v projection of the text states): dQ only
+        need_kv = same or ctx.needs_input_grad[1] or _ATTN_ALWAYS_KV
         dq = torch.empty_like(qbuf)
-        dkv = dq if same else torch.empty_like(kvbuf)
+        dkv = dq if same else (torch.empty_like(kvbuf) if need_kv else None)
         delta = torch.empty((B, heads, Nq), device=qbuf.device, dtype=F32)
         es = qbuf.element_size()
         _fn('attn_bwd' + sfx, qbuf.dtype)(qbuf.data_ptr() + qoff * es, kvbuf.data_ptr() + koff * es, kvbuf.data_ptr() + voff * es, _p(o), _p(do),
-                            _p(lse), dq.data_ptr() + qoff * es, dkv.data_ptr() + koff * es, dkv.data_ptr() + voff * es, _p(delta),
+                            _p(lse), dq.data_ptr() + qoff * es, dkv.data_ptr() + koff * es if need_kv else None,
+                            dkv.data_ptr() + voff * es if need_kv else None, _p(delta),
                             B, heads, Nq, Nk, D, ldq, ldk, ldk, C, Nq * ldq, Nk * ldk, Nk * ldk, Nq * C, _s())
         return dq, (None if same else dkv), None, None, None, None, None, None
 

@@ -557,3 +557,21 @@ def test_attention_propagates_nan(dev, heads, d):
         out = ops.self_attention(bad, heads).float()
         assert torch.isnan(out[1]).any(), where
         assert torch.equal(out[0], clean[0]) and torch.equal(out[2], clean[2])
+
+
+def test_attention_backward_query_gradient_only(dev):
+    """Cross-attention whose keys / values do not require grad (frozen k|v projection of the text states): the backward
+    produces dQ only (sidlsg_attn_bwd with dK = dV = NULL skips the dK/dV pass) -- and dQ is bit-identical to the full
+    backward's."""
+    from sid_lsg_amd import ops
+    g = torch.Generator().manual_seed(11)
+    B, Nq, Nk, heads, D = 2, 256, 77, 2, 40
+    C = heads * D
+    q = torch.randn(B, Nq, C, generator=g).to(dev).to(BF16)
+    kv = torch.randn(B, Nk, 2 * C, generator=g).to(dev).to(BF16)
+    do = torch.randn(B, Nq, C, generator=g).to(dev).to(BF16)
+    qa, kva = q.clone().requires_grad_(), kv.clone().requires_grad_()
+    ops.cross_attention(qa, kva, heads).backward(do)
+    qb = q.clone().requires_grad_()
+    ops.cross_attention(qb, kv, heads).backward(do)
+    assert torch.equal(qa.grad, qb.grad) and kva.grad is not None and float(kva.grad.abs().max()) > 0
