@@ -159,6 +159,103 @@ def cpu_baseline(arch, threads, kappa=1.5):
                        f'{dt:.1f} s on {threads} threads (setup {t_setup:.0f} s not timed); loss_fake {out["loss_fake"]:.1f}')
 
 
+LOSS_REFERENCE = os.path.join(ROOT, 'tests', 'golden', 'bench_loss_reference.json')
+LOSS_TOL = (2e-3, 1e-2)          # bf16 production mode against fp32: tests/test_gpu_unet.py::TOL_LOSS[bfloat16]
+
+
+def loss_reference_key(arch, batch_gpu, resolution, kappa):
+    return f'{arch}_b{batch_gpu}_{resolution}_k{kappa:g}'
+
+
+def load_loss_reference(args, world):
+    if args.teacher_weights != 'bf16' or not os.path.isfile(LOSS_REFERENCE):
+        return None
+    with open(LOSS_REFERENCE) as f:
+        return json.load(f).get(loss_reference_key(args.arch, args.batch_gpu, args.resolution, args.kappa))
+
+
+def check_losses(ref, it, lf, lg):
+    if it >= len(ref['loss_fake']):
+        return dict(iteration=it, ok=True, skipped=f'reference holds {len(ref["loss_fake"])} iterations')
+    rf, rg = ref['loss_fake'][it], ref['loss_G'][it]
+    ef, eg = abs(lf - rf) / abs(rf), abs(lg - rg) / abs(rg)
+    return dict(iteration=it, loss_fake=lf, loss_fake_ref=rf, rel_fake=ef, loss_G=lg, loss_G_ref=rg, rel_G=eg,
+                bounds=list(LOSS_TOL), ok=bool(ef <= LOSS_TOL[0] and eg <= LOSS_TOL[1]))
+
+
+class _Setup:
+    pass
+
+
+def setup_step(arch, b, resolution, kappa, dev, rank=0, world=1, teacher_weights='bf16', reducer=None, compute_dtype=torch.bfloat16):
+    """The benchmark's networks, optimizers, SiDStep and synthetic input stream (also used by tests/test_gpu_bench_parity.py and
+    tools/make_bench_loss_reference.py, which run the SAME workload in the fp32-accurate mode)."""
+    from sid_lsg_amd.optim import FusedAdamEMA
+    from sid_lsg_amd.sd_util import load_sd15
+    from sid_lsg_amd.sid_step import SiDStep
+    from sid_lsg_amd.text import TextConditioner
+    S = _Setup()
+    lat = resolution // 8
+    phi, vae, sched, text_encoder, tokenizer = load_sd15(f'random:{arch}', None, dev, compute_dtype, seed=0, compute_dtype=compute_dtype)
+    psi = phi.clone_network()
+    G = phi.clone_network()
+    G_ema = phi.clone_network(with_grad_buffers=False)
+    if teacher_weights == 'fp8':
+        phi.enable_fp8_weights()
+    text_encoder.to(torch.bfloat16)          # the text states are bf16 in both compute modes (PyTorch-ROCm CLIP, north_star)
+    cond = TextConditioner(tokenizer, text_encoder, out_dtype=compute_dtype)
+    opt_f = FusedAdamEMA(psi.parameters(), lr=1e-6, betas=(0.0, 0.999), eps=1e-8)
+    opt_g = FusedAdamEMA(G.parameters(), lr=1e-6, betas=(0.0, 0.999), eps=1e-8)
+    step = SiDStep(G, psi, phi, G_ema, sched, opt_f, opt_g, alpha=1.0, cfg_train_fake=kappa, cfg_eval_fake=kappa,
+                   cfg_eval_real=kappa, batch_gpu_total=b, init_timestep=625, reducer=reducer, world_size=world)
+    batch_size = b * world
+    gen = torch.Generator(device=dev)
+
+    # The inputs of iteration it+1 (noise, timesteps, tokenisation + CLIP text encoding of both phases' prompts: ~100 one-block
+    # kernels, 2.6 ms of an otherwise serial stream) are prepared on their own stream while iteration it runs -- a data-loader
+    # prefetch: every iteration still prepares exactly one set of inputs inside the timed region.  $SIDLSG_BENCH_PREFETCH=0: serial.
+    prefetch = os.environ.get('SIDLSG_BENCH_PREFETCH', '1') != '0'
+    prep_stream = torch.cuda.Stream(dev) if prefetch else None
+    if prefetch:
+        prep_stream.wait_stream(torch.cuda.current_stream())
+    pending = {}
+
+    def prepare(it):
+        with torch.cuda.stream(prep_stream) if prefetch else contextlib.nullcontext():
+            gen.manual_seed(1000 * rank + it)
+            inputs = dict(A=[], B=[])
+            for k, ph in enumerate(('A', 'B')):
+                prompts = synth_prompts(b, seed=(it * 2 + k) * 1000 + rank)      # rank 0's stream does not depend on the world size
+                z = torch.randn(b, 4, lat, lat, device=dev, generator=gen)
+                noise = torch.randn(b, 4, lat, lat, device=dev, generator=gen)
+                t = torch.randint(20, 980, (b,), device=dev, generator=gen)
+                inputs[ph].append(dict(z=z, noise=noise, t=t, cond=cond.encode(prompts), uncond=cond.uncond(b)))
+            ev = None
+            if prefetch:
+                ev = torch.cuda.Event()
+                ev.record()
+        return inputs, ev
+
+    def one_iteration(it):
+        inputs, ev = pending.pop(it, None) or prepare(it)
+        if prefetch:
+            pending[it + 1] = prepare(it + 1)
+            cur = torch.cuda.current_stream()
+            cur.wait_event(ev)
+            for ph in ('A', 'B'):
+                for r in inputs[ph]:
+                    for v in r.values():
+                        v.record_stream(cur)
+        half = min(50 * 1000, it * batch_size * 0.05)
+        beta = 0.5 ** (batch_size / max(half, 1e-8))
+        return (step.iteration_graphed if S.use_graph else step.iteration)(inputs, ema_beta=beta)
+
+    S.use_graph = False
+    S.step, S.phi, S.psi, S.G, S.G_ema, S.cond, S.sched, S.gen = step, phi, psi, G, G_ema, cond, sched, gen
+    S.batch_size, S.prepare, S.one_iteration, S.lat = batch_size, prepare, one_iteration, lat
+    return S
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -197,77 +294,31 @@ def main():
 
     from sid_lsg_amd._lib import lib
     from sid_lsg_amd.distributed import FlatGradReducer
-    from sid_lsg_amd.optim import FusedAdamEMA
-    from sid_lsg_amd.scheduler import DDPMScheduler
-    from sid_lsg_amd.sd_util import load_sd15
-    from sid_lsg_amd.sid_step import SiDStep
-    from sid_lsg_amd.text import TextConditioner
     lib.load()
 
     b = args.batch_gpu
     lat = args.resolution // 8
-    phi, vae, sched, text_encoder, tokenizer = load_sd15(f'random:{args.arch}', None, dev, torch.bfloat16, seed=0)
-    psi = phi.clone_network()
-    G = phi.clone_network()
-    G_ema = phi.clone_network(with_grad_buffers=False)
-    if args.teacher_weights == 'fp8':
-        phi.enable_fp8_weights()
-    text_encoder.to(torch.bfloat16)
-    cond = TextConditioner(tokenizer, text_encoder)
-    opt_f = FusedAdamEMA(psi.parameters(), lr=1e-6, betas=(0.0, 0.999), eps=1e-8)
-    opt_g = FusedAdamEMA(G.parameters(), lr=1e-6, betas=(0.0, 0.999), eps=1e-8)
-    step = SiDStep(G, psi, phi, G_ema, sched, opt_f, opt_g, alpha=1.0, cfg_train_fake=args.kappa, cfg_eval_fake=args.kappa,
-                   cfg_eval_real=args.kappa, batch_gpu_total=b, init_timestep=625,
-                   reducer=FlatGradReducer() if world > 1 else None, world_size=world)
-    batch_size = b * world
-    gen = torch.Generator(device=dev)
+    reducer = FlatGradReducer() if world > 1 else None
+    if reducer is not None and not args.graph:
+        reducer.enable_timing()          # exposed-communication figures of the multi-GPU run (`comm` in the JSON line)
+    S = setup_step(args.arch, b, args.resolution, args.kappa, dev, rank=rank, world=world, teacher_weights=args.teacher_weights,
+                   reducer=reducer)
+    step, phi, cond, sched, gen, batch_size = S.step, S.phi, S.cond, S.sched, S.gen, S.batch_size
+    one_iteration = S.one_iteration
+    loss_ref = load_loss_reference(args, world)
 
-    # The inputs of iteration it+1 (noise, timesteps, tokenisation + CLIP text encoding of both phases' prompts: ~100 one-block
-    # kernels, 2.6 ms of an otherwise serial stream) are prepared on their own stream while iteration it runs -- a data-loader
-    # prefetch: every iteration still prepares exactly one set of inputs inside the timed region.  $SIDLSG_BENCH_PREFETCH=0: serial.
-    prefetch = os.environ.get('SIDLSG_BENCH_PREFETCH', '1') != '0'
-    prep_stream = torch.cuda.Stream(dev) if prefetch else None
-    pending = {}
-
-    def prepare(it):
-        with torch.cuda.stream(prep_stream) if prefetch else contextlib.nullcontext():
-            gen.manual_seed(1000 * rank + it)
-            inputs = dict(A=[], B=[])
-            for k, ph in enumerate(('A', 'B')):
-                prompts = synth_prompts(b, seed=(it * 2 + k) * world + rank)
-                z = torch.randn(b, 4, lat, lat, device=dev, generator=gen)
-                noise = torch.randn(b, 4, lat, lat, device=dev, generator=gen)
-                t = torch.randint(20, 980, (b,), device=dev, generator=gen)
-                inputs[ph].append(dict(z=z, noise=noise, t=t, cond=cond.encode(prompts), uncond=cond.uncond(b)))
-            ev = None
-            if prefetch:
-                ev = torch.cuda.Event()
-                ev.record()
-        return inputs, ev
-
-    def one_iteration(it):
-        inputs, ev = pending.pop(it, None) or prepare(it)
-        if prefetch:
-            pending[it + 1] = prepare(it + 1)
-            cur = torch.cuda.current_stream()
-            cur.wait_event(ev)
-            for ph in ('A', 'B'):
-                for r in inputs[ph]:
-                    for v in r.values():
-                        v.record_stream(cur)
-        half = min(50 * 1000, it * batch_size * 0.05)
-        beta = 0.5 ** (batch_size / max(half, 1e-8))
-        return (step.iteration_graphed if use_graph else step.iteration)(inputs, ema_beta=beta)
-
-    use_graph = args.graph
+    S.use_graph = args.graph
 
     def sync():
         if world > 1:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    checks = []
     for it in range(args.warmup):
-        one_iteration(it)
+        lf, lg = one_iteration(it)
+        if it == 0 and rank == 0 and loss_ref is not None:          # iteration 0 of rank 0 does not depend on the world size
+            checks.append(check_losses(loss_ref, 0, float(lf), float(lg)))
     sync()
     timers = {}
     # the attention entry points the networks use: pre-scaled queries unless switched off (unet._build_prescale_plan)
@@ -280,15 +331,23 @@ def main():
                     attn=KernelTimer(lib, ATTN_FWD, attn_flops, stride=3), attn_bwd=KernelTimer(lib, ATTN_BWD, attn_bwd_flops, stride=3),
                     wgrad=KernelTimer(lib, 'sidlsg_wgrad_bf16', wgrad_flops, stride=7), conv_wgrad=KernelTimer(lib, 'sidlsg_conv3x3_wgrad_bf16', conv_wgrad_flops, stride=5),
                     gn=KernelTimer(lib, 'sidlsg_groupnorm_fwd', gn_bytes, stride=5))
-    if not args.no_kernel_timing and rank == 0 and not use_graph:      # rooflines of the step's kernel families, sampled live over the timed region
+    if not args.no_kernel_timing and rank == 0 and not S.use_graph:      # rooflines of the step's kernel families, sampled live over the timed region
         timers = make_timers()
         for tm in timers.values():
             tm.__enter__()
     t0 = time.time()
+    first = None
     for it in range(args.warmup, args.warmup + args.steps):
         lf, lg = one_iteration(it)
+        if first is None:
+            first = (lf, lg)            # device scalars of the first timed step: read after the timed region
     sync()
     dt = time.time() - t0
+    if rank == 0 and loss_ref is not None and first is not None and (world == 1 or args.warmup == 0):
+        checks.append(check_losses(loss_ref, args.warmup, float(first[0]), float(first[1])))
+    comm = reducer.timing_report(world) if (reducer is not None and reducer.timing) else None
+    if reducer is not None:
+        reducer.enable_timing(False)
     for tm in timers.values():
         tm.__exit__()
     if world > 1:      # max over ranks, BEFORE anything rank-dependent: every collective below is executed by every rank
@@ -296,13 +355,13 @@ def main():
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         dt = float(tt)
     t_host = None
-    if use_graph:                  # per-kernel events cannot see inside a graph launch: sample eager iterations now
+    if S.use_graph:                  # per-kernel events cannot see inside a graph launch: sample eager iterations now
         hs = time.time()
         for it in range(args.warmup + args.steps, args.warmup + args.steps + 3):
             one_iteration(it)
         t_host = (time.time() - hs) / 3 * 1e3          # host time to enqueue one graphed iteration (inputs + text encode + replay)
         torch.cuda.synchronize()
-        use_graph = False
+        S.use_graph = False
         if not args.no_kernel_timing:                 # (iterations contain the gradient exchange: every rank runs them)
             if rank == 0:
                 timers = make_timers()
@@ -373,6 +432,27 @@ def main():
         'step_tflops': value * img_tflop, 'step_mfma_frac': value * img_tflop / (PEAK_BF16_TFLOPS * world),
         'graph': bool(args.graph), 'host_enqueue_ms_per_step': t_host, 'loss_fake': float(lf), 'loss_G': float(lg), 'peak_mem_gb': torch.cuda.max_memory_allocated(dev) / 2 ** 30,
     }
+    # parity at the BENCH workload: the losses of iteration 0 and of the first timed step against the stored fp32-mode values
+    # (tests/golden/bench_loss_reference.json, made by tools/make_bench_loss_reference.py with the HIP fp32-accurate mode, itself
+    # pinned to the CPU oracle at batch 1 and 2 by tests/test_gpu_unet.py); bounds = the bf16 bounds of the parity suite
+    if loss_ref is None:
+        out['loss_check'] = 'no reference stored for this configuration'
+    elif not checks:
+        out['loss_check'] = 'not run'
+    else:
+        out['loss_check'] = 'ok' if all(c['ok'] for c in checks) else 'FAILED'
+        out['loss_check_detail'] = checks
+    # multi-GPU: how long the compute stream stood still in FlatGradReducer.wait per step and network (the part of the gradient
+    # exchange NOT hidden under compute), and the all-reduce rate the messages saw
+    if comm is not None:
+        ex = {k: v / (args.warmup + args.steps) for k, v in comm['exposed_ms'].items()}
+        out['comm'] = {'exposed_ms_per_step': ex, 'comm_exposed_ms': sum(ex.values()), 'messages_per_step': comm['messages'] / (args.warmup + args.steps),
+                       'bytes_per_step': comm['bytes'] / (args.warmup + args.steps), 'allreduce_ms_per_step': comm['comm_ms'] / (args.warmup + args.steps),
+                       'allreduce_algbw_GBps': comm['algbw_GBps'], 'allreduce_busbw_GBps': comm['busbw_GBps'],
+                       'backend': torch.distributed.get_backend(), 'note': 'events on the waiting stream around FlatGradReducer.wait (exposed) and on the '
+                       'communication stream around every message (rate); warmup + timed iterations'}
+    else:
+        out['comm'] = None
     if teacher is not None:
         n_fwd = (2 if args.kappa != 1 else 1) * b
         tf = n_fwd * f_tflop / (teacher * 1e-3)

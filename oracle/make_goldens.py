@@ -14,6 +14,7 @@ Every file records the weight checksum of the seeded random nets it was made wit
                reference-held arithmetic for GroupNorm+SiLU+conv3x3+time-embedding-add+1x1-shortcut (= the SD
                ResnetBlock2D when adaptive_scale=False) and for softmax(QK^T/sqrt(d))V attention:
                pins those pieces of row A5 for both the oracle UNet layers and the HIP ops.
+  loop_k15_a1_n50.npz  the same loop for 50 iterations (loss-curve drift check of the bf16 path).
   bias_act.npz reference torch_utils/ops/bias_act.py::_bias_act_ref (+ autograd grads).
   sampler.npz  reference torch_utils/misc.py::InfiniteSampler order.
 """
@@ -110,6 +111,14 @@ def gen_loops():
               lr=1e-5, glr=1e-5, resolution=128)
     # kappa 4.5 (BASELINE config #3 guidance), batch_gpu 1
     _run_loop('k45_a1', iterations=3, batch_size=2, batch_gpu=1, seed=11, alpha=1.0, kappa=(4.5, 4.5, 4.5),
+              lr=1e-4, glr=1e-4, resolution=128)
+
+
+def gen_loop_long():
+    """tests/golden/loop_k15_a1_n50.npz: FIFTY iterations of the unmodified reference loop (kappa = 1.5, alpha = 1): the loss
+    CURVE over a stretch long enough for rounding drift of a reduced-precision path to show (the networks move ~50 Adam steps
+    apart from their common start, so the generator loss leaves its near-zero start)."""
+    _run_loop('k15_a1_n50', iterations=50, batch_size=2, batch_gpu=2, seed=21, alpha=1.0, kappa=(1.5, 1.5, 1.5),
               lr=1e-4, glr=1e-4, resolution=128)
 
 
@@ -241,7 +250,7 @@ if __name__ == '__main__':
     if len(sys.argv) > 2 and sys.argv[1] == '_loop2_worker':
         _loop2_worker(sys.argv[2])
         sys.exit(0)
-    which = sys.argv[1:] or ['glue', 'loops', 'bias_act', 'sampler', 'blocks', 'loop2']
+    which = sys.argv[1:] or ['glue', 'loops', 'bias_act', 'sampler', 'blocks', 'loop2', 'loop_long']
     if 'loop2' in which:
         gen_loop_2rank()
     if 'blocks' in which:
@@ -254,3 +263,5 @@ if __name__ == '__main__':
         gen_sampler()
     if 'loops' in which:
         gen_loops()
+    if 'loop_long' in which:
+        gen_loop_long()

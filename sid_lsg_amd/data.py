@@ -3,6 +3,10 @@
   * `PromptDataset`: item contract of the reference's training/aesthetics_dataset.py::ImageDataset
     (`(dummy_image, prompt)`; file lookup order aesthetics_6_plus.txt, aesthetics_625_plus.txt,
     aesthetics_65_plus.txt under `path`; attributes name / resolution), without the blobfile/PIL imports.
+  * `CaptionDataset`: the caption side of the reference's training/mscoco_dataset.py::ImageDataset (the COCO-2014 validation
+    set of `--data`, read only by the metrics: metrics/sid_metric_utils.py:419-421 draws the evaluation prompts from it through
+    `InfiniteSampler(seed=0)`): every image file that has a same-named `.txt` next to it, in the reference's sorted recursive
+    order; the pixels are never decoded here (the generator metrics only use the text).
   * `InfiniteSampler`: rank-strided, windowed-shuffle index stream with the semantics of
     torch_utils/misc.py:110-141 (it defines which prompt each rank sees at each step); pinned against the
     reference by tests/golden/sampler.npz.
@@ -35,6 +39,45 @@ class PromptDataset(torch.utils.data.Dataset):
 
     def __getitem__(self, idx):
         return torch.zeros(1, 4, 4), self.prompt_list[idx]
+
+
+class CaptionDataset(torch.utils.data.Dataset):
+    """(dummy_image, caption) items of an image + caption directory (training/mscoco_dataset.py:11-44), or of a plain text
+    file with one caption per line."""
+    IMAGE_EXT = ('jpg', 'jpeg', 'png', 'gif', 'webp')
+
+    def __init__(self, path, resolution=512, random_crop=False, random_flip=0.0):
+        self.name, self.resolution = 'MSCOCO-2014', resolution
+        if os.path.isfile(path):
+            with open(path, 'rt') as f:
+                self.captions = [row.strip() for row in f if row.strip()]
+        else:
+            self.captions = []
+            for txt in self._caption_files(path):
+                with open(txt, 'rt') as f:
+                    self.captions.append(f.read().strip())
+        if not self.captions:
+            raise IOError(f'no captions under {path}')
+
+    @classmethod
+    def _caption_files(cls, path):
+        out = []
+        for entry in sorted(os.listdir(path)):
+            full = os.path.join(path, entry)
+            parts = entry.split('.')
+            if parts[-1].strip().lower() in cls.IMAGE_EXT and len(parts) > 1:
+                txt = os.path.join(path, parts[0] + '.txt')
+                if os.path.exists(txt):
+                    out.append(txt)
+            elif os.path.isdir(full):
+                out.extend(cls._caption_files(full))
+        return out
+
+    def __len__(self):
+        return len(self.captions)
+
+    def __getitem__(self, idx):
+        return torch.zeros(1, 4, 4), self.captions[idx]
 
 
 class InfiniteSampler:

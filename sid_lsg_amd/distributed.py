@@ -82,15 +82,51 @@ class FlatGradReducer:
             raise ValueError('exchange_dtype must be None, torch.float32 or torch.bfloat16')
         self.exchange_dtype = exchange_dtype if exchange_dtype is not None else torch.float32
         self._pending = []          # (fp32 view, bf16 staging tensor) pairs to write back in wait()
+        # measurement (bench.py --gpus N, tests): with `timing` on, every message is bracketed by events on the communication
+        # stream and every wait() by events on the stream that waits, so a multi-GPU run reports how long the compute stream
+        # actually stood still for the exchange (`exposed`) next to the all-reduce rate it saw
+        self.timing = False
+        self._t_msgs, self._t_waits = [], []
+
+    def enable_timing(self, on=True):
+        self.timing = bool(on) and self.stream is not None
+        self._t_msgs, self._t_waits = [], []
+
+    def timing_report(self, world=None):
+        """After a device synchronisation: dict(exposed_ms={tag: total}, waits={tag: count}, messages, bytes, comm_ms,
+        algbw_GBps = bytes / time of the all-reduce messages, busbw_GBps = algbw * 2 (n - 1) / n)."""
+        world = get_world_size() if world is None else world
+        exposed, waits = {}, {}
+        for tag, e0, e1 in self._t_waits:
+            exposed[tag] = exposed.get(tag, 0.0) + e0.elapsed_time(e1)
+            waits[tag] = waits.get(tag, 0) + 1
+        nbytes = sum(b for b, _, _ in self._t_msgs)
+        ms = sum(e0.elapsed_time(e1) for _, e0, e1 in self._t_msgs)
+        alg = nbytes / (ms * 1e-3) / 1e9 if ms > 0 else None
+        return dict(exposed_ms=exposed, waits=waits, messages=len(self._t_msgs), bytes=nbytes, comm_ms=ms, algbw_GBps=alg,
+                    busbw_GBps=(alg * 2 * (world - 1) / world) if alg is not None else None)
 
     def _all_reduce(self, view):
         """One message (called with the communication stream current, if there is one)."""
+        e0 = None
+        if self.timing and view.is_cuda:
+            e0 = torch.cuda.Event(enable_timing=True)
+            e0.record()
         if self.exchange_dtype == torch.bfloat16:
             stage = view.to(torch.bfloat16)
-            self.handles.append(torch.distributed.all_reduce(stage, group=self.group, async_op=True))
+            h = torch.distributed.all_reduce(stage, group=self.group, async_op=True)
             self._pending.append((view, stage))
         else:
-            self.handles.append(torch.distributed.all_reduce(view, group=self.group, async_op=True))
+            stage = view
+            h = torch.distributed.all_reduce(view, group=self.group, async_op=True)
+        self.handles.append(h)
+        if e0 is not None:
+            # the backend runs the collective on its own stream: joining it into the communication stream here (device-side
+            # only) makes the event pair bracket exactly this message, and the next message's start event wait for it
+            h.wait()
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            self._t_msgs.append((stage.numel() * stage.element_size(), e0, e1))
 
     def start_range(self, flat_grad, lo, hi, max_elems=1 << 28):
         """all-reduce flat_grad[lo:hi] (in messages of <= max_elems elements = 1 GiB fp32) on the communication stream,
@@ -125,7 +161,18 @@ class FlatGradReducer:
             for o in range(0, n, step):
                 self._all_reduce(flat_grad[o:o + step])
 
-    def wait(self):
+    def wait(self, tag='all'):
+        t0 = None
+        if self.timing:
+            t0 = torch.cuda.Event(enable_timing=True)
+            t0.record()
+        self._wait()
+        if t0 is not None:
+            t1 = torch.cuda.Event(enable_timing=True)
+            t1.record()
+            self._t_waits.append((tag, t0, t1))
+
+    def _wait(self):
         for h in self.handles:
             h.wait()
         self.handles = []

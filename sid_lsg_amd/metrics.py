@@ -145,13 +145,38 @@ def resize_for_detector(images_u8, size=256):
     return x.round().clamp(0, 255).to(torch.uint8)
 
 
+class _PromptList:
+    """A list of prompts with the dataset item contract `(image, text)` (for callers that hold plain strings)."""
+
+    def __init__(self, prompts):
+        self.prompt_list = list(prompts)
+
+    def __len__(self):
+        return len(self.prompt_list)
+
+    def __getitem__(self, i):
+        return None, self.prompt_list[i]
+
+
 class MetricOptions:
     """What a metric needs (reference: sid_metric_utils.MetricOptions): a generator `G(latents=, contexts=, init_timesteps=)`
-    returning images in [-1, 1], the prompt source, the detectors, the real-set statistics."""
+    returning images in [-1, 1], the prompt source, the detectors, the real-set statistics.
+    Prompt source: `dataset_kwargs` (what the reference passes, sid_training_loop.py:636: the evaluation caption set of
+    `--data`, built by class name) or `dataset` (an object with that item contract) or `prompts` (a list of strings).  The
+    evaluation order is the reference's: `InfiniteSampler(dataset, rank, num_gpus, seed=0)` (sid_metric_utils.py:420)."""
 
-    def __init__(self, G, prompts, resolution=512, init_timestep=625, detector=None, real_stats=None, open_clip_detector=None,
-                 clip_score_fn=None, device=None, seed=0, batch_gen=4, detector_size=256, progress=None):
-        self.G, self.prompts, self.resolution, self.init_timestep = G, list(prompts), resolution, init_timestep
+    def __init__(self, G, prompts=None, resolution=512, init_timestep=625, detector=None, real_stats=None, open_clip_detector=None,
+                 clip_score_fn=None, device=None, seed=0, batch_gen=4, detector_size=256, progress=None, dataset_kwargs=None,
+                 dataset=None):
+        from .dnnlib_util import construct_class_by_name
+        if dataset is None and dataset_kwargs:
+            dataset = construct_class_by_name(**dataset_kwargs)
+        if dataset is None:
+            if prompts is None:
+                raise ValueError('metrics need a prompt source: dataset_kwargs, dataset or prompts')
+            dataset = _PromptList(prompts)
+        self.dataset = dataset
+        self.G, self.resolution, self.init_timestep = G, resolution, init_timestep
         self.detector, self.real_stats, self.open_clip_detector, self.clip_score_fn = detector, real_stats, open_clip_detector, clip_score_fn
         self.device = torch.device(device if device is not None else 'cuda')
         self.seed, self.batch_gen, self.detector_size, self.progress = seed, batch_gen, detector_size, progress
@@ -159,8 +184,11 @@ class MetricOptions:
 
 
 def generator_feature_stats(opts, num_gen, compute_clip=False):
-    """sid_metric_utils.py:412-510: this rank's share of `num_gen` samples -- prompts rank-strided like the InfiniteSampler,
-    z ~ N(0, I) from a per-rank generator -- through G, the detector and (optionally) the CLIP detectors."""
+    """sid_metric_utils.py:412-510: this rank's share of `num_gen` samples -- prompts in the order of the reference's
+    `InfiniteSampler(dataset, rank, num_gpus, seed=0)` (shuffled, rank-strided; :420), z ~ N(0, I) from a per-rank generator --
+    through G, the detector and (optionally) the CLIP detectors."""
+    from .data import InfiniteSampler
+    order = iter(InfiniteSampler(opts.dataset, rank=opts.rank, num_replicas=opts.num_gpus, seed=0))
     detector = load_detector(opts.detector, opts.device)
     oc = load_detector(opts.open_clip_detector, opts.device) if (compute_clip and opts.open_clip_detector is not None) else None
     stats = FeatureStats(capture_mean_cov=True, max_items=None, device=opts.device)
@@ -170,7 +198,7 @@ def generator_feature_stats(opts, num_gen, compute_clip=False):
     oc_scores, clip_scores = [], []
     for i in range(0, len(mine), opts.batch_gen):
         idx = mine[i:i + opts.batch_gen]
-        texts = [opts.prompts[j % len(opts.prompts)] for j in idx]
+        texts = [opts.dataset[next(order)][1] for _ in idx]
         z = torch.randn([len(idx), 4, lat, lat], device=opts.device, generator=gen)
         with torch.no_grad():
             img = opts.G(latents=z, contexts=texts, init_timesteps=opts.init_timestep * torch.ones(len(idx), device=opts.device, dtype=torch.long))

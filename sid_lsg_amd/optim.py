@@ -64,10 +64,24 @@ class FusedAdamEMA:
         self.ema = self.w16 = None
         self.grad_scale = 1.0
 
-    def attach(self, ema=None, w16=None):
-        """ema: flat fp32 buffer of the EMA network; w16: flat bf16 compute copy of this network."""
-        self.ema, self.w16 = ema, w16
+    def attach(self, ema=None, w16=None, owner=None):
+        """ema: flat fp32 buffer of the EMA network; w16: flat bf16 compute copy of this network; owner: the network that owns
+        w16 -- told (`mark_w16_rewritten`) when a step has rewritten the WHOLE copy as plain bf16(master), which is the
+        precondition of its next refresh_compute_weights(cast=False)."""
+        self.ema, self.w16, self._owner = ema, w16, owner
+        self._covered = 0
         return self
+
+    _owner = None
+    _covered = 0
+
+    def _w16_written(self, n):
+        if self.w16 is None or self._owner is None:
+            return
+        self._covered += n
+        if self._covered >= self.flat.numel():
+            self._covered = 0
+            self._owner.mark_w16_rewritten()
 
     def zero_grad(self, set_to_none=False):
         self.grad.zero_()   # normally unnecessary: step() zeroes the gradient buffer
@@ -92,6 +106,8 @@ class FusedAdamEMA:
         lib.sidlsg_adam_ema(self.flat.data_ptr(), self.grad.data_ptr(), ops._p(self.exp_avg), self.exp_avg_sq.data_ptr(),
                             ops._p(self.ema) if use_ema else None, ops._p(self.w16), self.hyper.data_ptr(), self.flat.numel(),
                             1 if zero_grad else 0, ops._s())
+        self._covered = 0
+        self._w16_written(self.flat.numel())
 
     def launch_range(self, lo, hi, use_ema=True, zero_grad=True):
         """The same kernel on elements [lo, hi) of the flat buffers (the update is elementwise: any partition of the buffer
@@ -105,12 +121,14 @@ class FusedAdamEMA:
         lib.sidlsg_adam_ema(off(self.flat, 4), off(self.grad, 4), off(self.exp_avg, 4), off(self.exp_avg_sq, 4),
                             off(self.ema, 4) if use_ema else None, off(self.w16, 2), self.hyper.data_ptr(), hi - lo,
                             1 if zero_grad else 0, ops._s())
+        self._w16_written(hi - lo)
 
     def begin_step(self, ema_beta=None):
         """Host half of a step: advance the step counter and put the step's scalars (bias corrections, EMA beta, 1/world) in
         device memory.  step() does this itself unless `external_scalars` is set -- the captured HIP graph of the training
         step (SiDStep.iteration_graphed) contains only launch(), and its owner calls begin_step() before every replay."""
         self.step_count += 1
+        self._covered = 0
         self.set_hyper(0.0 if ema_beta is None else ema_beta)
 
     external_scalars = False

@@ -99,8 +99,8 @@ class SiDStep:
         self.early_gfwd = os.environ.get('SIDLSG_EARLY_GFWD', '1') != '0'
         self._graphs, self._graph_warm = {}, False
         opt_fake.grad_scale = opt_G.grad_scale = 1.0 / world_size     # DDP mean, folded into the optimizer kernel
-        opt_fake.attach(ema=None, w16=fake_score.flat_w16)
-        opt_G.attach(ema=(G_ema.flat_params if (G_ema is not None and G_ema is not G) else None), w16=G.flat_w16)
+        opt_fake.attach(ema=None, w16=fake_score.flat_w16, owner=fake_score)
+        opt_G.attach(ema=(G_ema.flat_params if (G_ema is not None and G_ema is not G) else None), w16=G.flat_w16, owner=G)
         if not (G.compute_dtype == fake_score.compute_dtype == true_score.compute_dtype):
             raise ValueError('G, fake_score and true_score must share one compute dtype (they share the noisy CFG batch)')
         self.phi.requires_grad_(False)
@@ -249,7 +249,7 @@ class SiDStep:
         if self.exchange:
             if not started:
                 self.reducer.start(net.flat_grads)  # few large all-reduce(SUM) on the comm stream
-            self.reducer.wait()
+            self.reducer.wait(tag='fake_score' if net is self.psi else 'G')
         opt.step(ema_beta=ema_beta)                 # nan_to_num, /world, Adam, EMA, bf16 copy, zero_grad: one kernel
         net.refresh_compute_weights(cast=False)     # backward-data operands (transposed bf16 weights)
 

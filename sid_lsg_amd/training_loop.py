@@ -214,6 +214,12 @@ def training_loop(
                 ev.record()
         return inputs, ev
 
+    if prep_stream is not None:
+        # the text encoder's weight upload / casts and the weight broadcast were enqueued on the main stream
+        prep_stream.wait_stream(torch.cuda.current_stream())
+    # (the prefetch draws the prompt / dropout / noise RNG one iteration ahead: a state captured at a tick is one draw set past
+    # the iteration it belongs to; the training-state files do not carry RNG state -- neither do the reference's, :656 -- so a
+    # resumed run re-seeds exactly as the reference does)
     upcoming = build_inputs()
     while True:
         inputs, ev = upcoming
@@ -264,19 +270,32 @@ def training_loop(
         if snapshot_ticks is not None and (done or cur_tick % snapshot_ticks == 0 or cur_tick in SNAPSHOT_EXTRA_TICKS) and rank == 0 and run_dir:
             with open(os.path.join(run_dir, f'network-snapshot-{alpha:03f}-{cur_nimg // 1000:06d}.pkl'), 'wb') as f:
                 pickle.dump(dict(ema=G_ema), f)
-        # metrics at the snapshot cadence (sid_training_loop.py:616-639): the EMA generator through the one-step sampler + VAE
-        if metrics and snapshot_ticks is not None and (done or cur_tick % snapshot_ticks == 0 or cur_tick in SNAPSHOT_EXTRA_TICKS):
+        # metrics at the snapshot cadence, from tick 1 on (sid_training_loop.py:616-639, `if cur_tick>0`): the EMA generator
+        # through the one-step sampler + VAE
+        if metrics and cur_tick > 0 and snapshot_ticks is not None and (done or cur_tick % snapshot_ticks == 0 or cur_tick in SNAPSHOT_EXTRA_TICKS):
             from functools import partial
 
             from . import metrics as metric_main
             from .sd_util import sid_sd_sampler
+            if G_ema is not G:
+                # the fused Adam + EMA kernel writes G_ema's fp32 masters through raw pointers; its forward compute copies are
+                # only as new as the last refresh -- without this the scores would be those of the INITIAL EMA weights
+                G_ema.refresh_compute_weights()
             G_eval = partial(sid_sd_sampler, unet=G_ema, noise_scheduler=noise_scheduler, text_encoder=text_encoder, tokenizer=tokenizer,
                              resolution=resolution, dtype=torch.float32, return_images=True, vae=vae, train_sampler=False)
+            # evaluation prompts: the caption set of `dataset_kwargs` (--data, the COCO-2014 validation captions the real-set
+            # statistics of --data_stat were computed on; sid_training_loop.py:636, sid_metric_utils.py:419-421)
+            if dataset_kwargs:
+                msrc = dict(dataset_kwargs=dict(dataset_kwargs))
+            else:
+                dist.print0('WARNING: metrics without dataset_kwargs (--data): the evaluation prompts are the TRAINING prompts, so '
+                            'fid30k_full / fid_clip_30k_full are NOT comparable with the reference\'s COCO-2014 numbers')
+                msrc = dict(dataset=dataset_obj)
             for metric in metrics:
                 extra = dict(num_test=metric_num_test) if metric_num_test is not None else {}
-                result = metric_main.calc_metric(metric, G=G_eval, prompts=getattr(dataset_obj, 'prompt_list', None) or [dataset_obj[i][1] for i in range(len(dataset_obj))], resolution=resolution,
-                                                 init_timestep=init_timestep, detector=metric_pt_path, real_stats=metric_real_stats,
-                                                 open_clip_detector=metric_open_clip_path, device=device, **extra)
+                result = metric_main.calc_metric(metric, G=G_eval, resolution=resolution, init_timestep=init_timestep, detector=metric_pt_path,
+                                                 real_stats=metric_real_stats, open_clip_detector=metric_open_clip_path, device=device,
+                                                 **msrc, **extra)
                 metric_main.report_metric(result, run_dir=run_dir, alpha=alpha,
                                           snapshot_pkl=os.path.join(run_dir, f'network-snapshot-{alpha:03f}-{cur_nimg // 1000:06d}.pkl') if run_dir else None)
                 for k, v in result.results.items():

@@ -111,6 +111,9 @@ def build_config(o):
         raise click.ClickException('--train_mode 0 / --fake_score_use_lora are not supported')
     c.metrics, c.resolution = o.metrics, o.resolution
     c.metric_real_stats = o.data_stat
+    if o.metrics is not None and o.data:
+        # the evaluation caption set (reference: training.mscoco_dataset.ImageDataset on --data, sid_train.py:232-235)
+        c.dataset_kwargs = EasyDict(class_name='sid_lsg_amd.data.CaptionDataset', path=o.data, resolution=o.resolution, random_flip=o.xflip)
     c.data_loader_kwargs = EasyDict(pin_memory=True, num_workers=o.workers, prefetch_factor=2)
     c.dataset_prompt_text_kwargs = EasyDict(class_name='sid_lsg_amd.data.PromptDataset', path=o.data_prompt_text,
                                             resolution=o.resolution, random_flip=o.xflip, prompt_only=True)

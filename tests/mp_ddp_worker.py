@@ -6,6 +6,8 @@
     mp_ddp_worker.py nccl <out>        FlatGradReducer (whole-buffer start(), segment-wise start_range() from the backward
                                        markers, bf16 exchange) on backend 'nccl' (= RCCL) at whatever WORLD_SIZE the launcher
                                        gives; world 1 forces the collectives to run (min_world=1).
+    mp_ddp_worker.py messages <out>    the 4 x 0.86 GB all-reduce messages of one full-size network on RCCL (world 1, forced)
+                                       with FlatGradReducer's timing on.
 Each rank writes <out>.rank<r>.npz; the launcher asserts on the contents."""
 import contextlib
 import os
@@ -166,5 +168,35 @@ def run_graph(out):
     torch.distributed.destroy_process_group()
 
 
+def run_messages(out):
+    """The gradient exchange of ONE full-size network (859.5 M fp32 values -> 4 all-reduce messages of ~0.86 GB) on RCCL,
+    collectives forced at world 1, with FlatGradReducer's timing on: what `bench.py --gpus N` reports as `comm`."""
+    from sid_lsg_amd.distributed import FlatGradReducer
+    torch.cuda.set_device(0)
+    dev = torch.device('cuda', 0)
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    torch.distributed.init_process_group('nccl', device_id=dev)
+    world = torch.distributed.get_world_size()
+    n = 859_520_964 + 60          # SD1.5 parameter total (the flat buffer pads every tensor to 64 elements: a little more)
+    g = torch.randn(n, device=dev)
+    want = g.clone() * world
+    warm = torch.ones(1 << 20, device=dev)
+    torch.distributed.all_reduce(warm)
+    red = FlatGradReducer(min_world=1)
+    red.enable_timing()
+    for _ in range(2):
+        g.copy_(want / world)
+        red.start(g)
+        # a compute-stream kernel the exchange overlaps with, then the wait whose duration is the exposed time
+        (warm * 2).sum()
+        red.wait(tag='G')
+        torch.cuda.synchronize()
+    rep = red.timing_report(world)
+    np.savez(f'{out}.rank0.npz', messages=rep['messages'] // 2, bytes=rep['bytes'] // 2, comm_ms=rep['comm_ms'] / 2,
+             exposed_ms=rep['exposed_ms']['G'] / 2, algbw_GBps=rep['algbw_GBps'], unchanged=bool(torch.equal(g, want)))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
 if __name__ == '__main__':
-    {'ddp': run_ddp, 'nccl': run_nccl, 'graph': run_graph}[sys.argv[1]](sys.argv[2])
+    {'ddp': run_ddp, 'nccl': run_nccl, 'graph': run_graph, 'messages': run_messages}[sys.argv[1]](sys.argv[2])

@@ -144,3 +144,22 @@ def test_bench_under_torchrun_two_ranks(dev):
     assert out['roofline']['launches'] > 0 and out['roofline']['isolated']['launches'] > 0 and out['teacher_pass']['ms'] > 0
     for k in ('loss_fake', 'loss_G'):
         assert np.isfinite(out[k])
+    # the exposed-communication diagnosis a multi-GPU run must carry
+    c = out['comm']
+    print('comm:', c)
+    assert set(c['exposed_ms_per_step']) == {'fake_score', 'G'} and c['comm_exposed_ms'] >= 0
+    assert c['messages_per_step'] >= 2 and c['bytes_per_step'] > 0 and c['allreduce_algbw_GBps'] > 0 and c['backend'] == 'gloo'
+    assert out['loss_check'] in ('ok', 'no reference stored for this configuration')
+
+
+def test_rccl_world1_timing_of_the_full_size_messages(dev, tmp_path):
+    """The exchange of one full-size network (859.5 M fp32 gradients = 4 messages of 0.86 GB) through RCCL at world size 1
+    (collectives forced): message count / bytes / rate and the exposed wait as FlatGradReducer reports them -- the figures
+    `bench.py --gpus N` prints as `comm`.  World 1 proves the plumbing and the reporting, not xGMI bandwidth."""
+    out = str(tmp_path / 'msg')
+    res = launch(1, 'messages', out)
+    assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
+    r = np.load(f'{out}.rank0.npz')
+    print({k: r[k].tolist() for k in r.files})
+    assert int(r['messages']) == 4 and int(r['bytes']) >= 859_520_964 * 4 and float(r['algbw_GBps']) > 0
+    assert float(r['exposed_ms']) > 0 and float(r['comm_ms']) > 0 and bool(r['unchanged'])

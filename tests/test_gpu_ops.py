@@ -328,6 +328,38 @@ def test_cross_attention_prescaled_queries(dev):
     close(kd.grad, kr.grad, 2e-2, 'dkv')
 
 
+@pytest.mark.parametrize('N,heads,D', [(4096, 8, 40), (1024, 8, 80), (256, 8, 160), (4096, 5, 64)])
+def test_prescaled_attention_is_as_accurate_as_plain(dev, N, heads, D):
+    """the `_ps` path (softmax scale folded into the queries BEFORE their bf16 rounding, exponent arguments straight
+    out of the QK^T MFMA) measured against the plain path on SD-sized shapes, each against the same fp64 attention of the fp32
+    queries: the pre-scaled path must not be less accurate (rel. l2 of output and gradients within 1.25x + 2e-4 of the plain
+    path's) -- so a looser loss tolerance elsewhere cannot hide a systematic error of the _ps kernels."""
+    from sid_lsg_amd import ops
+    B, C = 1, heads * D
+    c = D ** -0.5 * 1.4426950408889634
+    g = torch.Generator().manual_seed(11)
+    q32 = torch.randn(B, N, C, generator=g)
+    kv = (torch.randn(B, N, 2 * C, generator=g)).to(BF16)
+    do = torch.randn(B, N, C, generator=g).to(BF16)
+    # fp64 reference on the fp32 queries (what both bf16 roundings approximate)
+    qr, kr = q32.double().requires_grad_(), kv.double().requires_grad_()
+    yr = attn_ref(qr, kr[..., :C], kr[..., C:], heads)
+    yr.backward(do.double())
+    res = {}
+    for name, ps in (('plain', False), ('ps', True)):
+        qb = ((q32 * c) if ps else q32).to(BF16)
+        qkv = torch.cat([qb, kv], -1).to(dev).requires_grad_()
+        y = ops.self_attention(qkv, heads, prescaled=ps)
+        y.backward(do.to(dev))
+        l2 = lambda a, b: float((a.double().cpu() - b).norm() / b.norm())     # noqa: E731
+        res[name] = (l2(y, yr.detach()), l2(qkv.grad[..., :C], qr.grad), l2(qkv.grad[..., C:2 * C], kr.grad[..., :C]),
+                     l2(qkv.grad[..., 2 * C:], kr.grad[..., C:]))
+    print(f'N {N} heads {heads} d {D}: rel l2 (out, dq, dk, dv)  plain {["%.2e" % v for v in res["plain"]]}  pre-scaled {["%.2e" % v for v in res["ps"]]}')
+    for a, b, what in zip(res['ps'], res['plain'], ('out', 'dq', 'dk', 'dv')):
+        assert a <= 1.25 * b + 2e-4, f'{what}: pre-scaled {a:.3e} vs plain {b:.3e}'
+        assert a < 1e-2
+
+
 @pytest.mark.parametrize('B,N,L,heads,D', [(2, 256, 77, 2, 40), (2, 64, 13, 4, 32), (1, 1024, 77, 8, 80), (2, 100, 77, 2, 160)])
 def test_cross_attention(dev, B, N, L, heads, D):
     from sid_lsg_amd import ops

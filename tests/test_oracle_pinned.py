@@ -64,6 +64,22 @@ def test_loop_matches_reference(golden_dir, name):
     np.testing.assert_allclose(np.array(fixtures.checksum(psi))[1], g['fake_score_checksum'][1], rtol=1e-6)
 
 
+def test_loop_50_iterations_matches_reference(golden_dir):
+    """The 50-iteration curve of the unmodified reference loop (tests/golden/loop_k15_a1_n50.npz): the restatement stays within
+    north_star's 1e-3 of every recorded loss over the whole stretch (two fp32 implementations of 50 Adam(beta1 = 0) steps)."""
+    g = _load(golden_dir, 'loop_k15_a1_n50.npz')
+    cfg = str(g['cfg'])
+    kw = {k[3:]: g[k].tolist() for k in g.files if k.startswith('kw_')}
+    kw['kappa'] = tuple(kw['kappa'])
+    res = sid_ref.training_loop_ref(lambda: fixtures.factory(cfg), [str(p) for p in g['prompts']], **kw)
+    vals = np.array([v for _, v in res['losses']])
+    ref = g['loss_values']
+    assert vals.shape == ref.shape == (100,)
+    rel = np.abs(vals - ref) / np.abs(ref)
+    print('max rel error over 50 iterations: fake', rel[0::2].max(), 'G', rel[1::2].max())
+    assert rel.max() < 1e-3
+
+
 def test_infinite_sampler_matches_reference(golden_dir):
     g = _load(golden_dir, 'sampler.npz')
     for key in g.files:
