@@ -395,7 +395,7 @@ def main():
         _ops._WGRAD_SIDE = wgrad_side
     # north_star's second figure: MFMA utilisation of the CFG teacher pass alone (phi forward on the [uncond; cond] batch of
     # 2b samples + guidance + x0), timed with events on a few extra passes after the timed region (rank 0)
-    teacher = None
+    teacher = pair = None
     if timers:
         from sid_lsg_amd.sd_util import hip_denoise, hip_prepare_denoise
         with torch.no_grad():
@@ -412,6 +412,24 @@ def main():
             e1.record()
             torch.cuda.synchronize()
             teacher = e0.elapsed_time(e1) / 5.0
+            # the same for the GROUPED pass of phase B: fake-score network + teacher on the stacked batch of 4b samples, one launch
+            # per layer for both (HipUNet2DCondition.forward_pair; sid_step.py)
+            pair = None
+            if step.grouped:
+                from sid_lsg_amd import ops as _o
+
+                def pair_pass():
+                    ef, er = S.psi.forward_pair(phi, prep.xin, prep.tt, prep.ctx)
+                    _o.cfg_x0(ef, prep.xt, prep.s0, prep.s1, args.kappa, True, torch.bfloat16)
+                    _o.cfg_x0(er, prep.xt, prep.s0, prep.s1, args.kappa, True, torch.bfloat16)
+                pair_pass()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(5):
+                    pair_pass()
+                e1.record()
+                torch.cuda.synchronize()
+                pair = e0.elapsed_time(e1) / 5.0
     if rank != 0:
         _shutdown(world)
         return
@@ -430,7 +448,7 @@ def main():
                                f'batch_gpu={b}, fp32 masters + bf16 MFMA compute, Adam(beta1=0)+EMA, random-init weights',
                    'global_batch': batch_size, 'parallelism': f'dp{world}', 'teacher_weights': args.teacher_weights},
         'step_tflops': value * img_tflop, 'step_mfma_frac': value * img_tflop / (PEAK_BF16_TFLOPS * world),
-        'graph': bool(args.graph), 'host_enqueue_ms_per_step': t_host, 'loss_fake': float(lf), 'loss_G': float(lg), 'peak_mem_gb': torch.cuda.max_memory_allocated(dev) / 2 ** 30,
+        'graph': bool(args.graph), 'grouped_frozen_pass': bool(step.grouped), 'host_enqueue_ms_per_step': t_host, 'loss_fake': float(lf), 'loss_G': float(lg), 'peak_mem_gb': torch.cuda.max_memory_allocated(dev) / 2 ** 30,
     }
     # parity at the BENCH workload: the losses of iteration 0 and of the first timed step against the stored fp32-mode values
     # (tests/golden/bench_loss_reference.json, made by tools/make_bench_loss_reference.py with the HIP fp32-accurate mode, itself
@@ -458,6 +476,11 @@ def main():
         tf = n_fwd * f_tflop / (teacher * 1e-3)
         out['teacher_pass'] = {'what': f'phi forward on the CFG batch of {n_fwd} samples + guidance + x0 (no grad)', 'ms': teacher,
                                'tflops': tf, 'mfma_frac': tf / PEAK_BF16_TFLOPS}
+        if pair is not None:
+            tf2 = 2 * n_fwd * f_tflop / (pair * 1e-3)
+            out['frozen_pair_pass'] = {'what': f'GROUPED pass of phase B: fake-score network + teacher on the stacked batch of {2 * n_fwd} samples '
+                                               '(one launch per layer for both networks) + guidance + x0 (no grad)', 'ms': pair, 'tflops': tf2,
+                                       'mfma_frac': tf2 / PEAK_BF16_TFLOPS, 'vs_two_separate_passes': 2 * teacher / pair}
     if timers:
         KERNELS = {'conv': 'implicit-GEMM conv3x3 fwd + dgrad (gemm_v3_kernel<1>, gemm_bf16_kernel<*,*,1|2>)',
                    'gemm': 'dense GEMM fwd + dgrad: Linear / 1x1 conv over tokens (gemm_v3_kernel<0>, gemm_bf16_kernel<*,*,0>, gemm_finish_kernel)',

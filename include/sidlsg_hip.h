@@ -82,6 +82,33 @@ int sidlsg_layernorm_bwd_nblocks(int rows); /* host: ws = nblocks*C*2 floats */
 int sidlsg_layernorm_bwd(const void* x, const void* dy, const float* stats, const float* gamma, const void* dres, void* dx,
                          float* dgamma, float* dbeta, float* ws, int rows, int C, void* stream);
 
+/* ---- grouped launches: TWO networks of identical architecture evaluated on ONE stacked batch ---------------------------
+ * Phase B of the step evaluates the frozen fake-score network and the frozen teacher on identical inputs
+ * (`sid_sd_denoise(unet=fake_score, ...)` and `sid_sd_denoise(unet=true_score, ...)`, sid_training_loop.py:494-506, each a CFG
+ * batch through sid_sd_util.py:259-265).  Here both run as ONE pass over a stacked batch [set 0 samples ; set 1 samples]:
+ * every weight-bearing kernel takes a second parameter set and picks it per block (rows / samples of the second half), every
+ * parameter-free kernel (attention, GEGLU, SiLU, concat) simply sees twice the batch.  One grid of 2x the blocks fills the
+ * chip where either network's grid alone does not (16x16 / 8x8 stages, the time-embedding MLP, the 77-token K/V
+ * projections), and the frozen passes issue half the launches.  M (rows) resp. B (samples) must be even; the halves need not
+ * be tile aligned.  Same epilogue contract as the ungrouped entry points; res / rowvec / outputs are stacked like the input.
+ * The backward-data pass of a layer is the same entry point with (dY, transposed weight set 0, transposed weight set 1).
+ * bf16 only; frozen networks only (there is no grouped weight gradient). */
+int sidlsg_gemm_bf16_g2(const void* A, int lda, const void* W, const void* W1, void* C, int ldc, const float* bias, const float* bias1,
+                        const void* res, int ldres, const float* rowvec, int ld_rowvec, int rows_per_batch, int M, int N, int K,
+                        float alpha, int flags, void* stream);
+int sidlsg_conv3x3_bf16_g2(const void* X, int ldx, const void* W, const void* W1, void* Y, int ldc, const float* bias, const float* bias1,
+                           const void* res, int ldres, const float* rowvec, int ld_rowvec, int B, int H, int Wd, int Cin, int Cout,
+                           int stride, int ups, float alpha, int flags, void* stream);
+int sidlsg_groupnorm_fwd_g2(const void* x, const float* gamma, const float* beta, const float* gamma1, const float* beta1, void* y,
+                            float* stats, float* ws, int B, int HW, int C, int G, float eps, int silu, void* stream);
+int sidlsg_groupnorm_bwd_g2(const void* x, const void* dy, const float* stats, const float* gamma, const float* beta, const float* gamma1,
+                            const float* beta1, const void* dres, void* dx, float* ws, int B, int HW, int C, int G, int silu,
+                            void* stream);
+int sidlsg_layernorm_fwd_g2(const void* x, const float* gamma, const float* beta, const float* gamma1, const float* beta1, void* y,
+                            float* stats, int rows, int C, float eps, void* stream);
+int sidlsg_layernorm_bwd_g2(const void* x, const void* dy, const float* stats, const float* gamma, const float* gamma1, const void* dres,
+                            void* dx, int rows, int C, void* stream);
+
 /* ---- attention (diffusers Attention + AttnProcessor2_0 / xformers; sid_sd_util.py:102-113) --
  * O = softmax(Q K^T D^-1/2) V per head; Q/K/V/O are strided views ([b][token][h*D + d], token
  * stride ld*, batch stride bs*, in elements) so the fused QKV projection is consumed in place.

@@ -48,7 +48,26 @@ struct GemmParams {
     int group_m;                 // v3: m-tiles per group of the logical tile order (see gemm_v3_kernel)
     float* ws;                   // split-K: fp32 [splits][M][N] partial-sum slabs
     const float* wscale;         // fp8-weight path: per-output-channel dequantisation scale [N] (else null)
+    // grouped launch (sidlsg_*_g2: two networks of identical shape evaluated on one stacked activation matrix): rows [0, Mg) are
+    // contracted with (W, bias), rows [Mg, M) with (W1, bias1).  Mg = 0: ordinary launch.  Mtot: row count of a split-K slab
+    // (= M; kept separately because a block narrows its M to its own set's row range, see group_select)
+    const bf16* W1;
+    const float* bias1;
+    int Mg, Mtot;
 };
+
+// m-tiles of a launch: each set of a grouped launch starts on a tile boundary of its own (Mg need not be a multiple of BM)
+__host__ __device__ inline int m_tiles_rt(const GemmParams& p, int bm) { return p.Mg ? 2 * ((p.Mg + bm - 1) / bm) : (p.M + bm - 1) / bm; }
+// the block's set: rewrites p (a by-value kernel argument: plain scalar registers) to that set's weights, bias and row limit
+// and returns the block's first row.  Everything downstream (loader range checks, epilogue, stores) keeps using p unchanged.
+template <int BM>
+__device__ __forceinline__ int group_select(GemmParams& p, int mt) {
+    if (!p.Mg) return mt * BM;
+    const int tg = (p.Mg + BM - 1) / BM;
+    if (mt >= tg) { p.W = p.W1; p.bias = p.bias1; return p.Mg + (mt - tg) * BM; }
+    p.M = p.Mg;
+    return mt * BM;
+}
 
 enum { F_OUT_F32 = 1, F_SILU = 2, F_ACCUM = 4 };
 
@@ -295,14 +314,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_kernel(GemmParams p) { 
 
     // ---- XCD-aware block -> tile map: blocks that share an A row-panel sit on one XCD (own L2)
     const int tiles_n = (p.N + BN - 1) / BN;
-    const int tiles_m = (p.M + BM - 1) / BM;
+    const int tiles_m = m_tiles_rt(p, BM);
     const int nblk = tiles_n * tiles_m;
     int bid = blockIdx.x;
     {
         const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
-    const int m0 = (bid / tiles_n) * BM;
+    const int m0 = group_select<BM>(p, bid / tiles_n);
     const int n0 = (bid % tiles_n) * BN;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -481,7 +500,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_kernel(GemmParams p) { 
             for (int ni = 0; ni < NT; ni++) {
                 const bool paired = (ni | 1) < NT;
                 const int nb = n0 + wn0 + (paired ? 32 * (ni >> 1) + lg * 8 + (ni & 1) * 4 : 16 * ni + lg * 4);
-                float* dst = p.ws + ((size_t)blockIdx.y * p.M + m) * p.N + nb;     // this split's slab: plain 16-byte stores
+                float* dst = p.ws + ((size_t)blockIdx.y * p.Mtot + m) * p.N + nb;     // this split's slab: plain 16-byte stores
                 if (nb + 4 <= p.N) *reinterpret_cast<f32x4*>(dst) = acc[ni][mi];
                 else
                     for (int r = 0; r < 4; r++)
@@ -679,10 +698,11 @@ __global__ void gemm_finish_kernel(GemmParams p, int nsp) {      // nsp: number 
     }
     for (; sidx < nsp; sidx++) v += *reinterpret_cast<const f32x4*>(p.ws + sidx * slab + i);
     const float* rv = p.rowvec ? p.rowvec + (size_t)(m / p.rows_per_batch) * p.ldrv : nullptr;
+    const float* bias = (p.Mg && m >= p.Mg) ? p.bias1 : p.bias;      // grouped launch: the row's set
 #pragma unroll
     for (int e = 0; e < 4; e++) {
         float x = v[e] * p.alpha;
-        if (p.bias) x += p.bias[n + e];
+        if (bias) x += bias[n + e];
         if (rv) x += rv[n + e];
         if (p.res) x += bf2f(p.res[(size_t)m * p.ldres + n + e]);
         if (p.flags & F_SILU) x = silu_f(x);
@@ -782,7 +802,7 @@ extern "C" int sidlsg_exp_set_trace(void* ptr) { return hipMemcpyToSymbol(HIP_SY
 // -- was measured in the same session: 30-50 % SLOWER on every SD shape (e.g. conv 64x64 320->320 124 -> 195 us, FF-in 239 ->
 // 355 us).  Two co-resident blocks per CU hide more than a deeper pipeline in one; the variant is not in the build.)
 template <int MODE, int STAGES>   // MODE 0 dense, 1 conv3x3 with Cin % 64 == 0
-DEVFN void gemm_v3_body(const GemmParams& p) {
+DEVFN void gemm_v3_body(GemmParams& p) {
     constexpr int BM = 128, BN = 160, MT = 4, NT = 5;
     constexpr bool SCHED_FENCE = SIDLSG_V3_SCHED_FENCE;
     constexpr int STAGE = (BM + BN) * BK;
@@ -796,7 +816,7 @@ DEVFN void gemm_v3_body(const GemmParams& p) {
     // at 16x16 -- every XCD streamed the whole weight matrix; measured 154 -> 130 us on 4096x10240x1280 and 90 -> 72
     // us on the 8x8 2560->1280 conv.)
     const int tiles_n = (p.N + BN - 1) / BN;
-    const int tiles_m = (p.M + BM - 1) / BM;
+    const int tiles_m = m_tiles_rt(p, BM);
 #ifdef SIDLSG_EXP_K1             // measurement build: one K-tile per output tile (prologue + epilogue cost)
     const int nk_all = 1;
 #else
@@ -821,7 +841,7 @@ DEVFN void gemm_v3_body(const GemmParams& p) {
         mt = first_m + in_g % gm;
         nt = in_g / gm;
     }
-    const int m0 = mt * BM;
+    const int m0 = group_select<BM>(p, mt);
     const int n0 = nt * BN;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1049,7 +1069,7 @@ DEVFN void gemm_v3_body(const GemmParams& p) {
             for (int ni = 0; ni < NT; ni++) {
                 const bool paired = (ni | 1) < NT;
                 const int nb = n0 + wn0 + (paired ? 32 * (ni >> 1) + lg * 8 + (ni & 1) * 4 : 16 * ni + lg * 4);
-                float* dst = p.ws + ((size_t)split * p.M + m) * p.N + nb;
+                float* dst = p.ws + ((size_t)split * p.Mtot + m) * p.N + nb;
                 if (nb + 4 <= p.N) *reinterpret_cast<f32x4*>(dst) = acc[ni][mi];
                 else
                     for (int r = 0; r < 4; r++)
@@ -1086,7 +1106,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_v3_kernel(GemmParams p) { ge
 
 template <int MODE>
 static int launch_gemm_v3(const GemmParams& p, hipStream_t s) {
-    const int tiles = ((p.M + 127) / 128) * ((p.N + 159) / 160);
+    const int tiles = m_tiles_rt(p, 128) * ((p.N + 159) / 160);
     const size_t lds = (size_t)2 * (128 + 160) * BK * sizeof(bf16);
     static bool attr_done = false;
     if (!attr_done) {
@@ -1445,7 +1465,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void gemm_as_kernel(GemmParams p) {
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
     const int mt = bid / items_per_panel, it = bid - mt * items_per_panel;
-    const int m0 = mt * BM;
+    const int m0 = group_select<BM>(p, mt);
     const int nt0 = it * tpi, ntl = min(tpi, tiles_n - nt0);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1652,7 +1672,7 @@ static int launch_gemm_as(const GemmParams& p, hipStream_t s) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_as_kernel<NKT, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done = true;
     }
-    const int panels = (p.M + 127) / 128, tiles_n = p.N / 160;
+    const int panels = m_tiles_rt(p, 128), tiles_n = p.N / 160;
     // work item = (panel, range of column tiles): whole panels when they fill the chip, else split the column range so that
     // ~512 items exist (an item re-loads its A panel: keep ranges >= 2 tiles when N allows)
     int tpi = tiles_n;
@@ -1667,7 +1687,7 @@ static int launch_gemm_as(const GemmParams& p, hipStream_t s) {
 
 template <int BM, int BN, int MODE>
 static int launch_gemm(const GemmParams& p, hipStream_t s) {
-    const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
+    const int tiles = m_tiles_rt(p, BM) * ((p.N + BN - 1) / BN);
     const size_t lds = (size_t)2 * (BM + BN) * BK * sizeof(bf16);
     static bool attr_done = false;
     if (!attr_done) {
@@ -1686,7 +1706,9 @@ static int launch_gemm(const GemmParams& p, hipStream_t s) {
 }
 
 template <int MODE>
-static int dispatch_gemm(const GemmParams& p, hipStream_t s) {
+static int dispatch_gemm(const GemmParams& pin, hipStream_t s) {
+    GemmParams p = pin;
+    p.Mtot = p.M;
     // N multiple of 160 (every SD channel count is a multiple of 320) -> exact 160-wide tiles and, for dense rows /
     // Cin % 64 == 0 convs, the direct-to-LDS kernel (v3); otherwise 128-wide; narrow outputs (conv_out, dgrad of conv_in)
     // -> 64-wide.  Small pixel counts (8x8 / 16x16 stages, small batches) would give < 256 tiles = idle CUs: split K when
@@ -1699,7 +1721,7 @@ static int dispatch_gemm(const GemmParams& p, hipStream_t s) {
             (!p.res || (p.ldres & 7) == 0) && (long long)p.M * p.ldc < (1ll << 30) && (!p.res || (long long)p.M * p.ldres < (1ll << 30)))
             return launch_gemm_as<5>(p, s);
     }
-    auto tiles = [&](int bm, int bn) { return (long long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn); };
+    auto tiles = [&](int bm, int bn) { return (long long)m_tiles_rt(p, bm) * ((p.N + bn - 1) / bn); };
     const bool n160 = p.N % 160 == 0;
     static const bool v3_on = !(getenv("SIDLSG_GEMM_V3") && atoi(getenv("SIDLSG_GEMM_V3")) == 0);   // A/B switch
     const bool v3 = n160 && v3_on && MODE != 2;
@@ -2343,6 +2365,51 @@ int sidlsg_gemm_bf16(const void* A, int lda, const void* W, void* C, int ldc, co
     if (!fits31(ab) || !fits31(wb)) return SIDLSG_EINVAL;
     p.a_bytes = (unsigned)ab; p.w_bytes = (unsigned)wb;
     return dispatch_gemm<0>(p, (hipStream_t)stream);
+}
+
+// Grouped dense GEMM: two weight sets on one stacked activation matrix (M even): rows [0, M/2) use (W, bias), rows [M/2, M)
+// use (W1, bias1); res / rowvec / C are stacked like A.  One launch fills the chip where each half alone would not (the frozen
+// fake-score and teacher passes of phase B read identical inputs: sid_training_loop.py:494-506).  bf16 only.
+int sidlsg_gemm_bf16_g2(const void* A, int lda, const void* W, const void* W1, void* C, int ldc, const float* bias, const float* bias1,
+                        const void* res, int ldres, const float* rowvec, int ld_rowvec, int rows_per_batch, int M, int N, int K,
+                        float alpha, int flags, void* stream) {
+    if (!W1 || (M & 1) || (bias != nullptr) != (bias1 != nullptr)) return SIDLSG_EINVAL;
+    GemmParams p{};
+    p.A = (const bf16*)A; p.W = (const bf16*)W; p.C = C; p.bias = bias; p.res = (const bf16*)res; p.rowvec = rowvec;
+    p.W1 = (const bf16*)W1; p.bias1 = bias1; p.Mg = M / 2;
+    p.ldrv = ld_rowvec > 0 ? ld_rowvec : N;
+    p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldc = ldc; p.ldres = ldres; p.rows_per_batch = rows_per_batch;
+    p.alpha = alpha; p.flags = flags;
+    if (int e = check_common(p)) return e;
+    const unsigned long long ab = ((unsigned long long)(M - 1) * lda + K) * 2ull, wb = (unsigned long long)N * K * 2ull;
+    if (!fits31(ab) || !fits31(wb)) return SIDLSG_EINVAL;
+    p.a_bytes = (unsigned)ab; p.w_bytes = (unsigned)wb;
+    return dispatch_gemm<0>(p, (hipStream_t)stream);
+}
+
+// Grouped 3x3 convolution: samples [0, B/2) use (W, bias), samples [B/2, B) use (W1, bias1) (B even).
+int sidlsg_conv3x3_bf16_g2(const void* X, int ldx, const void* W, const void* W1, void* Y, int ldc, const float* bias, const float* bias1,
+                           const void* res, int ldres, const float* rowvec, int ld_rowvec, int B, int H, int Wd, int Cin, int Cout,
+                           int stride, int ups, float alpha, int flags, void* stream) {
+    if (stride != 1 && stride != 2) return SIDLSG_EINVAL;
+    if ((Cin & 7) || !W1 || (B & 1) || (bias != nullptr) != (bias1 != nullptr)) return SIDLSG_EINVAL;
+    if (ups && ((H | Wd) & 1)) return SIDLSG_EINVAL;
+    GemmParams p{};
+    p.A = (const bf16*)X; p.W = (const bf16*)W; p.C = Y; p.bias = bias; p.res = (const bf16*)res; p.rowvec = rowvec;
+    p.W1 = (const bf16*)W1; p.bias1 = bias1;
+    p.ldrv = ld_rowvec > 0 ? ld_rowvec : Cout;
+    p.H = H; p.Wd = Wd; p.Cin = Cin; p.stride = stride; p.ups = ups;
+    p.Ho = (H + 2 - 3) / stride + 1; p.Wo = (Wd + 2 - 3) / stride + 1;
+    p.M = B * p.Ho * p.Wo; p.N = Cout; p.K = 9 * Cin; p.lda = ldx; p.ldc = ldc; p.ldres = ldres;
+    p.Mg = p.M / 2;
+    p.rows_per_batch = p.Ho * p.Wo; p.alpha = alpha; p.flags = flags;
+    if (int e = check_common(p)) return e;
+    const int Hs = ups ? H / 2 : H, Ws = ups ? Wd / 2 : Wd;
+    const unsigned long long ab = (((unsigned long long)B * Hs * Ws - 1) * ldx + Cin) * 2ull, wb = (unsigned long long)Cout * 9 * Cin * 2ull;
+    if (!fits31(ab) || !fits31(wb)) return SIDLSG_EINVAL;
+    p.a_bytes = (unsigned)ab; p.w_bytes = (unsigned)wb;
+    if (Cin % 64 == 0) return dispatch_gemm<1>(p, (hipStream_t)stream);
+    return dispatch_gemm<2>(p, (hipStream_t)stream);
 }
 
 // Implicit-GEMM 3x3 convolution, pad 1, NHWC.  X: [B][Hs][Ws][ldx] (ldx >= Cin, pixel stride),

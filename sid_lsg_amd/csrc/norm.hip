@@ -101,9 +101,11 @@ DEVFN void gn_fold_partials(const float* __restrict__ p, const GnGeom& g, float*
 template <typename T, bool F8 = false>      // F8: y receives e4m3 bytes (same [B][HW][C] geometry)
 __global__ void gn_apply_kernel(const T* __restrict__ x, const float* __restrict__ part,
                                 const float* __restrict__ gamma, const float* __restrict__ beta,
-                                T* __restrict__ y, float* __restrict__ stats, GnGeom g, float eps, int act) {
+                                T* __restrict__ y, float* __restrict__ stats, GnGeom g, float eps, int act,
+                                const float* __restrict__ gamma1, const float* __restrict__ beta1, int split) {
     extern __shared__ float sm[];  // mean[G], rstd[G]
     const int b = blockIdx.y, chunk = blockIdx.x;
+    if (gamma1 && b >= split) { gamma = gamma1; beta = beta1; }      // grouped launch: samples [split, B) belong to the second network
     // fold the nch per-chunk partials of every group: all threads load (one (sum, sumsq) pair each, independent loads), LDS
     // float adds combine them -- a serial loop of nch dependent-latency loads in G threads cost several us per block
     gn_fold_partials(part + (size_t)b * g.nch * g.G * 2, g, sm);
@@ -159,9 +161,11 @@ __global__ void gn_apply_kernel(const T* __restrict__ x, const float* __restrict
 template <typename T>
 __global__ void gn_bwd_stats_kernel(const T* __restrict__ x, const T* __restrict__ dy,
                                     const float* __restrict__ stats, const float* __restrict__ gamma,
-                                    const float* __restrict__ beta, float* __restrict__ part, GnGeom g, int act) {
+                                    const float* __restrict__ beta, float* __restrict__ part, GnGeom g, int act,
+                                    const float* __restrict__ gamma1, const float* __restrict__ beta1, int split) {
     extern __shared__ float sm[];  // [rows][C][2]
     const int b = blockIdx.y, chunk = blockIdx.x;
+    if (gamma1 && b >= split) { gamma = gamma1; beta = beta1; }
     const int cc = threadIdx.x % g.C8, rl = threadIdx.x / g.C8;
     float mu[8], rs[8], ga[8], be[8], a[8], c[8];
 #pragma unroll
@@ -223,7 +227,9 @@ template <typename T>
 __global__ void gn_bwd_apply_kernel(const T* __restrict__ x, const T* __restrict__ dy,
                                     const float* __restrict__ stats, const float* __restrict__ gamma,
                                     const float* __restrict__ beta, const float* __restrict__ part,
-                                    const T* __restrict__ add, T* __restrict__ dx, GnGeom g, int act) {
+                                    const T* __restrict__ add, T* __restrict__ dx, GnGeom g, int act,
+                                    const float* __restrict__ gamma1, const float* __restrict__ beta1, int split) {
+    if (gamma1 && (int)blockIdx.y >= split) { gamma = gamma1; beta = beta1; }
     // add (may be null): gradient arriving at x through its OTHER consumer (residual / shortcut branch); summed here
     // instead of in a separate elementwise kernel
     extern __shared__ float sm[];  // s1[G], s2[G]
@@ -309,12 +315,14 @@ constexpr int LN_MAXCH = 4;   // chunks of 8 per lane -> C <= 2048
 template <typename T, int NCH, int R, bool F8 = false>      // F8: y receives e4m3 bytes
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, T* __restrict__ y,
-                                                     float* __restrict__ stats, int rows, int C, float eps, int rpw) {
+                                                     float* __restrict__ stats, int rows, int C, float eps, int rpw,
+                                                     const float* __restrict__ gamma1, const float* __restrict__ beta1, int split) {
     const int lane = threadIdx.x & 63;
     const int C8 = C >> 3;
     const int rbeg = (blockIdx.x * 4 + (threadIdx.x >> 6)) * rpw;      // rpw rows per wave
     const int rend = min(rows, rbeg + rpw);
     if (rbeg >= rows) return;
+    if (gamma1 && rbeg >= split) { gamma = gamma1; beta = beta1; }     // grouped launch (split % rpw == 0): rows [split, rows) = second network
     float ga[NCH][8], be[NCH][8];
 #pragma unroll
     for (int i = 0; i < NCH; i++) {
@@ -387,9 +395,11 @@ template <typename T, int NCH, int R>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy,
                                                      const float* __restrict__ stats, const float* __restrict__ gamma,
                                                      const T* __restrict__ add, T* __restrict__ dx,
-                                                     float* __restrict__ part, int rows, int C, int rows_per_block) {
+                                                     float* __restrict__ part, int rows, int C, int rows_per_block,
+                                                     const float* __restrict__ gamma1, int split) {
     extern __shared__ float dyn[];  // [4 waves][C][2] for the param-grad partials
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (gamma1 && (int)blockIdx.x * rows_per_block >= split) gamma = gamma1;     // grouped launch (split % rows_per_block == 0)
     const int C8 = C >> 3;
     float ga[NCH][8], pg[NCH][8], pb[NCH][8];
 #pragma unroll
@@ -512,14 +522,16 @@ int sidlsg_groupnorm_nchunks(int B, int HW, int C, int G) {
 // y = act(GroupNorm(x)); x,y: [B][HW][C]; stats: [B][G][2] fp32 (mean, rstd) saved for backward
 template <typename T, bool F8 = false>
 static int groupnorm_fwd_t(const void* x, const float* gamma, const float* beta, void* y, float* stats, float* ws,
-                           int B, int HW, int C, int G, float eps, int silu, void* stream) {
+                           int B, int HW, int C, int G, float eps, int silu, void* stream, const float* gamma1 = nullptr,
+                           const float* beta1 = nullptr) {
     GnGeom g; if (int e = gn_geom(g, B, HW, C, G)) return e;
+    if (gamma1 && ((B & 1) || !beta1)) return SIDLSG_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     const int threads = g.C8 * g.rows;
     hipLaunchKernelGGL(gn_stats_kernel<T>, dim3(g.nch, B), dim3(threads), (size_t)g.rows * C * 2 * sizeof(float), s,
                        (const T*)x, ws, g);
     hipLaunchKernelGGL((gn_apply_kernel<T, F8>), dim3(g.nch, B), dim3(threads), (size_t)2 * G * (1 + GN_FOLD) * sizeof(float), s,
-                       (const T*)x, ws, gamma, beta, (T*)y, stats, g, eps, silu);
+                       (const T*)x, ws, gamma, beta, (T*)y, stats, g, eps, silu, gamma1, beta1, B / 2);
     return sidlsg_last_error();
 }
 
@@ -527,14 +539,15 @@ static int groupnorm_fwd_t(const void* x, const float* gamma, const float* beta,
 template <typename T>
 static int groupnorm_bwd_t(const void* x, const void* dy, const float* stats, const float* gamma, const float* beta,
                            const void* dres, void* dx, float* dgamma, float* dbeta, float* ws, int B, int HW, int C, int G,
-                           int silu, void* stream) {
+                           int silu, void* stream, const float* gamma1 = nullptr, const float* beta1 = nullptr) {
     GnGeom g; if (int e = gn_geom(g, B, HW, C, G)) return e;
+    if (gamma1 && ((B & 1) || !beta1 || dgamma || dbeta)) return SIDLSG_EINVAL;      // grouped: frozen networks (no parameter gradients)
     hipStream_t s = (hipStream_t)stream;
     const int threads = g.C8 * g.rows;
     hipLaunchKernelGGL(gn_bwd_stats_kernel<T>, dim3(g.nch, B), dim3(threads), (size_t)g.rows * C * 2 * sizeof(float), s,
-                       (const T*)x, (const T*)dy, stats, gamma, beta, ws, g, silu);
+                       (const T*)x, (const T*)dy, stats, gamma, beta, ws, g, silu, gamma1, beta1, B / 2);
     hipLaunchKernelGGL(gn_bwd_apply_kernel<T>, dim3(g.nch, B), dim3(threads), (size_t)2 * G * (1 + GN_FOLD) * sizeof(float), s,
-                       (const T*)x, (const T*)dy, stats, gamma, beta, ws, (const T*)dres, (T*)dx, g, silu);
+                       (const T*)x, (const T*)dy, stats, gamma, beta, ws, (const T*)dres, (T*)dx, g, silu, gamma1, beta1, B / 2);
     if (dgamma && dbeta) {
         const int P = B * g.nch;
         hipLaunchKernelGGL(colsum_reduce2_kernel, reduce_grid(C, P), dim3(256), 0, s, ws, dgamma, dbeta, P, (size_t)C * 2, C);
@@ -545,15 +558,20 @@ static int groupnorm_bwd_t(const void* x, const void* dy, const float* stats, co
 // y = LayerNorm(x) over C; x,y [rows][C]; stats [rows][2]
 template <typename T, bool F8 = false>
 static int layernorm_fwd_t(const void* x, const float* gamma, const float* beta, void* y, float* stats, int rows, int C,
-                           float eps, void* stream) {
+                           float eps, void* stream, const float* gamma1 = nullptr, const float* beta1 = nullptr) {
     if (C % 8 || C > 8 * 64 * LN_MAXCH || rows <= 0) return SIDLSG_EINVAL;
+    if (gamma1 && ((rows & 1) || !beta1)) return SIDLSG_EINVAL;
     const int nch = (C / 8 + 63) / 64;
     const int R = nch <= 1 ? 4 : 2;
     // rows per wave: enough waves to fill the chip (>= ~4096), at most 16 rows (amortises the gamma/beta loads)
     int rpw = rows / 4096; rpw = rpw < R ? R : (rpw > 16 ? 16 : rpw); rpw = (rpw + R - 1) / R * R;
+    if (gamma1) {       // grouped launch: a wave's row range must not straddle the two networks' halves
+        while (rpw > R && (rows / 2) % rpw) rpw -= R;
+        if ((rows / 2) % rpw) return SIDLSG_EINVAL;
+    }
     const dim3 grid((rows + 4 * rpw - 1) / (4 * rpw));
 #define LN_FWD(NCH, RR) hipLaunchKernelGGL((ln_fwd_kernel<T, NCH, RR, F8>), grid, dim3(256), 0, (hipStream_t)stream, (const T*)x, gamma, \
-                                           beta, (T*)y, stats, rows, C, eps, rpw)
+                                           beta, (T*)y, stats, rows, C, eps, rpw, gamma1, beta1, rows / 2)
     if (nch == 1) LN_FWD(1, 4); else if (nch == 2) LN_FWD(2, 2); else if (nch == 3) LN_FWD(3, 2); else LN_FWD(4, 2);
 #undef LN_FWD
     return sidlsg_last_error();
@@ -565,16 +583,24 @@ static int layernorm_bwd_nblocks(int rows) {
 // dx, and dgamma/dbeta (+=) when non-null; ws: [nblocks][C][2] floats
 template <typename T>
 static int layernorm_bwd_t(const void* x, const void* dy, const float* stats, const float* gamma, const void* dres, void* dx,
-                           float* dgamma, float* dbeta, float* ws, int rows, int C, void* stream) {
+                           float* dgamma, float* dbeta, float* ws, int rows, int C, void* stream, const float* gamma1 = nullptr) {
     if (C % 8 || C > 8 * 64 * LN_MAXCH || rows <= 0) return SIDLSG_EINVAL;
     hipStream_t s = (hipStream_t)stream;
-    const int nb = layernorm_bwd_nblocks(rows);
-    const int rpb = (rows + nb - 1) / nb;
+    int nb = layernorm_bwd_nblocks(rows);
+    int rpb = (rows + nb - 1) / nb;
+    if (gamma1) {       // grouped launch (frozen networks): blocks must not straddle the halves
+        if ((rows & 1) || dgamma || dbeta) return SIDLSG_EINVAL;
+        const int half = rows / 2;
+        int nbh = layernorm_bwd_nblocks(half);
+        rpb = (half + nbh - 1) / nbh;
+        while (half % rpb) rpb++;
+        nb = 2 * (half / rpb);
+    }
     const bool pg = dgamma && dbeta;
     const int nch = (C / 8 + 63) / 64;
     const size_t lds = pg ? (size_t)4 * C * 2 * sizeof(float) : 0;
 #define LN_BWD(NCH, R) hipLaunchKernelGGL((ln_bwd_kernel<T, NCH, R>), dim3(nb), dim3(256), lds, s, (const T*)x, (const T*)dy, \
-                                          stats, gamma, (const T*)dres, (T*)dx, pg ? ws : nullptr, rows, C, rpb)
+                                          stats, gamma, (const T*)dres, (T*)dx, pg ? ws : nullptr, rows, C, rpb, gamma1, rows / 2)
     if (nch == 1) LN_BWD(1, 2); else if (nch == 2) LN_BWD(2, 2); else if (nch == 3) LN_BWD(3, 1); else LN_BWD(4, 1);
 #undef LN_BWD
     if (pg) {
@@ -606,6 +632,28 @@ int sidlsg_layernorm_fwd_fp8(const void* x, const float* gamma, const float* bet
 int sidlsg_groupnorm_fwd_fp8(const void* x, const float* gamma, const float* beta, void* y8, float* stats, float* ws, int B, int HW, int C, int G,
                              float eps, int silu, void* stream) {
     return groupnorm_fwd_t<bf16, true>(x, gamma, beta, y8, stats, ws, B, HW, C, G, eps, silu, stream);
+}
+// Grouped variants (bf16; two frozen networks on one stacked batch): samples / rows of the first half are normalised with
+// (gamma, beta), those of the second half with (gamma1, beta1).  Backward: data gradient only.
+int sidlsg_groupnorm_fwd_g2(const void* x, const float* gamma, const float* beta, const float* gamma1, const float* beta1, void* y, float* stats,
+                            float* ws, int B, int HW, int C, int G, float eps, int silu, void* stream) {
+    if (!gamma1) return SIDLSG_EINVAL;
+    return groupnorm_fwd_t<bf16>(x, gamma, beta, y, stats, ws, B, HW, C, G, eps, silu, stream, gamma1, beta1);
+}
+int sidlsg_groupnorm_bwd_g2(const void* x, const void* dy, const float* stats, const float* gamma, const float* beta, const float* gamma1,
+                            const float* beta1, const void* dres, void* dx, float* ws, int B, int HW, int C, int G, int silu, void* stream) {
+    if (!gamma1) return SIDLSG_EINVAL;
+    return groupnorm_bwd_t<bf16>(x, dy, stats, gamma, beta, dres, dx, nullptr, nullptr, ws, B, HW, C, G, silu, stream, gamma1, beta1);
+}
+int sidlsg_layernorm_fwd_g2(const void* x, const float* gamma, const float* beta, const float* gamma1, const float* beta1, void* y, float* stats,
+                            int rows, int C, float eps, void* stream) {
+    if (!gamma1) return SIDLSG_EINVAL;
+    return layernorm_fwd_t<bf16>(x, gamma, beta, y, stats, rows, C, eps, stream, gamma1, beta1);
+}
+int sidlsg_layernorm_bwd_g2(const void* x, const void* dy, const float* stats, const float* gamma, const float* gamma1, const void* dres, void* dx,
+                            int rows, int C, void* stream) {
+    if (!gamma1) return SIDLSG_EINVAL;
+    return layernorm_bwd_t<bf16>(x, dy, stats, gamma, dres, dx, nullptr, nullptr, nullptr, rows, C, stream, gamma1);
 }
 SIDLSG_BOTH(sidlsg_layernorm_bwd, layernorm_bwd_t,
             (const void* x, const void* dy, const float* stats, const float* gamma, const void* dres, void* dx, float* dgamma, float* dbeta, float* ws, int rows, int C, void* stream),

@@ -222,14 +222,76 @@ class Fp8Weight:
         return self.q.view(torch.float8_e4m3fn).float() * self.scale[:, None]
 
 
+# ---- grouped launches: two networks of identical architecture on one stacked batch ----------------------------------------
+class Pair(tuple):
+    """(set 0, set 1): the same parameter (forward weight copy, backward-data operand, bias, norm scale / shift) of the two
+    networks of a grouped pass.  The first half of the stacked batch is evaluated with set 0, the second half with set 1
+    (include/sidlsg_hip.h "grouped launches")."""
+    __slots__ = ()
+
+    def __new__(cls, a, b):
+        return super().__new__(cls, (a, b))
+
+    @property
+    def shape(self):
+        return self[0].shape
+
+
+_dual = None     # while a grouped pass is being recorded: id(tensor of network 0) -> the same tensor of network 1
+
+
+class dual_networks:
+    """`with ops.dual_networks(partner_map): net0.forward_nhwc(stacked inputs)` -- every weight-bearing op issued inside looks
+    its parameters' partners up in `partner_map` (HipUNet2DCondition.partner_map(other)) and launches the grouped (`_g2`) entry
+    point with both sets; parameter-free ops just see the stacked batch.  The autograd nodes keep the pairs, so the backward
+    (data gradients only: both networks are frozen) needs no context."""
+
+    def __init__(self, partner_map):
+        self.map = partner_map
+
+    def __enter__(self):
+        global _dual
+        if _dual is not None:
+            raise RuntimeError('grouped passes do not nest')
+        _dual = self.map
+        return self
+
+    def __exit__(self, *exc):
+        global _dual
+        _dual = None
+        return False
+
+
+def _pair(t):
+    """(t, partner of t) under dual_networks; None stays None."""
+    if t is None:
+        return None
+    try:
+        return Pair(t, _dual[id(t)])
+    except KeyError:
+        raise RuntimeError('grouped pass: a parameter of the first network has no partner in the second one (different '
+                           'architectures, fp8 weights, or compute copies re-created after the partner map was built)') from None
+
+
 # raw launches
 def gemm(a, w16, out=None, bias=None, res=None, rowvec=None, rows_per_batch=1, alpha=1.0, out_f32=False, lda=None):
-    """C[M,N] = alpha*A[M,K] W[N,K]^T + bias + rowvec[m//rpb] + res"""
+    """C[M,N] = alpha*A[M,K] W[N,K]^T + bias + rowvec[m//rpb] + res.  w16 / bias may be Pairs (grouped launch: rows of the
+    first half of A with set 0, of the second half with set 1)."""
     M = a.shape[0]
     K = w16.shape[1]
     N = w16.shape[0]
     lda = a.stride(0) if lda is None else lda
     f32 = a.dtype == F32
+    if isinstance(w16, Pair):
+        if a.dtype != BF16 or w16[0].dtype != BF16 or w16[1].dtype != BF16 or w16[0].shape != w16[1].shape:
+            raise RuntimeError('grouped GEMM: bf16 activations and two bf16 weight matrices of one shape')
+        ensure_workspace(a.device)
+        if out is None:
+            out = torch.empty((M, N), device=a.device, dtype=F32 if out_f32 else BF16)
+        lib.sidlsg_gemm_bf16_g2(_p(a), lda, _p(w16[0]), _p(w16[1]), _p(out), out.stride(0), _p(bias[0]) if bias is not None else None,
+                                _p(bias[1]) if bias is not None else None, _p(res), res.stride(0) if res is not None else 0, _p(rowvec),
+                                rowvec.stride(0) if rowvec is not None else 0, rows_per_batch, M, N, K, float(alpha), 1 if out_f32 else 0, _s())
+        return out
     if f32 and w16.dtype != F32:
         raise RuntimeError('fp32 activations need the fp32 compute copy of the weights')
     ensure_workspace(a.device)
@@ -255,6 +317,15 @@ def conv3x3(x, w16, bias=None, res=None, rowvec=None, stride=1, ups=0, out_f32=F
     Cout = w16.shape[0]
     Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
     f32 = x.dtype == F32
+    if isinstance(w16, Pair):
+        if x.dtype != BF16 or w16[0].dtype != BF16 or w16[1].dtype != BF16 or w16[0].shape != w16[1].shape:
+            raise RuntimeError('grouped conv: bf16 activations and two bf16 weight matrices of one shape')
+        ensure_workspace(x.device)
+        out = torch.empty((B, Ho, Wo, Cout), device=x.device, dtype=F32 if out_f32 else BF16)
+        lib.sidlsg_conv3x3_bf16_g2(_p(x), Cin, _p(w16[0]), _p(w16[1]), _p(out), Cout, _p(bias[0]) if bias is not None else None,
+                                   _p(bias[1]) if bias is not None else None, _p(res), Cout if res is not None else 0, _p(rowvec),
+                                   rowvec.stride(0) if rowvec is not None else 0, B, H, W, Cin, Cout, stride, ups, 1.0, 1 if out_f32 else 0, _s())
+        return out
     if f32 and w16.dtype != F32:
         raise RuntimeError('fp32 activations need the fp32 compute copy of the weights')
     ensure_workspace(x.device)
@@ -320,7 +391,41 @@ class _Linear(torch.autograd.Function):
         return dx, None, None, None, None, dres, drv, None, None
 
 
+class _LinearG2(torch.autograd.Function):
+    """_Linear for the grouped pass of two FROZEN networks: parameters arrive as Pairs, the backward is the data gradient only
+    (nothing of the forward input is kept alive for a weight gradient)."""
+
+    @staticmethod
+    def forward(ctx, x, bias, w16, w16t, res, rowvec, rows_per_batch, out_f32):
+        _chk(x, BF16)
+        y = gemm(x, w16, bias=bias, res=res, rowvec=rowvec, rows_per_batch=rows_per_batch, out_f32=out_f32)
+        ctx.w16t, ctx.rpb = w16t, rows_per_batch
+        ctx.has_res, ctx.has_rv = res is not None, rowvec is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = dy.contiguous()
+        if dy.dtype != BF16:
+            dy = dy.to(BF16)
+        dx = gemm(dy, ctx.w16t) if ctx.needs_input_grad[0] else None
+        drv = colsum(dy, ctx.rpb, per_batch=True) if (ctx.has_rv and ctx.needs_input_grad[5]) else None
+        dres = dy if (ctx.has_res and ctx.needs_input_grad[4]) else None
+        return dx, None, None, None, dres, drv, None, None
+
+
+def _frozen(*params):
+    for p in params:
+        for q in (p if isinstance(p, Pair) else (p,)):
+            if q is not None and q.requires_grad:
+                raise RuntimeError('a grouped pass evaluates FROZEN networks: call requires_grad_(False) on both first')
+
+
 def linear(x, weight, bias, w16, w16t, res=None, rowvec=None, rows_per_batch=1, out_f32=False):
+    if _dual is not None:
+        wp, bp = _pair(weight), _pair(bias)
+        _frozen(wp, bp)
+        return _LinearG2.apply(x, Pair(bp[0], bp[1]) if bp is not None else None, _pair(w16), _pair(w16t), res, rowvec, rows_per_batch, out_f32)
     return _Linear.apply(x, weight, bias, w16, w16t, res, rowvec, rows_per_batch, out_f32)
 
 
@@ -388,7 +493,46 @@ class _Conv3x3(torch.autograd.Function):
         return dx, None, None, None, None, dres, drv, None, None, None, None
 
 
+class _Conv3x3G2(torch.autograd.Function):
+    """_Conv3x3 for the grouped pass of two frozen networks (Pairs; data gradient only)."""
+
+    @staticmethod
+    def forward(ctx, x, bias, w16, w16t, res, rowvec, stride, ups, out_f32):
+        _chk(x, BF16)
+        y = conv3x3(x, w16, bias=bias, res=res, rowvec=rowvec, stride=stride, ups=ups, out_f32=out_f32)
+        ctx.w16t = w16t
+        ctx.cfg = (stride, ups, res is not None, rowvec is not None, x.shape)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        stride, ups, has_res, has_rv, xs = ctx.cfg
+        dy = dy.contiguous()
+        if dy.dtype != BF16:
+            dy = dy.to(BF16)
+        B, Ho, Wo, Cout = dy.shape
+        dx = None
+        if ctx.needs_input_grad[0]:
+            g = dy
+            if stride == 2:
+                g = torch.empty((B, xs[1], xs[2], Cout), device=dy.device, dtype=BF16)
+                lib.sidlsg_zero_insert2(_p(dy), _p(g), B, Ho, Wo, xs[1], xs[2], Cout, _s())
+            dx = conv3x3(g, ctx.w16t)
+            if ups:
+                full = dx
+                dx = torch.empty(xs, device=dy.device, dtype=BF16)
+                lib.sidlsg_sumpool2x2(_p(full), _p(dx), B, xs[1], xs[2], xs[3], _s())
+        drv = colsum(dy.view(B * Ho * Wo, Cout), Ho * Wo, per_batch=True) if (has_rv and ctx.needs_input_grad[5]) else None
+        dres = dy if (has_res and ctx.needs_input_grad[4]) else None
+        return dx, None, None, None, dres, drv, None, None, None
+
+
 def conv3x3_op(x, weight, bias, w16, w16t, res=None, rowvec=None, stride=1, ups=0, out_f32=False, bias_p=None):
+    if _dual is not None:
+        wp, bp = _pair(weight), _pair(bias)
+        _frozen(wp, bp)
+        bq = _pair(bias_p) if bias_p is not None else bp        # (conv_out: the zero-padded bias of the padded output channels)
+        return _Conv3x3G2.apply(x, Pair(bq[0], bq[1]) if bq is not None else None, _pair(w16), _pair(w16t), res, rowvec, stride, ups, out_f32)
     return _Conv3x3.apply(x, weight, bias, w16, w16t, res, rowvec, stride, ups, out_f32, bias_p)
 
 
@@ -436,7 +580,55 @@ class _GroupNorm(torch.autograd.Function):
         return dx, None, None, None, None, None, None
 
 
+class _GroupNormG2(torch.autograd.Function):
+    """_GroupNorm for the grouped pass: samples of the first half of the batch use (gamma, beta) of set 0, the others set 1."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, groups, eps, silu, fork):
+        _chk(x, BF16)
+        B, C = x.shape[0], x.shape[-1]
+        HW = x.numel() // (B * C)
+        n = lib.sidlsg_groupnorm_ws_floats.raw(B, HW, C, groups)
+        if n < 0 or B % 2:
+            raise RuntimeError(f'grouped groupnorm: unsupported shape B={B} HW={HW} C={C} G={groups}')
+        ws = torch.empty(n, device=x.device, dtype=F32)
+        stats = torch.empty((B, groups, 2), device=x.device, dtype=F32)
+        y = torch.empty_like(x)
+        lib.sidlsg_groupnorm_fwd_g2(_p(x), _p(gamma[0]), _p(beta[0]), _p(gamma[1]), _p(beta[1]), _p(y), _p(stats), _p(ws), B, HW, C, groups,
+                                    float(eps), int(silu), _s())
+        ctx.save_for_backward(x, stats)
+        ctx.params = (gamma, beta)
+        ctx.cfg = (B, HW, C, groups, int(silu), n)
+        if fork:
+            return y, x.view(x.shape)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy, dkeep=None):
+        x, stats = ctx.saved_tensors
+        gamma, beta = ctx.params
+        B, HW, C, groups, silu, n = ctx.cfg
+        if dy is None:
+            return dkeep, None, None, None, None, None, None
+        dy = dy.contiguous()
+        if dy.dtype != BF16:
+            dy = dy.to(BF16)
+        if dkeep is not None:
+            dkeep = dkeep.contiguous()
+            if dkeep.dtype != BF16:
+                dkeep = dkeep.to(BF16)
+        ws = torch.empty(n, device=x.device, dtype=F32)
+        dx = torch.empty_like(x)
+        lib.sidlsg_groupnorm_bwd_g2(_p(x), _p(dy), _p(stats), _p(gamma[0]), _p(beta[0]), _p(gamma[1]), _p(beta[1]),
+                                    _p(dkeep) if dkeep is not None else None, _p(dx), _p(ws), B, HW, C, groups, silu, _s())
+        return dx, None, None, None, None, None, None
+
+
 def group_norm(x, gamma, beta, groups, eps, silu, fork=False):
+    if _dual is not None:
+        gp, bp = _pair(gamma), _pair(beta)
+        _frozen(gp, bp)
+        return _GroupNormG2.apply(x, gp, bp, groups, eps, silu, fork)
     return _GroupNorm.apply(x, gamma, beta, groups, eps, silu, fork)
 
 
@@ -478,7 +670,68 @@ class _LayerNorm(torch.autograd.Function):
         return dx, None, None, None, None
 
 
+class _LayerNormG2(torch.autograd.Function):
+    """_LayerNorm for the grouped pass: token rows of the first half use set 0, of the second half set 1.  Halves whose row count
+    the kernel cannot align its per-wave row ranges with (tiny test networks) run as two ordinary launches on the half views."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps, fork):
+        _chk(x, BF16)
+        C = x.shape[-1]
+        rows = x.numel() // C
+        if rows % 2:
+            raise RuntimeError('grouped layernorm: odd row count')
+        half = rows // 2
+        y = torch.empty_like(x)
+        stats = torch.empty((rows, 2), device=x.device, dtype=F32)
+        grouped = half % 16 == 0
+        if grouped:
+            lib.sidlsg_layernorm_fwd_g2(_p(x), _p(gamma[0]), _p(beta[0]), _p(gamma[1]), _p(beta[1]), _p(y), _p(stats), rows, C, float(eps), _s())
+        else:
+            es = x.element_size()
+            for h in (0, 1):
+                lib.sidlsg_layernorm_fwd(x.data_ptr() + h * half * C * es, _p(gamma[h]), _p(beta[h]), y.data_ptr() + h * half * C * es,
+                                         stats.data_ptr() + h * half * 8, half, C, float(eps), _s())
+        ctx.save_for_backward(x, stats)
+        ctx.params, ctx.grouped = gamma, grouped
+        if fork:
+            return y, x.view(x.shape)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy, dkeep=None):
+        x, stats = ctx.saved_tensors
+        gamma = ctx.params
+        if dy is None:
+            return dkeep, None, None, None, None
+        C = x.shape[-1]
+        rows = x.numel() // C
+        half = rows // 2
+        dy = dy.contiguous()
+        if dy.dtype != BF16:
+            dy = dy.to(BF16)
+        if dkeep is not None:
+            dkeep = dkeep.contiguous()
+            if dkeep.dtype != BF16:
+                dkeep = dkeep.to(BF16)
+        dx = torch.empty_like(x)
+        if ctx.grouped:
+            lib.sidlsg_layernorm_bwd_g2(_p(x), _p(dy), _p(stats), _p(gamma[0]), _p(gamma[1]), _p(dkeep) if dkeep is not None else None, _p(dx),
+                                        rows, C, _s())
+        else:
+            es = x.element_size()
+            for h in (0, 1):
+                o = h * half * C * es
+                lib.sidlsg_layernorm_bwd(x.data_ptr() + o, dy.data_ptr() + o, stats.data_ptr() + h * half * 8, _p(gamma[h]),
+                                         dkeep.data_ptr() + o if dkeep is not None else None, dx.data_ptr() + o, None, None, None, half, C, _s())
+        return dx, None, None, None, None
+
+
 def layer_norm(x, gamma, beta, eps=1e-5, fork=False):
+    if _dual is not None:
+        gp, bp = _pair(gamma), _pair(beta)
+        _frozen(gp, bp)
+        return _LayerNormG2.apply(x, gp, bp, eps, fork)
     return _LayerNorm.apply(x, gamma, beta, eps, fork)
 
 

@@ -87,6 +87,15 @@ class SiDStep:
         self.side = None
         if os.environ.get('SIDLSG_TEACHER_STREAM', '1') != '0' and torch.cuda.is_available():     # A/B switch (+2 % images/s on MI355X)
             self.side = ops.side_stream(G.flat_params.device)
+        # Grouped frozen passes (include/sidlsg_hip.h "grouped launches"): the two networks run as ONE pass over the stacked batch
+        # [psi's CFG batch ; phi's CFG batch] -- every contraction / normalisation launch carries both parameter sets and picks
+        # one per block, so the grids of the 16x16 / 8x8 stages, the time-embedding MLP and the 77-token K/V projections are
+        # twice as large and the frozen passes issue half the launches (forward AND data-gradient backward).
+        # $SIDLSG_GROUPED_FROZEN: 1 = on, 0 = off (the two-stream path above, kept as the A/B control), auto (default) = on unless
+        # gradients are exchanged between ranks: there psi's exchange + optimizer step hide under the teacher's forward, which a
+        # joint pass (psi must be up to date when it starts) would give up.
+        mode = os.environ.get('SIDLSG_GROUPED_FROZEN', 'auto').lower()
+        self.grouped = (mode == '1' or (mode == 'auto' and not self.exchange)) and self._can_group()
         # opt-in: optimizer steps issued segment-wise from inside the backward, on their own stream (_SegmentedUpdate).  Same
         # results; measured NEUTRAL on one MI355X (221.5 / 220.9 vs 221.7 / 220.8 ms per iteration): the trace shows 3.2 of
         # the 4.8-5.5 ms of each optimizer kernel moving under the backward, and the kernels it then shares HBM with
@@ -104,6 +113,12 @@ class SiDStep:
         if not (G.compute_dtype == fake_score.compute_dtype == true_score.compute_dtype):
             raise ValueError('G, fake_score and true_score must share one compute dtype (they share the noisy CFG batch)')
         self.phi.requires_grad_(False)
+
+    def _can_group(self):
+        from .unet import HipUNet2DCondition
+        a, b = self.psi, self.phi
+        return (torch.cuda.is_available() and type(a) is HipUNet2DCondition and type(b) is HipUNet2DCondition and a.cfg == b.cfg
+                and a.compute_dtype == b.compute_dtype == torch.bfloat16 and 'fp8' not in a._flat and 'fp8' not in b._flat)
 
     def enable_segmented_optimizer(self, on=True):
         self.seg_opt = bool(on)
@@ -194,6 +209,17 @@ class SiDStep:
                                    act_dtype=self.psi.compute_dtype)
         k2 = self.k2 if guided else 1.0
         k4 = self.k4 if guided else 1.0
+        if self.grouped and self._can_group():
+            # one grouped pass over [psi's batch ; phi's batch] (:494-506: two sid_sd_denoise calls on identical inputs)
+            if before_fake_eval is not None:
+                before_fake_eval()
+            eps_f, eps_r = self.psi.forward_pair(self.phi, prep.xin, prep.tt, prep.ctx)
+            cd = self.psi.compute_dtype
+            y_fake = ops.cfg_x0(eps_f, prep.xt, prep.s0, prep.s1, k2, True, cd)     # u + k (c - u), then x0 (sid_sd_util.py:264-272)
+            y_real = ops.cfg_x0(eps_r, prep.xt, prep.s0, prep.s1, k4, True, cd)
+            loss = ops.sid_generator_loss(images, y_real, y_fake, self.alpha, self.lsg / self.bgt)   # :508-530
+            loss.backward()                                                             # :532-533
+            return loss.detach()
         # teacher first: neither G's forward nor phi's reads psi, so a pending psi gradient exchange / optimizer step
         # (before_fake_eval) overlaps with them.  y_real and y_fake are independent: the order does not change the math.
         if self.side is None:

