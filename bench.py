@@ -78,6 +78,34 @@ class KernelTimer:
         return dict(launches=len(self.events), calls=self.calls, ms=ms, flops=self.flops)
 
 
+class DispatchTrace:
+    """Per-family kernel time of the step from per-DISPATCH timestamps (include/sidlsg_hip.h "in-library kernel timing"): every
+    `stride`-th call of a family launches its kernels with start / stop events bound to the kernel's own dispatch packet, so the
+    durations are the begin -> end intervals `rocprofv3 --kernel-trace` reports for the same command -- not event records around a
+    launch, which add barrier packets and over-state ~50 us kernels under three concurrent streams by ~1.5x (round 3)."""
+    FAM = dict(gemm=0, conv=1, attn=2, attn_bwd=3, wgrad=4, conv_wgrad=5, gn=6, gn_bwd=7, ln=8, ln_bwd=9)
+    STRIDE = dict(gemm=7, conv=5, attn=3, attn_bwd=3, wgrad=5, conv_wgrad=3, gn=5, gn_bwd=5, ln=7, ln_bwd=7)
+
+    def __init__(self, lib):
+        self.lib = lib
+
+    def start(self):
+        self.lib.sidlsg_trace_enable(1 << 17)
+        for k, f in self.FAM.items():
+            self.lib.sidlsg_trace_set_stride(f, self.STRIDE[k])
+
+    def stop(self):
+        torch.cuda.synchronize()
+        out = {}
+        buf = torch.zeros(5, dtype=torch.float64)
+        for k, f in self.FAM.items():
+            self.lib.sidlsg_trace_read(f, buf.data_ptr())
+            ms, work, sampled, calls, kernels = buf.tolist()
+            out[k] = dict(launches=int(sampled), calls=int(calls), ms=ms, flops=work, kernels=int(kernels))
+        self.lib.sidlsg_trace_enable(0)
+        return out
+
+
 def conv_flops(*a):
     # sidlsg_conv3x3_bf16(X, ldx, W, Y, ldc, bias, res, ldres, rowvec, ld_rowvec, B, H, Wd, Cin, Cout, stride, ups, alpha, flags, stream)
     B, H, Wd, Cin, Cout, stride = a[10], a[11], a[12], a[13], a[14], a[15]
@@ -331,10 +359,10 @@ def main():
                     attn=KernelTimer(lib, ATTN_FWD, attn_flops, stride=3), attn_bwd=KernelTimer(lib, ATTN_BWD, attn_bwd_flops, stride=3),
                     wgrad=KernelTimer(lib, 'sidlsg_wgrad_bf16', wgrad_flops, stride=7), conv_wgrad=KernelTimer(lib, 'sidlsg_conv3x3_wgrad_bf16', conv_wgrad_flops, stride=5),
                     gn=KernelTimer(lib, 'sidlsg_groupnorm_fwd', gn_bytes, stride=5))
-    if not args.no_kernel_timing and rank == 0 and not S.use_graph:      # rooflines of the step's kernel families, sampled live over the timed region
-        timers = make_timers()
-        for tm in timers.values():
-            tm.__enter__()
+    trace = DispatchTrace(lib)
+    tracing = not args.no_kernel_timing and rank == 0 and not S.use_graph
+    if tracing:      # rooflines of the step's kernel families, sampled live over the timed region
+        trace.start()
     t0 = time.time()
     first = None
     for it in range(args.warmup, args.warmup + args.steps):
@@ -348,8 +376,8 @@ def main():
     comm = reducer.timing_report(world) if (reducer is not None and reducer.timing) else None
     if reducer is not None:
         reducer.enable_timing(False)
-    for tm in timers.values():
-        tm.__exit__()
+    if tracing:
+        timers = trace.stop()
     if world > 1:      # max over ranks, BEFORE anything rank-dependent: every collective below is executed by every rank
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
@@ -364,33 +392,41 @@ def main():
         S.use_graph = False
         if not args.no_kernel_timing:                 # (iterations contain the gradient exchange: every rank runs them)
             if rank == 0:
-                timers = make_timers()
-            for tm in timers.values():
-                tm.__enter__()
+                trace.start()
             for it in range(args.warmup + args.steps + 3, args.warmup + args.steps + 6):
                 one_iteration(it)
             torch.cuda.synchronize()
-            for tm in timers.values():
-                tm.__exit__()
-    # The timed region runs the teacher on a second HIP stream beside the fake-score network (sid_step.py) and the weight
-    # gradients on a third (ops._OnWgradStream): kernels of the
-    # streams share the chip, so a launch's event-bracketed duration over the timed region (= what rocprofv3 --kernel-trace
-    # reports for the same command) is longer than the kernel's own.  A few extra iterations AFTER the timed region, with that
-    # overlap switched off, give each family's stand-alone figure (`isolated` in the roofline objects).
+            if rank == 0:
+                timers = trace.stop()
+    # For comparison, the OLD way of timing (HIP events recorded around sampled launches; rounds 1-3): two extra iterations after
+    # the timed region, same stream concurrency -- `event_bracketed` in the roofline objects.
+    bracketed = {}
+    if not args.no_kernel_timing:          # rank-independent condition: the iterations exchange gradients
+        tms = make_timers() if rank == 0 else {}
+        for tm in tms.values():
+            tm.__enter__()
+        for it in range(args.warmup + args.steps + 10, args.warmup + args.steps + 12):
+            one_iteration(it)
+        torch.cuda.synchronize()
+        for k, tm in tms.items():
+            tm.__exit__()
+            bracketed[k] = tm.result()
+    # The timed region runs the teacher (or the early generator forward) on a second HIP stream and the weight gradients on a
+    # third (ops._OnWgradStream): kernels of the streams share the chip, so a kernel's duration over the timed region (what
+    # rocprofv3 --kernel-trace reports for the same command) is longer than the kernel's own.  A few extra iterations AFTER the
+    # timed region, with that overlap switched off, give each family's stand-alone figure (`isolated` in the roofline objects).
     iso = {}
     if not args.no_kernel_timing and step.side is not None:          # rank-independent condition: the iterations exchange gradients
         from sid_lsg_amd import ops as _ops
         side, step.side = step.side, None
         wgrad_side, _ops._WGRAD_SIDE = _ops._WGRAD_SIDE, False      # weight gradients back on the main stream as well
-        tms = make_timers() if rank == 0 else {}
-        for tm in tms.values():
-            tm.__enter__()
+        if rank == 0:
+            trace.start()
         for it in range(args.warmup + args.steps, args.warmup + args.steps + 3):
             one_iteration(it)
         torch.cuda.synchronize()
-        for k, tm in tms.items():
-            tm.__exit__()
-            iso[k] = tm.result()
+        if rank == 0:
+            iso = trace.stop()
         step.side = side
         _ops._WGRAD_SIDE = wgrad_side
     # north_star's second figure: MFMA utilisation of the CFG teacher pass alone (phi forward on the [uncond; cond] batch of
@@ -488,15 +524,19 @@ def main():
                    'attn_bwd': f'flash attention backward ({ATTN_BWD}: attn_q_kernel<*,*,1,*,*> + attn_dkdv_kernel)',
                    'wgrad': 'dense weight gradient dW += dY^T A (wgrad_v2_kernel<0> + wgrad_reduce_kernel)',
                    'conv_wgrad': 'conv3x3 weight gradient (wgrad_v2_kernel<1>, wgrad_v2w_kernel<1> + wgrad_reduce_kernel)',
-                   'gn': 'GroupNorm(32)+SiLU forward (gn_stats_kernel + gn_apply_kernel, one entry point)'}
+                   'gn': 'GroupNorm(32)+SiLU forward (gn_stats_kernel + gn_apply_kernel, one entry point)',
+                   'gn_bwd': 'GroupNorm(32)+SiLU backward (gn_bwd_stats_kernel + gn_bwd_apply_kernel [+ colsum_reduce2_kernel])',
+                   'ln': 'LayerNorm forward (ln_fwd_kernel)', 'ln_bwd': 'LayerNorm backward (ln_bwd_kernel [+ colsum_reduce2_kernel])'}
 
         def roof(key):
-            r = timers[key].result()
-            hbm = key == 'gn'
+            r = timers[key]
+            hbm = key in ('gn', 'gn_bwd', 'ln', 'ln_bwd')
             div, peak, unit = (1e9, PEAK_HBM_GBS, 'GB/s') if hbm else (1e12, PEAK_BF16_TFLOPS, 'TFLOP/s')
             ach = r['flops'] / (r['ms'] * 1e-3) / div if r['ms'] > 0 else 0.0
             o = {'bound': 'hbm' if hbm else 'mfma', 'kernel': KERNELS[key], 'achieved': ach, 'peak': peak, 'unit': unit, 'frac': ach / peak,
-                 'traffic': None, 'launches': r['launches'], 'launches_total': r['calls'], 'avg_launch_ms': r['ms'] / max(r['launches'], 1),
+                 'timing': 'per-dispatch start/stop timestamps of every sampled call\'s kernels over the timed region (hipExtLaunchKernelGGL: the '
+                           'interval rocprofv3 --kernel-trace reports; all kernels of a call, e.g. split-K GEMM + its finish kernel)',
+                 'traffic': None, 'launches': r['launches'], 'launches_total': r['calls'], 'kernels_timed': r['kernels'], 'avg_launch_ms': r['ms'] / max(r['launches'], 1),
                  # share of the step: sampled average duration x all launches of the timed region (streams overlap: the shares of all
                  # families add up to more than the wall time)
                  'est_ms_per_step': r['ms'] / max(r['launches'], 1) * r['calls'] / args.steps,
@@ -505,7 +545,13 @@ def main():
             if q is not None and q['ms'] > 0:
                 a2 = q['flops'] / (q['ms'] * 1e-3) / div
                 o['isolated'] = {'achieved': a2, 'frac': a2 / peak, 'avg_launch_ms': q['ms'] / max(q['launches'], 1), 'launches': q['launches'],
-                                 'what': '3 iterations after the timed region with the teacher-stream and weight-gradient-stream overlap off'}
+                                 'what': '3 iterations after the timed region with the side-stream and weight-gradient-stream overlap off'}
+            q = bracketed.get(key)
+            if q is not None and q['ms'] > 0:
+                a3 = q['flops'] / (q['ms'] * 1e-3) / div
+                o['event_bracketed'] = {'achieved': a3, 'frac': a3 / peak, 'avg_launch_ms': q['ms'] / max(q['launches'], 1), 'launches': q['launches'],
+                                        'what': 'HIP events recorded AROUND sampled launches (the figure of rounds 1-3), 2 iterations after the timed '
+                                                'region with the same stream concurrency: includes the two barrier packets and the dispatch gap'}
             return o
         objs = {k: roof(k) for k in timers}
         # HBM-side bytes per launch: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, gfx950-corrected) of the SAME

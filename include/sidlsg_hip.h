@@ -109,6 +109,19 @@ int sidlsg_layernorm_fwd_g2(const void* x, const float* gamma, const float* beta
 int sidlsg_layernorm_bwd_g2(const void* x, const void* dy, const float* stats, const float* gamma, const float* gamma1, const void* dres,
                             void* dx, int rows, int C, void* stream);
 
+/* ---- in-library kernel timing (measurement only; bench.py) -------------------------------------------------------------------
+ * Kernel durations as `rocprofv3 --kernel-trace` reports them, taken live: while tracing is enabled every `stride`-th CALL of a
+ * kernel family launches its kernels with start / stop events bound to the kernel's own dispatch packet (hipExtLaunchKernelGGL) --
+ * no extra packets in the stream, unlike events recorded around a launch.  Families: 0 dense GEMM fwd + dgrad, 1 conv3x3 fwd +
+ * dgrad, 2 attention forward, 3 attention backward, 4 dense weight gradient, 5 conv weight gradient, 6 GroupNorm forward,
+ * 7 GroupNorm backward, 8 LayerNorm forward, 9 LayerNorm backward.  Work = algorithmic flop (0-5) or bytes (6-9) of the call.
+ * sidlsg_trace_read (after a device synchronisation): out[0] summed kernel ms of the sampled calls, out[1] their summed work,
+ * out[2] sampled calls, out[3] all calls of the family since enable, out[4] timed kernels. */
+int sidlsg_trace_enable(int max_kernels);
+int sidlsg_trace_pause(int paused);
+int sidlsg_trace_set_stride(int family, int stride);
+int sidlsg_trace_read(int family, double* out);
+
 /* ---- attention (diffusers Attention + AttnProcessor2_0 / xformers; sid_sd_util.py:102-113) --
  * O = softmax(Q K^T D^-1/2) V per head; Q/K/V/O are strided views ([b][token][h*D + d], token
  * stride ld*, batch stride bs*, in elements) so the fused QKV projection is consumed in place.

@@ -744,15 +744,15 @@ template <int DP, int QT, bool PS>
 static int launch_attn_q(const AttnParams& p, int mode, hipStream_t s) {
     const int qb = 4 * QT * 16;
     if (mode == 0) {
-        if (p.D == DP - 8) hipLaunchKernelGGL((attn_q_kernel<DP, QT, 0, true, PS>), dim3((p.Nq + qb - 1) / qb, p.H, p.B), dim3(256), 0, s, p);
-        else hipLaunchKernelGGL((attn_q_kernel<DP, QT, 0, false, PS>), dim3((p.Nq + qb - 1) / qb, p.H, p.B), dim3(256), 0, s, p);
-    } else hipLaunchKernelGGL((attn_q_kernel<DP, QT, 1, false, PS>), dim3((p.Nq + qb - 1) / qb, p.H, p.B), dim3(256), 0, s, p);
+        if (p.D == DP - 8) SIDLSG_LAUNCH((attn_q_kernel<DP, QT, 0, true, PS>), dim3((p.Nq + qb - 1) / qb, p.H, p.B), dim3(256), 0, s, p);
+        else SIDLSG_LAUNCH((attn_q_kernel<DP, QT, 0, false, PS>), dim3((p.Nq + qb - 1) / qb, p.H, p.B), dim3(256), 0, s, p);
+    } else SIDLSG_LAUNCH((attn_q_kernel<DP, QT, 1, false, PS>), dim3((p.Nq + qb - 1) / qb, p.H, p.B), dim3(256), 0, s, p);
     return sidlsg_last_error();
 }
 template <int DP, int KT, bool PS>
 static int launch_attn_dkdv(const AttnParams& p, hipStream_t s) {
     const int kb = 4 * KT * 16;
-    hipLaunchKernelGGL((attn_dkdv_kernel<DP, KT, PS>), dim3((p.Nk + kb - 1) / kb, p.H, p.B), dim3(256), 0, s, p);
+    SIDLSG_LAUNCH((attn_dkdv_kernel<DP, KT, PS>), dim3((p.Nk + kb - 1) / kb, p.H, p.B), dim3(256), 0, s, p);
     return sidlsg_last_error();
 }
 template <int DP, int QT, int KT, bool PS>
@@ -825,6 +825,7 @@ extern "C" {
 int sidlsg_attn_fwd(const void* Q, const void* K, const void* V, void* O, float* LSE, int B, int H, int Nq, int Nk, int D,
                     int ldq, int ldk, int ldv, int ldo, long long bsq, long long bsk, long long bsv, long long bso,
                     void* stream) {
+    SidlsgTraceScope ts(SIDLSG_FAM_ATTN_FWD, 4.0 * B * H * Nq * (double)Nk * D);
     return attn_fwd_impl(false, Q, K, V, O, LSE, B, H, Nq, Nk, D, ldq, ldk, ldv, ldo, bsq, bsk, bsv, bso, stream);
 }
 
@@ -832,6 +833,7 @@ int sidlsg_attn_fwd(const void* Q, const void* K, const void* V, void* O, float*
 int sidlsg_attn_bwd(const void* Q, const void* K, const void* V, const void* O, const void* dO, const float* LSE, void* dQ,
                     void* dK, void* dV, float* delta, int B, int H, int Nq, int Nk, int D, int ldq, int ldk, int ldv, int ldo,
                     long long bsq, long long bsk, long long bsv, long long bso, void* stream) {
+    SidlsgTraceScope ts(SIDLSG_FAM_ATTN_BWD, ((dK && dV) ? 10.0 : 6.0) * B * H * Nq * (double)Nk * D);
     return attn_bwd_impl(false, Q, K, V, O, dO, LSE, dQ, dK, dV, delta, B, H, Nq, Nk, D, ldq, ldk, ldv, ldo, bsq, bsk, bsv, bso, stream);
 }
 
@@ -842,11 +844,13 @@ int sidlsg_attn_bwd(const void* Q, const void* K, const void* V, const void* O, 
 int sidlsg_attn_fwd_ps(const void* Q, const void* K, const void* V, void* O, float* LSE, int B, int H, int Nq, int Nk, int D,
                        int ldq, int ldk, int ldv, int ldo, long long bsq, long long bsk, long long bsv, long long bso,
                        void* stream) {
+    SidlsgTraceScope ts(SIDLSG_FAM_ATTN_FWD, 4.0 * B * H * Nq * (double)Nk * D);
     return attn_fwd_impl(true, Q, K, V, O, LSE, B, H, Nq, Nk, D, ldq, ldk, ldv, ldo, bsq, bsk, bsv, bso, stream);
 }
 int sidlsg_attn_bwd_ps(const void* Q, const void* K, const void* V, const void* O, const void* dO, const float* LSE, void* dQ,
                        void* dK, void* dV, float* delta, int B, int H, int Nq, int Nk, int D, int ldq, int ldk, int ldv, int ldo,
                        long long bsq, long long bsk, long long bsv, long long bso, void* stream) {
+    SidlsgTraceScope ts(SIDLSG_FAM_ATTN_BWD, ((dK && dV) ? 10.0 : 6.0) * B * H * Nq * (double)Nk * D);
     return attn_bwd_impl(true, Q, K, V, O, dO, LSE, dQ, dK, dV, delta, B, H, Nq, Nk, D, ldq, ldk, ldv, ldo, bsq, bsk, bsv, bso, stream);
 }
 

@@ -131,5 +131,25 @@ template <typename T> DEVFN void zerov8(T* p) {
     stv8<T>(p, z);
 }
 
+// ---- in-library kernel timing (trace.hip): families of the step's kernels, and the launch macro every family kernel goes through
+enum { SIDLSG_FAM_GEMM = 0, SIDLSG_FAM_CONV, SIDLSG_FAM_ATTN_FWD, SIDLSG_FAM_ATTN_BWD, SIDLSG_FAM_WGRAD, SIDLSG_FAM_CONV_WGRAD,
+       SIDLSG_FAM_GN_FWD, SIDLSG_FAM_GN_BWD, SIDLSG_FAM_LN_FWD, SIDLSG_FAM_LN_BWD, SIDLSG_TRACE_FAMILIES };
+bool sidlsg_trace_scope_begin(int family, double work);
+void sidlsg_trace_scope_end();
+bool sidlsg_trace_events(hipEvent_t* e0, hipEvent_t* e1);
+struct SidlsgTraceScope {
+    bool open;
+    SidlsgTraceScope(int family, double work) : open(sidlsg_trace_scope_begin(family, work)) {}
+    ~SidlsgTraceScope() { if (open) sidlsg_trace_scope_end(); }
+};
+#include <hip/hip_ext.h>
+// hipLaunchKernelGGL, or -- inside a sampled trace scope -- the same launch with start / stop events bound to ITS dispatch packet
+#define SIDLSG_LAUNCH(kern, grid, block, lds, stream, ...)                                                     \
+    do {                                                                                                        \
+        hipEvent_t te0_, te1_;                                                                                  \
+        if (sidlsg_trace_events(&te0_, &te1_)) hipExtLaunchKernelGGL(kern, grid, block, lds, stream, te0_, te1_, 0, __VA_ARGS__); \
+        else hipLaunchKernelGGL(kern, grid, block, lds, stream, __VA_ARGS__);                                   \
+    } while (0)
+
 // Launch-error helper for the extern "C" entry points: returns the HIP error code (0 = ok).
 static inline int sidlsg_last_error() { return (int)hipGetLastError(); }

@@ -1118,10 +1118,10 @@ static int launch_gemm_v3(const GemmParams& p, hipStream_t s) {
     GemmParams q = p;
     static const int group_env = getenv("SIDLSG_GEMM_GROUP_M") ? atoi(getenv("SIDLSG_GEMM_GROUP_M")) : 4;   // A/B switch (measured: 4 and 8 equivalent, 1 = row-major strips)
     q.group_m = group_env < 1 ? 1 : group_env;
-    hipLaunchKernelGGL((gemm_v3_kernel<MODE>), dim3(tiles * splits), dim3(NTHREADS), lds, s, q);
+    SIDLSG_LAUNCH((gemm_v3_kernel<MODE>), dim3(tiles * splits), dim3(NTHREADS), lds, s, q);
     if (p.kt_per_split) {
         const size_t n4 = ((size_t)p.M * p.N + 3) / 4;
-        hipLaunchKernelGGL(gemm_finish_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, p, splits);
+        SIDLSG_LAUNCH(gemm_finish_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, p, splits);
     }
     return sidlsg_last_error();
 }
@@ -1413,10 +1413,10 @@ static int launch_gemm_mx8(const GemmParams& p, hipStream_t s) {
         q.ws = w.ptr;
         splits = (nk + q.kt_per_split - 1) / q.kt_per_split;
     }
-    hipLaunchKernelGGL((gemm_mx8_kernel<MODE>), dim3(tiles * splits), dim3(NTHREADS), lds, s, q);
+    SIDLSG_LAUNCH((gemm_mx8_kernel<MODE>), dim3(tiles * splits), dim3(NTHREADS), lds, s, q);
     if (splits > 1) {
         const size_t n4 = ((size_t)p.M * p.N + 3) / 4;
-        hipLaunchKernelGGL(gemm_finish_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, q, splits);
+        SIDLSG_LAUNCH(gemm_finish_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, q, splits);
     }
     return sidlsg_last_error();
 }
@@ -1680,8 +1680,8 @@ static int launch_gemm_as(const GemmParams& p, hipStream_t s) {
     GemmParams q = p;
     q.group_m = tpi;
     const int items = panels * ((tiles_n + tpi - 1) / tpi);
-    if (p.res) hipLaunchKernelGGL((gemm_as_kernel<NKT, true>), dim3(items), dim3(NTHREADS), lds, s, q);
-    else hipLaunchKernelGGL((gemm_as_kernel<NKT, false>), dim3(items), dim3(NTHREADS), lds, s, q);
+    if (p.res) SIDLSG_LAUNCH((gemm_as_kernel<NKT, true>), dim3(items), dim3(NTHREADS), lds, s, q);
+    else SIDLSG_LAUNCH((gemm_as_kernel<NKT, false>), dim3(items), dim3(NTHREADS), lds, s, q);
     return sidlsg_last_error();
 }
 
@@ -1697,10 +1697,10 @@ static int launch_gemm(const GemmParams& p, hipStream_t s) {
     }
     const int nk = (p.K + BK - 1) / BK;
     const int splits = p.kt_per_split ? (nk + p.kt_per_split - 1) / p.kt_per_split : 1;
-    hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, MODE>), dim3(tiles, splits), dim3(NTHREADS), lds, s, p);
+    SIDLSG_LAUNCH((gemm_bf16_kernel<BM, BN, MODE>), dim3(tiles, splits), dim3(NTHREADS), lds, s, p);
     if (p.kt_per_split) {
         const size_t n4 = ((size_t)p.M * p.N + 3) / 4;
-        hipLaunchKernelGGL(gemm_finish_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, p, splits);
+        SIDLSG_LAUNCH(gemm_finish_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, p, splits);
     }
     return sidlsg_last_error();
 }
@@ -1709,6 +1709,7 @@ template <int MODE>
 static int dispatch_gemm(const GemmParams& pin, hipStream_t s) {
     GemmParams p = pin;
     p.Mtot = p.M;
+    SidlsgTraceScope ts(MODE == 0 ? SIDLSG_FAM_GEMM : SIDLSG_FAM_CONV, 2.0 * p.M * (double)p.N * p.K);
     // N multiple of 160 (every SD channel count is a multiple of 320) -> exact 160-wide tiles and, for dense rows /
     // Cin % 64 == 0 convs, the direct-to-LDS kernel (v3); otherwise 128-wide; narrow outputs (conv_out, dgrad of conv_in)
     // -> 64-wide.  Small pixel counts (8x8 / 16x16 stages, small batches) would give < 256 tiles = idle CUs: split K when
@@ -2315,12 +2316,12 @@ static int launch_wgrad(WgradParams p, hipStream_t s) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_v2w_kernel<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * WG_MB * (160 + WG_T) * 2);
             attr_done = true;
         }
-        if (tn == 160) hipLaunchKernelGGL((wgrad_v2w_kernel<MODE>), dim3(tiles * splits), dim3(NTHREADS), lds, s, p);
-        else hipLaunchKernelGGL((wgrad_v2_kernel<MODE>), dim3(tiles * splits), dim3(NTHREADS), lds, s, p);
+        if (tn == 160) SIDLSG_LAUNCH((wgrad_v2w_kernel<MODE>), dim3(tiles * splits), dim3(NTHREADS), lds, s, p);
+        else SIDLSG_LAUNCH((wgrad_v2_kernel<MODE>), dim3(tiles * splits), dim3(NTHREADS), lds, s, p);
     } else
-    hipLaunchKernelGGL((wgrad_bf16_kernel<MODE>), dim3(tiles, splits), dim3(NTHREADS), 0, s, p);
+    SIDLSG_LAUNCH((wgrad_bf16_kernel<MODE>), dim3(tiles, splits), dim3(NTHREADS), 0, s, p);
     if (splits > 1 && p.ws)
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((nk / 4 + 256) / 256)), dim3(256), 0, s, p.ws, p.dW, (size_t)nk, splits);
+        SIDLSG_LAUNCH(wgrad_reduce_kernel, dim3((unsigned)((nk / 4 + 256) / 256)), dim3(256), 0, s, p.ws, p.dW, (size_t)nk, splits);
     return sidlsg_last_error();
 }
 
@@ -2445,6 +2446,7 @@ int sidlsg_wgrad_bf16(const void* dY, int ldy, const void* A, int lda, float* dW
     const unsigned long long ab = ((unsigned long long)(M - 1) * lda + K) * 2ull, yb = ((unsigned long long)(M - 1) * ldy + N) * 2ull;
     if (!fits31(ab) || !fits31(yb)) return SIDLSG_EINVAL;
     p.a_bytes = (unsigned)ab; p.y_bytes = (unsigned)yb;
+    SidlsgTraceScope ts(SIDLSG_FAM_WGRAD, 2.0 * M * (double)N * K);
     return launch_wgrad<0>(p, (hipStream_t)stream);
 }
 
@@ -2461,13 +2463,14 @@ int sidlsg_conv3x3_wgrad_bf16(const void* dY, int ldy, const void* X, int ldx, f
     const unsigned long long ab = (((unsigned long long)B * Hs * Ws - 1) * ldx + Cin) * 2ull, yb = ((unsigned long long)(p.M - 1) * ldy + Cout) * 2ull;
     if (!fits31(ab) || !fits31(yb)) return SIDLSG_EINVAL;
     p.a_bytes = (unsigned)ab; p.y_bytes = (unsigned)yb;
+    SidlsgTraceScope ts(SIDLSG_FAM_CONV_WGRAD, 2.0 * p.M * (double)p.N * p.K);
     return launch_wgrad<1>(p, (hipStream_t)stream);
 }
 
 // ---- fp8-weight contractions (see gemm_fp8w_kernel).  W8: e4m3 bytes [N][K]; wscale: fp32 [N].  K % 16 == 0.
 int sidlsg_quantize_fp8_rows(const void* src_bf16, void* dst_fp8, float* scale, int rows, int cols, void* stream) {
     if (rows <= 0 || cols <= 0 || (cols & 7) || !src_bf16 || !dst_fp8 || !scale) return SIDLSG_EINVAL;
-    hipLaunchKernelGGL(quantize_fp8_rows_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const bf16*)src_bf16,
+    SIDLSG_LAUNCH(quantize_fp8_rows_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const bf16*)src_bf16,
                        (unsigned char*)dst_fp8, scale, rows, cols);
     return sidlsg_last_error();
 }
@@ -2486,7 +2489,7 @@ int sidlsg_gemm_fp8w(const void* A, int lda, const void* W8, const float* wscale
     if (!fits31(ab) || !fits31(wb)) return SIDLSG_EINVAL;
     p.a_bytes = (unsigned)ab; p.w_bytes = (unsigned)wb;
     const int tiles = ((M + F8_T - 1) / F8_T) * ((N + F8_T - 1) / F8_T);
-    hipLaunchKernelGGL((gemm_fp8w_kernel<0>), dim3(tiles), dim3(NTHREADS), 0, (hipStream_t)stream, p);
+    SIDLSG_LAUNCH((gemm_fp8w_kernel<0>), dim3(tiles), dim3(NTHREADS), 0, (hipStream_t)stream, p);
     return sidlsg_last_error();
 }
 
@@ -2505,6 +2508,7 @@ int sidlsg_gemm_mx8(const void* A8, int lda, const void* W8, const float* wscale
     const unsigned long long ab = (unsigned long long)(M - 1) * lda + K, wb = (unsigned long long)N * K;
     if (!fits31(ab) || !fits31(wb)) return SIDLSG_EINVAL;
     p.a_bytes = (unsigned)ab; p.w_bytes = (unsigned)wb;
+    SidlsgTraceScope ts(SIDLSG_FAM_GEMM, 2.0 * p.M * (double)p.N * p.K);
     return launch_gemm_mx8<0>(p, (hipStream_t)stream);
 }
 
@@ -2524,6 +2528,7 @@ int sidlsg_conv3x3_mx8(const void* X8, int ldx, const void* W8, const float* wsc
     const unsigned long long wb = (unsigned long long)Cout * 9 * Cin;
     if (!fits31(ab) || !fits31(wb)) return SIDLSG_EINVAL;
     p.a_bytes = (unsigned)(ab - (unsigned long long)(Wd + 1) * ldx); p.w_bytes = (unsigned)wb;
+    SidlsgTraceScope ts(SIDLSG_FAM_CONV, 2.0 * p.M * (double)p.N * p.K);
     return launch_gemm_mx8<1>(p, (hipStream_t)stream);
 }
 
@@ -2540,7 +2545,7 @@ int sidlsg_cast_fp8(const void* src_bf16, void* dst_fp8, long long n, void* stre
     const size_t n8 = (size_t)n / 8;
     size_t blocks = (n8 + 255) / 256;
     if (blocks > 256 * 16) blocks = 256 * 16;
-    hipLaunchKernelGGL(cast_fp8_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const bf16*)src_bf16, (unsigned char*)dst_fp8, n8);
+    SIDLSG_LAUNCH(cast_fp8_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const bf16*)src_bf16, (unsigned char*)dst_fp8, n8);
     return sidlsg_last_error();
 }
 
@@ -2562,7 +2567,7 @@ int sidlsg_conv3x3_fp8w(const void* X, int ldx, const void* W8, const float* wsc
     if (!fits31(ab) || !fits31(wb)) return SIDLSG_EINVAL;
     p.a_bytes = (unsigned)ab; p.w_bytes = (unsigned)wb;
     const int tiles = ((p.M + F8_T - 1) / F8_T) * ((p.N + F8_T - 1) / F8_T);
-    hipLaunchKernelGGL((gemm_fp8w_kernel<2>), dim3(tiles), dim3(NTHREADS), 0, (hipStream_t)stream, p);
+    SIDLSG_LAUNCH((gemm_fp8w_kernel<2>), dim3(tiles), dim3(NTHREADS), 0, (hipStream_t)stream, p);
     return sidlsg_last_error();
 }
 

@@ -526,11 +526,12 @@ static int groupnorm_fwd_t(const void* x, const float* gamma, const float* beta,
                            const float* beta1 = nullptr) {
     GnGeom g; if (int e = gn_geom(g, B, HW, C, G)) return e;
     if (gamma1 && ((B & 1) || !beta1)) return SIDLSG_EINVAL;
+    SidlsgTraceScope ts(SIDLSG_FAM_GN_FWD, (double)B * HW * C * (sizeof(T) + (F8 ? 1 : sizeof(T))));      // algorithmic bytes: read x, write y
     hipStream_t s = (hipStream_t)stream;
     const int threads = g.C8 * g.rows;
-    hipLaunchKernelGGL(gn_stats_kernel<T>, dim3(g.nch, B), dim3(threads), (size_t)g.rows * C * 2 * sizeof(float), s,
+    SIDLSG_LAUNCH(gn_stats_kernel<T>, dim3(g.nch, B), dim3(threads), (size_t)g.rows * C * 2 * sizeof(float), s,
                        (const T*)x, ws, g);
-    hipLaunchKernelGGL((gn_apply_kernel<T, F8>), dim3(g.nch, B), dim3(threads), (size_t)2 * G * (1 + GN_FOLD) * sizeof(float), s,
+    SIDLSG_LAUNCH((gn_apply_kernel<T, F8>), dim3(g.nch, B), dim3(threads), (size_t)2 * G * (1 + GN_FOLD) * sizeof(float), s,
                        (const T*)x, ws, gamma, beta, (T*)y, stats, g, eps, silu, gamma1, beta1, B / 2);
     return sidlsg_last_error();
 }
@@ -542,15 +543,16 @@ static int groupnorm_bwd_t(const void* x, const void* dy, const float* stats, co
                            int silu, void* stream, const float* gamma1 = nullptr, const float* beta1 = nullptr) {
     GnGeom g; if (int e = gn_geom(g, B, HW, C, G)) return e;
     if (gamma1 && ((B & 1) || !beta1 || dgamma || dbeta)) return SIDLSG_EINVAL;      // grouped: frozen networks (no parameter gradients)
+    SidlsgTraceScope ts(SIDLSG_FAM_GN_BWD, (double)B * HW * C * sizeof(T) * (dres ? 4 : 3));                // read x, dy (, dres), write dx
     hipStream_t s = (hipStream_t)stream;
     const int threads = g.C8 * g.rows;
-    hipLaunchKernelGGL(gn_bwd_stats_kernel<T>, dim3(g.nch, B), dim3(threads), (size_t)g.rows * C * 2 * sizeof(float), s,
+    SIDLSG_LAUNCH(gn_bwd_stats_kernel<T>, dim3(g.nch, B), dim3(threads), (size_t)g.rows * C * 2 * sizeof(float), s,
                        (const T*)x, (const T*)dy, stats, gamma, beta, ws, g, silu, gamma1, beta1, B / 2);
-    hipLaunchKernelGGL(gn_bwd_apply_kernel<T>, dim3(g.nch, B), dim3(threads), (size_t)2 * G * (1 + GN_FOLD) * sizeof(float), s,
+    SIDLSG_LAUNCH(gn_bwd_apply_kernel<T>, dim3(g.nch, B), dim3(threads), (size_t)2 * G * (1 + GN_FOLD) * sizeof(float), s,
                        (const T*)x, (const T*)dy, stats, gamma, beta, ws, (const T*)dres, (T*)dx, g, silu, gamma1, beta1, B / 2);
     if (dgamma && dbeta) {
         const int P = B * g.nch;
-        hipLaunchKernelGGL(colsum_reduce2_kernel, reduce_grid(C, P), dim3(256), 0, s, ws, dgamma, dbeta, P, (size_t)C * 2, C);
+        SIDLSG_LAUNCH(colsum_reduce2_kernel, reduce_grid(C, P), dim3(256), 0, s, ws, dgamma, dbeta, P, (size_t)C * 2, C);
     }
     return sidlsg_last_error();
 }
@@ -561,6 +563,7 @@ static int layernorm_fwd_t(const void* x, const float* gamma, const float* beta,
                            float eps, void* stream, const float* gamma1 = nullptr, const float* beta1 = nullptr) {
     if (C % 8 || C > 8 * 64 * LN_MAXCH || rows <= 0) return SIDLSG_EINVAL;
     if (gamma1 && ((rows & 1) || !beta1)) return SIDLSG_EINVAL;
+    SidlsgTraceScope ts(SIDLSG_FAM_LN_FWD, (double)rows * C * (sizeof(T) + (F8 ? 1 : sizeof(T))));
     const int nch = (C / 8 + 63) / 64;
     const int R = nch <= 1 ? 4 : 2;
     // rows per wave: enough waves to fill the chip (>= ~4096), at most 16 rows (amortises the gamma/beta loads)
@@ -570,7 +573,7 @@ static int layernorm_fwd_t(const void* x, const float* gamma, const float* beta,
         if ((rows / 2) % rpw) return SIDLSG_EINVAL;
     }
     const dim3 grid((rows + 4 * rpw - 1) / (4 * rpw));
-#define LN_FWD(NCH, RR) hipLaunchKernelGGL((ln_fwd_kernel<T, NCH, RR, F8>), grid, dim3(256), 0, (hipStream_t)stream, (const T*)x, gamma, \
+#define LN_FWD(NCH, RR) SIDLSG_LAUNCH((ln_fwd_kernel<T, NCH, RR, F8>), grid, dim3(256), 0, (hipStream_t)stream, (const T*)x, gamma, \
                                            beta, (T*)y, stats, rows, C, eps, rpw, gamma1, beta1, rows / 2)
     if (nch == 1) LN_FWD(1, 4); else if (nch == 2) LN_FWD(2, 2); else if (nch == 3) LN_FWD(3, 2); else LN_FWD(4, 2);
 #undef LN_FWD
@@ -586,6 +589,7 @@ static int layernorm_bwd_t(const void* x, const void* dy, const float* stats, co
                            float* dgamma, float* dbeta, float* ws, int rows, int C, void* stream, const float* gamma1 = nullptr) {
     if (C % 8 || C > 8 * 64 * LN_MAXCH || rows <= 0) return SIDLSG_EINVAL;
     hipStream_t s = (hipStream_t)stream;
+    SidlsgTraceScope ts(SIDLSG_FAM_LN_BWD, (double)rows * C * sizeof(T) * (dres ? 4 : 3));
     int nb = layernorm_bwd_nblocks(rows);
     int rpb = (rows + nb - 1) / nb;
     if (gamma1) {       // grouped launch (frozen networks): blocks must not straddle the halves
@@ -599,12 +603,12 @@ static int layernorm_bwd_t(const void* x, const void* dy, const float* stats, co
     const bool pg = dgamma && dbeta;
     const int nch = (C / 8 + 63) / 64;
     const size_t lds = pg ? (size_t)4 * C * 2 * sizeof(float) : 0;
-#define LN_BWD(NCH, R) hipLaunchKernelGGL((ln_bwd_kernel<T, NCH, R>), dim3(nb), dim3(256), lds, s, (const T*)x, (const T*)dy, \
+#define LN_BWD(NCH, R) SIDLSG_LAUNCH((ln_bwd_kernel<T, NCH, R>), dim3(nb), dim3(256), lds, s, (const T*)x, (const T*)dy, \
                                           stats, gamma, (const T*)dres, (T*)dx, pg ? ws : nullptr, rows, C, rpb, gamma1, rows / 2)
     if (nch == 1) LN_BWD(1, 2); else if (nch == 2) LN_BWD(2, 2); else if (nch == 3) LN_BWD(3, 1); else LN_BWD(4, 1);
 #undef LN_BWD
     if (pg) {
-        hipLaunchKernelGGL(colsum_reduce2_kernel, reduce_grid(C, nb), dim3(256), 0, s, ws, dgamma, dbeta, nb, (size_t)C * 2, C);
+        SIDLSG_LAUNCH(colsum_reduce2_kernel, reduce_grid(C, nb), dim3(256), 0, s, ws, dgamma, dbeta, nb, (size_t)C * 2, C);
     }
     return sidlsg_last_error();
 }

@@ -607,3 +607,41 @@ def test_attention_backward_query_gradient_only(dev):
     qb = q.clone().requires_grad_()
     ops.cross_attention(qb, kv, heads).backward(do)
     assert torch.equal(qa.grad, qb.grad) and kva.grad is not None and float(kva.grad.abs().max()) > 0
+
+
+def test_dispatch_trace_reports_kernel_time(dev):
+    """The in-library kernel timing (include/sidlsg_hip.h "in-library kernel timing", what bench.py's roofline objects are made
+    of): per-dispatch timestamps of sampled calls.  On a long kernel they must agree with the wall time of a back-to-back batch
+    of the same launch (events around 40 launches: per-launch overheads amortised), and the bookkeeping must be exact."""
+    from sid_lsg_amd import ops
+    from sid_lsg_amd._lib import lib
+    M, N, K = 65536, 1280, 1280                   # ~0.2 ms per launch
+    a, w = rnd(M, K, seed=1).to(dev), rnd(N, K, seed=2, scale=K ** -0.5).to(dev)
+    out = torch.empty(M, N, device=dev, dtype=BF16)
+    for _ in range(3):
+        ops.gemm(a, w, out=out)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(40):
+        ops.gemm(a, w, out=out)
+    e1.record()
+    torch.cuda.synchronize()
+    batch_ms = e0.elapsed_time(e1) / 40
+    lib.sidlsg_trace_enable(1024)
+    lib.sidlsg_trace_set_stride(0, 3)
+    for _ in range(40):
+        ops.gemm(a, w, out=out)
+    torch.cuda.synchronize()
+    buf = torch.zeros(5, dtype=torch.float64)
+    lib.sidlsg_trace_read(0, buf.data_ptr())
+    ms, work, sampled, calls, kernels = buf.tolist()
+    lib.sidlsg_trace_set_stride(0, 1)
+    lib.sidlsg_trace_enable(0)
+    print(f'batch of 40: {batch_ms * 1e3:.1f} us per launch; dispatch timestamps: {ms / sampled * 1e3:.1f} us per launch over {int(sampled)} of {int(calls)} calls')
+    assert calls == 40 and sampled == 14 and kernels == 14 and abs(work - 14 * 2.0 * M * N * K) < 1e6
+    assert 0.8 * batch_ms < ms / sampled < 1.1 * batch_ms
+    # disabled again: nothing is recorded, launches still work
+    ops.gemm(a, w, out=out)
+    lib.sidlsg_trace_read(0, buf.data_ptr())
+    assert buf[3] == 0

@@ -595,8 +595,9 @@ def test_product_loop_50_iteration_curve_has_no_drift(dev, golden_dir, tmp_path,
     print(f'[{mode}] generator loss rel where |loss_G| > 100 ({int(big.sum())} iterations): max {rel_g[big].max():.2e}, median {np.median(rel_g[big]):.2e}')
     print(f'[{mode}] rel_f per iteration: {np.array2string(rel_f, precision=1, max_line_width=200)}')
     print(f'[{mode}] err_G / scale per iteration: {np.array2string(scale_g, precision=1, max_line_width=200)}')
-    if cd == F32:
-        assert rel_f.max() < 1e-3 and rel_g.max() < 1e-3
+    if cd == F32:      # north_star's 1e-3 on every loss of every iteration (the generator loss passes through ~1.5: bound it where it is
+        # not a cancellation remainder, and on the loss scale everywhere); observed: 6e-6 / 3e-5 / 1e-5
+        assert rel_f.max() < 1e-3 and rel_g[big].max() < 1e-3 and scale_g.max() < 1e-3
         return
     # bf16, FREE-RUNNING over 50 Adam(beta1 = 0) steps at lr = 1e-4 (100x the production learning rate): besides the per-step rounding
     # noise (first iterations: fake 2e-4, G 7e-4 of the scale) the two trajectories separate -- every gradient SIGN disagreement (~1.3 %
