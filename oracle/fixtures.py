@@ -69,3 +69,51 @@ def factory(cfg_name='tiny', seed=1234):
 def checksum(module_or_tensors):
     ts = list(module_or_tensors.parameters() if isinstance(module_or_tensors, torch.nn.Module) else module_or_tensors)
     return float(sum(p.detach().double().sum() for p in ts)), float(sum(p.detach().double().abs().sum() for p in ts))
+
+
+# ---- evaluation-metric fixtures (tests/golden/metrics_ref.npz) ---------------------------------------
+METRIC_CAPTIONS = [f'evaluation caption number {i}: {w}' for i, w in enumerate(
+    'a red barn in the snow|two cats on a sofa|a bowl of oranges|city lights at dusk|a sailing boat|an old bicycle|a mountain lake|'
+    'a plate of pasta|a child with a kite|a dog on the beach|a steam engine|tulips in a vase|a desert road|a wooden bridge|'
+    'a tea cup and a book|a lighthouse at night|a hot air balloon'.split('|'))]
+
+
+class CaptionSet(torch.utils.data.Dataset):
+    """Item contract of the reference's metric dataset (training/mscoco_dataset.py: `(image, caption)`, attribute `resolution`)."""
+
+    def __init__(self, resolution=512, **_):
+        self.resolution, self.name = resolution, 'captions'
+
+    def __len__(self):
+        return len(METRIC_CAPTIONS)
+
+    def __getitem__(self, i):
+        return torch.zeros(1, 4, 4), METRIC_CAPTIONS[i]
+
+
+def text_images(contexts, resolution):
+    """Stand-in generator output: an image in ~[-1.2, 1.2] that is a pure function of the caption (so a replay does not depend on
+    which RNG drew the latents): smooth low-frequency content + noise, [N, 3, R, R] fp32 on the CPU."""
+    import zlib
+    out = []
+    for c in contexts:
+        g = torch.Generator().manual_seed(zlib.crc32(str(c).encode()))
+        low = F.interpolate(torch.randn(1, 3, 16, 16, generator=g), size=(resolution, resolution), mode='bilinear', align_corners=False)[0]
+        out.append((0.8 * low + 0.25 * torch.randn(3, resolution, resolution, generator=g)).clamp(-1.2, 1.2))
+    return torch.stack(out)
+
+
+class StandInDetector(torch.nn.Module):
+    """Stand-in for the TorchScript Inception (`detector(uint8 NCHW images, return_features=True) -> [N, F]`): a fixed seeded
+    conv + pooling; fp32, so CPU and GPU agree to rounding."""
+
+    def __init__(self, features=24, seed=99):
+        super().__init__()
+        g = torch.Generator().manual_seed(seed)
+        self.register_buffer('w', torch.randn(features, 3, 8, 8, generator=g) * 0.05)
+        self.register_buffer('mix', torch.randn(features, features, generator=g) * 0.3)
+
+    def forward(self, img, return_features=True):
+        x = F.conv2d(img.to(torch.float32) / 255.0 - 0.5, self.w, stride=8)
+        x = torch.tanh(x).mean(dim=(2, 3))
+        return x @ self.mix

@@ -15,6 +15,8 @@ Every file records the weight checksum of the seeded random nets it was made wit
                ResnetBlock2D when adaptive_scale=False) and for softmax(QK^T/sqrt(d))V attention:
                pins those pieces of row A5 for both the oracle UNet layers and the HIP ops.
   loop_k15_a1_n50.npz  the same loop for 50 iterations (loss-curve drift check of the bf16 path).
+  metrics_ref.npz  the reference's evaluation path (metrics/sid_metric_utils.py: generator feature statistics, PIL LANCZOS resize,
+               InfiniteSampler prompt order, FeatureStats) + the Frechet distance formula on stand-in generator / detector objects.
   bias_act.npz reference torch_utils/ops/bias_act.py::_bias_act_ref (+ autograd grads).
   sampler.npz  reference torch_utils/misc.py::InfiniteSampler order.
 """
@@ -234,6 +236,72 @@ def gen_blocks():
     print('blocks done', sorted(k for k in out if k.endswith('_y')))
 
 
+def gen_metrics():
+    """tests/golden/metrics_ref.npz: the reference's OWN evaluation code path (metrics/sid_metric_utils.py, loaded from its file:
+    `compute_feature_stats_for_generator` :412-510 with `FeatureStats` :112-188, `resize_images_in_tensor` :353-375 and the
+    InfiniteSampler prompt order) run on stand-in generator / detector objects, plus the Frechet distance with the three lines of
+    metrics/sid_fid_and_clip.py:65-67 (restated here: they sit inside a function that needs the COCO images).
+    Absent packages are stubbed where the module imports them: networks.clip (open_clip / timm), torchvision.transforms[.functional]
+    -- `to_pil_image` / `to_tensor` are restated from torchvision's documented semantics for uint8 CHW tensors / RGB images."""
+    import importlib.util
+    import types
+
+    import scipy.linalg
+    from PIL import Image
+    ref_harness.import_reference()                          # dnnlib, torch_utils on sys.path; Sampler drift patch
+    ref_harness._stub('networks')
+    ref_harness._stub('networks.clip', CLIP=ref_harness._Missing)
+    tv = ref_harness._stub('torchvision')
+    tvt = ref_harness._stub('torchvision.transforms')
+    tv.transforms = tvt
+
+    def to_pil_image(t):                                    # uint8 [C, H, W] -> PIL RGB
+        return Image.fromarray(t.permute(1, 2, 0).cpu().numpy())
+
+    def to_tensor(img):                                     # PIL RGB -> float32 [C, H, W] in [0, 1]
+        return torch.from_numpy(np.array(img)).permute(2, 0, 1).contiguous().to(torch.float32).div(255)
+    tvt.functional = ref_harness._stub('torchvision.transforms.functional', to_pil_image=to_pil_image, to_tensor=to_tensor)
+    spec = importlib.util.spec_from_file_location('ref_sid_metric_utils', os.path.join(ref_harness.REFERENCE_ROOT, 'metrics', 'sid_metric_utils.py'))
+    mu = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mu)
+    import dnnlib
+    R, N = 512, 12
+    det = fixtures.StandInDetector()
+    seen = dict(contexts=[], resized=[])
+
+    def G(latents, contexts, init_timesteps):
+        assert latents.shape[1:] == (4, R // 8, R // 8) and len(contexts) == latents.shape[0] and int(init_timesteps[0]) == 625
+        seen['contexts'].extend(str(c) for c in contexts)
+        return fixtures.text_images(contexts, R)
+
+    def detector(images, **kw):
+        assert kw == dict(return_features=True) and images.dtype == torch.uint8 and images.shape[1:] == (3, 256, 256)
+        seen['resized'].append(images.clone())
+        return det(images)
+    mu.get_feature_detector = lambda **kw: detector
+    opts = types.SimpleNamespace(G=G, init_timestep=625, rank=0, num_gpus=1, device=torch.device('cpu'), progress=mu.ProgressMonitor(),
+                                 dataset_kwargs=dnnlib.EasyDict(class_name='oracle.fixtures.CaptionSet', resolution=R))
+    torch.manual_seed(0)
+    stats = mu.compute_feature_stats_for_generator(opts=opts, detector_url='stand-in', detector_kwargs=dict(return_features=True),
+                                                   batch_size=8, batch_gen=4, capture_mean_cov=True, max_items=N)
+    mu_gen, sigma_gen = stats.get_mean_cov()
+    F_ = mu_gen.shape[0]
+    rng = np.random.RandomState(5)
+    mu_real = rng.normal(size=F_) * 0.05
+    a = rng.normal(size=(F_, F_)) * 0.05
+    sigma_real = a @ a.T + 0.01 * np.eye(F_)
+    m = np.square(mu_gen - mu_real).sum()                                      # metrics/sid_fid_and_clip.py:65
+    sq, _ = scipy.linalg.sqrtm(np.dot(sigma_gen, sigma_real), disp=False)      # :66
+    fid = float(np.real(m + np.trace(sigma_gen + sigma_real - sq * 2)))        # :67
+    resized = torch.cat(seen['resized'])
+    np.savez_compressed(os.path.join(OUT, 'metrics_ref.npz'), captions=np.array(fixtures.METRIC_CAPTIONS), resolution=R, num_items=N,
+                        contexts=np.array(seen['contexts'][:N]), resized_first=resized[0].numpy(),
+                        resized_sums=resized[:N].to(torch.float64).sum(dim=(2, 3)).numpy(),
+                        features_all=torch.cat([det(r[None]) for r in resized[:N]]).numpy(),
+                        mu_gen=mu_gen, sigma_gen=sigma_gen, mu_real=mu_real, sigma_real=sigma_real, fid=fid, stats_num_items=stats.num_items)
+    print('metrics: fid', fid, 'num_items', stats.num_items, 'contexts', seen['contexts'][:4])
+
+
 def gen_sampler():
     ref = ref_harness.import_reference()
     out = {}
@@ -250,7 +318,7 @@ if __name__ == '__main__':
     if len(sys.argv) > 2 and sys.argv[1] == '_loop2_worker':
         _loop2_worker(sys.argv[2])
         sys.exit(0)
-    which = sys.argv[1:] or ['glue', 'loops', 'bias_act', 'sampler', 'blocks', 'loop2', 'loop_long']
+    which = sys.argv[1:] or ['glue', 'loops', 'bias_act', 'sampler', 'blocks', 'loop2', 'loop_long', 'metrics']
     if 'loop2' in which:
         gen_loop_2rank()
     if 'blocks' in which:
@@ -265,3 +333,5 @@ if __name__ == '__main__':
         gen_loops()
     if 'loop_long' in which:
         gen_loop_long()
+    if 'metrics' in which:
+        gen_metrics()

@@ -4,7 +4,7 @@ Reference: metrics/sid_metric_main.py:25-123 (registry, `calc_metric`, `report_m
 `fid_clip_30k_full` / `fid_test` / `fid_clip_test` entries), metrics/sid_fid_and_clip.py:32-74 (the Frechet distance between
 the Inception feature statistics of generated images and of the real set), metrics/sid_metric_utils.py:112-188
 (`FeatureStats`) and :412-510 (the generation loop: prompts through the InfiniteSampler, z ~ N(0, I) at resolution / 8,
-uint8 images, 256 x 256 resize for the detector; the CLIP score is the mean cosine of the detector's image | text halves).
+uint8 images, 256 x 256 PIL-LANCZOS resize for the detector (reproduced bit for bit on the GPU); the CLIP score is the mean cosine of the detector's image | text halves).
 
 What is different here (not a translation):
   * the feature statistics live ON THE GPU in fp64 (`FeatureStats.raw_mean / raw_cov` are device tensors; x^T x is one
@@ -137,12 +137,57 @@ def load_detector(path, device):
             return pickle.load(f).to(device).eval()
 
 
+_LANCZOS_CACHE = {}
+
+
+def _lanczos_coefficients(in_size, out_size):
+    """The integer filter bank of Pillow's 8-bit LANCZOS resampling, [out_size, in_size] int64 (Pillow src/libImaging/Resample.c:
+    `precompute_coeffs` with the a = 3 windowed sinc -- support 3 * max(scale, 1) input pixels around (x + 0.5) * scale, weights
+    normalised to sum 1 -- then `normalize_coeffs_8bpc`: round-half-away to 22 fractional bits)."""
+    import math
+    key = (in_size, out_size)
+    if key in _LANCZOS_CACHE:
+        return _LANCZOS_CACHE[key]
+    scale = in_size / out_size
+    fscale = max(scale, 1.0)
+    support = 3.0 * fscale
+    K = np.zeros((out_size, in_size), dtype=np.int64)
+    for xx in range(out_size):
+        center = (xx + 0.5) * scale
+        xmin = max(int(center - support + 0.5), 0)
+        xmax = min(int(center + support + 0.5), in_size)
+        arg = (np.arange(xmin, xmax) - center + 0.5) / fscale
+        with np.errstate(invalid='ignore', divide='ignore'):
+            sinc = lambda t: np.where(t == 0, 1.0, np.sin(np.pi * t) / (np.pi * t))      # noqa: E731
+            w = np.where((arg >= -3.0) & (arg < 3.0), sinc(arg) * sinc(arg / 3.0), 0.0)
+        tot = w.sum()
+        if tot != 0:
+            w = w / tot
+        K[xx, xmin:xmax] = np.where(w < 0, np.trunc(-0.5 + w * (1 << 22)), np.trunc(0.5 + w * (1 << 22))).astype(np.int64)
+    _LANCZOS_CACHE[key] = K
+    return K
+
+
 def resize_for_detector(images_u8, size=256):
-    """uint8 NCHW -> uint8 NCHW at size x size (bilinear on the GPU; sid_metric_utils.py `resize_images_in_tensor`)."""
-    if images_u8.shape[-1] == size and images_u8.shape[-2] == size:
+    """uint8 NCHW -> uint8 NCHW at size x size with the arithmetic of the reference's `resize_images_in_tensor`
+    (sid_metric_utils.py:353-375: per image `PIL.Image.resize((256, 256), Image.LANCZOS)`, back to uint8) -- on the device, for the
+    whole batch: Pillow's two passes (horizontal, then vertical, each rounded to 8 bits) with its 22-bit fixed-point coefficients.
+    Sums of 8-bit pixels times 22-bit integers are exact in fp64, so two fp64 GEMMs reproduce the integer pipeline bit for bit
+    (pinned against PIL itself: tests/golden/metrics_ref.npz, tests/test_host_logic.py)."""
+    if images_u8.dtype != torch.uint8 or images_u8.ndim != 4:
+        raise ValueError('resize_for_detector: uint8 NCHW images')
+    H, W = images_u8.shape[-2:]
+    if H == size and W == size:
         return images_u8
-    x = torch.nn.functional.interpolate(images_u8.float(), size=(size, size), mode='bilinear', align_corners=False)
-    return x.round().clamp(0, 255).to(torch.uint8)
+    dev = images_u8.device
+    kh = torch.from_numpy(_lanczos_coefficients(W, size)).to(dev, torch.float64)
+    kv = torch.from_numpy(_lanczos_coefficients(H, size)).to(dev, torch.float64)
+    half, one = float(1 << 21), float(1 << 22)
+    t = torch.matmul(images_u8.to(torch.float64), kh.t())                      # [N, C, H, size]
+    t = torch.floor((t + half) / one).clamp_(0, 255)
+    t = torch.matmul(kv, t)                                                    # [N, C, size, size]
+    t = torch.floor((t + half) / one).clamp_(0, 255)
+    return t.to(torch.uint8)
 
 
 class _PromptList:

@@ -103,7 +103,11 @@ def training_loop(
     rng_device=None, metric_real_stats=None, metric_num_test=None,
 ):
     if not train_mode:
-        raise NotImplementedError('evaluation mode (FID/CLIP metrics) is outside the hot-path scope (SURVEY.md section 8(f))')
+        return evaluate_network(run_dir=run_dir, dataset_kwargs=dataset_kwargs, network_kwargs=network_kwargs, device=device, metrics=metrics,
+                                init_timestep=init_timestep, metric_pt_path=metric_pt_path, metric_open_clip_path=metric_open_clip_path,
+                                pretrained_model_name_or_path=pretrained_model_name_or_path, network_pkl=network_pkl, resolution=resolution,
+                                num_steps=num_steps, metric_real_stats=metric_real_stats, metric_num_test=metric_num_test,
+                                dataset_prompt_text_kwargs=dataset_prompt_text_kwargs)
     if num_steps != 1:
         raise NotImplementedError(f'num_steps={num_steps}: only the one-step generator is trained (the reference marks its '
                                   'multi-step training sampler as unfinished, sid_sd_util.py:165)')
@@ -316,6 +320,58 @@ def training_loop(
             break
     dist.print0('\nExiting...')
     return dict(G=G, fake_score=fake_score, G_ema=G_ema)
+
+
+def evaluate_network(run_dir, dataset_kwargs, network_kwargs, device, metrics, init_timestep, metric_pt_path, metric_open_clip_path,
+                     pretrained_model_name_or_path, network_pkl, resolution, num_steps=1, metric_real_stats=None, metric_num_test=None,
+                     dataset_prompt_text_kwargs=None):
+    """`--train_mode 0` (sid_training_loop.py:680-745): load the text encoder / VAE / scheduler, un-pickle the distilled generator
+    from `network_pkl` (`pickle.load(f)['ema']`, the file the training loop writes at the snapshot ticks) and evaluate every metric
+    with 1, 2 and 4 generation steps; each result goes to `<dirname(run_dir)>/<metric><number>_<steps>.txt` in the reference's
+    `key: value` format.  The preview PNG grids of that branch are not produced (cold path, like the training loop's)."""
+    import re
+    from functools import partial
+
+    from . import metrics as metric_main
+    from .sd_util import sid_sd_sampler
+    if not metrics:
+        raise ValueError('--train_mode 0 evaluates metrics: pass --metrics')
+    if not network_pkl or not os.path.isfile(network_pkl):
+        raise FileNotFoundError(f'--network_pkl {network_pkl!r}: a local network-snapshot-*.pkl is needed (there is no network to fetch one)')
+    dtype = resolve_compute_dtype(dict(network_kwargs).get('compute_dtype'))
+    _, vae, noise_scheduler, text_encoder, tokenizer = load_sd15(
+        pretrained_model_name_or_path=pretrained_model_name_or_path, pretrained_vae_model_name_or_path=None, device=device,
+        weight_dtype=dtype, lora_config=None, compute_dtype=dtype)
+    dist.print0('Loading network completed')
+    dist.print0(f'Loading network from "{network_pkl}"...')
+    with open(network_pkl, 'rb') as f:
+        G_ema = pickle.load(f)['ema'].to(device)
+    G_ema.eval().requires_grad_(False)
+    m = re.search(r'-(\d+)\.pkl$', network_pkl)
+    number_part = m.group(1) if m else '_final'
+    if dataset_kwargs:
+        msrc = dict(dataset_kwargs=dict(dataset_kwargs))
+    else:
+        dist.print0('WARNING: no dataset_kwargs (--data): evaluating on the training prompts; not comparable with the reference\'s COCO numbers')
+        msrc = dict(dataset_kwargs=dict(dataset_prompt_text_kwargs))
+    out = {}
+    for num_steps_eval in (1, 2, 4):
+        for metric in metrics:
+            G_eval = partial(sid_sd_sampler, unet=G_ema, noise_scheduler=noise_scheduler, text_encoder=text_encoder, tokenizer=tokenizer,
+                             resolution=resolution, dtype=torch.float32, return_images=True, vae=vae, num_steps=num_steps, train_sampler=False,
+                             num_steps_eval=num_steps_eval)
+            extra = dict(num_test=metric_num_test) if metric_num_test is not None else {}
+            result = metric_main.calc_metric(metric, G=G_eval, resolution=resolution, init_timestep=init_timestep, detector=metric_pt_path,
+                                             real_stats=metric_real_stats, open_clip_detector=metric_open_clip_path, device=device, **msrc, **extra)
+            out[(metric, num_steps_eval)] = result
+            if dist.get_rank() == 0:
+                print(result.results)
+                txt = os.path.join(os.path.dirname(run_dir) if run_dir else '.', f'{metric}{number_part}_{num_steps_eval:d}.txt')
+                print(txt)
+                with open(txt, 'w') as f:                          # save_metric (sid_training_loop.py:134-137)
+                    for k, v in result.items():
+                        f.write(f'{k}: {v}\n')
+    return out
 
 
 def _hip_opt(kw):

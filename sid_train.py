@@ -13,7 +13,7 @@ Differences (documented, not silent):
   * `--fp16` only selects the optimizer eps; masters are fp32 and compute is bf16 MFMA, or -- with the added option
     `--precision fp32` -- the fp32-accurate mode (the reference's own default precision, ~20x slower);
   * `--metrics` run through sid_lsg_amd/metrics.py at the snapshot ticks and need LOCAL detector / statistics files
-    (--metric_pt_path, --data_stat); `--train_mode 0` raises;
+    (--metric_pt_path, --data_stat); `--train_mode 0 --network_pkl <snapshot>` evaluates a snapshot (1 / 2 / 4 steps);
   * `--data` is optional (it is the COCO image set used only by the metrics).
 """
 import json
@@ -71,8 +71,8 @@ OPTIONS = [
     (('--tmin',), dict(type=click.IntRange(min=0), default=20, show_default=True, help='Smallest teacher time step')),
     (('--lr',), dict(type=click.FloatRange(min=0, min_open=True), default=1e-6, show_default=True, help='Fake-score learning rate')),
     (('--glr',), dict(type=click.FloatRange(min=0, min_open=True), default=1e-6, show_default=True, help='Generator learning rate')),
-    (('--train_mode',), dict(type=bool, default=True, show_default=True, help='Distill (True) or evaluate metrics (unsupported)')),
-    (('--network_pkl',), dict(type=str, default=None, help='Network pickle for metrics (unsupported)')),
+    (('--train_mode',), dict(type=bool, default=True, show_default=True, help='Distill (True) or evaluate the metrics of --network_pkl with 1 / 2 / 4 generation steps (False)')),
+    (('--network_pkl',), dict(type=str, default=None, help='network-snapshot-*.pkl to evaluate with --train_mode 0')),
     (('--cfg_train_fake',), dict(type=float, default=1, show_default=True, help='kappa1: guidance scale when training the fake score')),
     (('--cfg_eval_fake',), dict(type=float, default=1, show_default=True, help='kappa2 = kappa3: guidance scale when evaluating the fake score')),
     (('--cfg_eval_real',), dict(type=float, default=1, show_default=True, help='kappa4: guidance scale when evaluating the teacher')),
@@ -107,8 +107,13 @@ def build_config(o):
         for flag, path in (('--metric_pt_path', o.metric_pt_path), ('--data_stat', o.data_stat)):
             if not path or not os.path.isfile(path):
                 raise click.ClickException(f'--metrics needs {flag} to be a local file (got {path!r})')
-    if not o.train_mode or o.fake_score_use_lora:
-        raise click.ClickException('--train_mode 0 / --fake_score_use_lora are not supported')
+    if o.fake_score_use_lora:
+        raise click.ClickException('--fake_score_use_lora is not supported')
+    if not o.train_mode:
+        if o.metrics is None:
+            raise click.ClickException('--train_mode 0 evaluates a network snapshot: --metrics is required')
+        if not o.network_pkl or not os.path.isfile(o.network_pkl):
+            raise click.ClickException(f'--train_mode 0 needs --network_pkl to be a local network-snapshot-*.pkl (got {o.network_pkl!r})')
     c.metrics, c.resolution = o.metrics, o.resolution
     c.metric_real_stats = o.data_stat
     if o.metrics is not None and o.data:
@@ -130,7 +135,7 @@ def build_config(o):
     c.update(batch_size=o.batch, batch_gpu=o.batch_gpu, loss_scaling=o.ls, loss_scaling_G=o.lsg, cudnn_benchmark=o.bench,
              kimg_per_tick=o.tick, snapshot_ticks=o.snap, state_dump_ticks=o.dump, alpha=o.alpha, tmax=o.tmax, tmin=o.tmin)
     c.update(cfg_train_fake=o.cfg_train_fake, cfg_eval_fake=o.cfg_eval_fake, cfg_eval_real=o.cfg_eval_real, num_steps=o.num_steps,
-             train_mode=True, network_pkl=o.network_pkl, fake_score_use_lora=False, enable_xformers=o.enable_xformers,
+             train_mode=bool(o.train_mode), network_pkl=o.network_pkl, fake_score_use_lora=False, enable_xformers=o.enable_xformers,
              gradient_checkpointing=o.gradient_checkpointing, pretrained_model_name_or_path=o.sd_model,
              pretrained_vae_model_name_or_path=o.sd_model, metric_pt_path=o.metric_pt_path,
              metric_open_clip_path=o.metric_open_clip_path, metric_clip_path=o.metric_clip_path)

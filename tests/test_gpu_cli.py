@@ -101,7 +101,38 @@ def test_train_with_fid_metric(tmp_path):
     assert all(r['snapshot_pkl'].startswith('network-snapshot-') for r in rows)
     stats = [json.loads(ln) for ln in open(glob.glob(os.path.join(run_dir, 'stats_*.jsonl'))[0])]
     assert any('Metrics/fid30k_full' in r for r in stats)
+    # --train_mode 0 (sid_training_loop.py:680-745): evaluate the snapshot the run wrote, 1 / 2 / 4 generation steps, on the caption set
+    # of --data, results as `<metric><kimg>_<steps>.txt` next to the run directory in the reference's `key: value` format
+    snaps = sorted(glob.glob(os.path.join(run_dir, 'network-snapshot-*.pkl')))
+    assert snaps
+    caps = tmp_path / 'coco_captions.txt'
+    caps.write_text('\n'.join(f'evaluation caption {i}' for i in range(9)) + '\n')
+    ev = CliRunner().invoke(sid_train.main, [
+        '--outdir', str(runs), '--data_prompt_text', str(tmp_path), '--data', str(caps), '--sd_model', 'random:tiny', '--seed', '1', '--resolution', '128',
+        '--train_mode', '0', '--network_pkl', snaps[-1], '--metrics', 'fid_test', '--metric_pt_path', det_path, '--data_stat', stat_path],
+        catch_exceptions=False)
+    assert ev.exit_code == 0, ev.output
+    kimg = snaps[-1][-10:-4]
+    for steps in (1, 2, 4):
+        txt = os.path.join(str(runs), f'fid_test{kimg}_{steps}.txt')
+        assert os.path.isfile(txt), os.listdir(str(runs))
+        body = open(txt).read()
+        assert body.startswith('results: ') and 'fid30k_full' in body and 'metric: fid_test' in body
+    none = CliRunner().invoke(sid_train.main, ['--outdir', str(runs), '--data_prompt_text', str(tmp_path), '--sd_model', 'random:tiny',
+                                               '--train_mode', '0', '--metrics', 'fid_test', '--metric_pt_path', det_path, '--data_stat', stat_path])
+    assert none.exit_code != 0 and '--network_pkl' in none.output
     # missing files are refused up front
     bad = CliRunner().invoke(sid_train.main, ['--outdir', str(runs), '--data_prompt_text', str(tmp_path), '--sd_model', 'random:tiny',
                                               '--metrics', 'fid30k_full', '--metric_pt_path', '/nonexistent.pt', '-n'])
     assert bad.exit_code != 0 and '--metric_pt_path' in bad.output
+
+
+@pytest.mark.gpu
+def test_metrics_pipeline_matches_reference_golden_on_gpu(golden_dir):
+    """SURVEY section 8(f4) on the device: prompt order, uint8 conversion, the PIL-LANCZOS resize (fp64 GEMMs on the GPU), the fp64
+    feature statistics on the GPU and the eigenvalue form of the Frechet distance against vectors from the REFERENCE's own
+    evaluation code (tests/golden/metrics_ref.npz, oracle/make_goldens.py::gen_metrics)."""
+    if not torch.cuda.is_available():
+        pytest.skip('needs an MI355X')
+    from test_host_logic import replay_metrics_golden
+    replay_metrics_golden(golden_dir, 'cuda')

@@ -419,3 +419,50 @@ dist.print0("METRICS_OK", dist.get_world_size(), float(metrics.frechet_distance(
                           '127.0.0.1', '--master-port', '29633', str(script)], capture_output=True, text=True,
                          env=dict(os.environ, MASTER_ADDR='127.0.0.1'), timeout=300)
     assert out.returncode == 0 and 'METRICS_OK 2' in out.stdout, out.stdout[-1000:] + out.stderr[-2000:]
+
+
+def replay_metrics_golden(golden_dir, device):
+    """Our evaluation pipeline (sid_lsg_amd.metrics) on `device` against tests/golden/metrics_ref.npz -- vectors produced by the
+    REFERENCE's own `compute_feature_stats_for_generator` / `FeatureStats` / `resize_images_in_tensor` (metrics/sid_metric_utils.py)
+    and the Frechet formula of metrics/sid_fid_and_clip.py:65-67, on the stand-in generator / detector of oracle/fixtures.py."""
+    from oracle import fixtures
+    from sid_lsg_amd import metrics
+    g = np.load(os.path.join(golden_dir, 'metrics_ref.npz'))
+    assert [str(c) for c in g['captions']] == fixtures.METRIC_CAPTIONS
+    R, N = int(g['resolution']), int(g['num_items'])
+    det = fixtures.StandInDetector().to(device)
+    seen = dict(contexts=[], resized=[])
+
+    def G(latents, contexts, init_timesteps):
+        assert latents.shape[1:] == (4, R // 8, R // 8) and latents.device.type == torch.device(device).type
+        seen['contexts'].extend(contexts)
+        return fixtures.text_images(contexts, R).to(device)
+
+    def detector(img, return_features=True):
+        seen['resized'].append(img.clone())
+        return det(img)
+    res = metrics.calc_metric('fid_test', G=G, dataset_kwargs=dict(class_name='oracle.fixtures.CaptionSet', resolution=R), resolution=R,
+                              init_timestep=625, detector=detector, real_stats=(g['mu_real'], g['sigma_real']), device=device, num_test=N)
+    # 1. prompt order = the reference's InfiniteSampler(seed = 0) stream through its DataLoader
+    assert seen['contexts'] == [str(c) for c in g['contexts']]
+    # 2. uint8 conversion + PIL LANCZOS resize to 256 x 256: bit for bit
+    resized = torch.cat(seen['resized'])
+    assert resized.shape == (N, 3, 256, 256) and resized.dtype == torch.uint8
+    assert np.array_equal(resized[0].cpu().numpy(), g['resized_first'])
+    assert np.array_equal(resized.to(torch.float64).sum(dim=(2, 3)).cpu().numpy(), g['resized_sums'])
+    # 3. features -> FeatureStats mean / covariance -> Frechet distance
+    o = metrics.MetricOptions(G=G, dataset_kwargs=dict(class_name='oracle.fixtures.CaptionSet', resolution=R), resolution=R, detector=detector,
+                              real_stats=(g['mu_real'], g['sigma_real']), device=device)
+    stats, _, _ = metrics.generator_feature_stats(o, N)
+    mu, sigma = stats.get_mean_cov()
+    assert stats.num_items == int(g['stats_num_items'])
+    np.testing.assert_allclose(mu, g['mu_gen'], rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(sigma, g['sigma_gen'], rtol=1e-4, atol=1e-8)
+    fid = res.results.fid30k_full
+    print(f'[{device}] FID {fid:.9f} vs the reference path {float(g["fid"]):.9f}')
+    assert abs(fid - float(g['fid'])) < 1e-5 * abs(float(g['fid']))
+    return fid
+
+
+def test_metrics_pipeline_matches_reference_golden_cpu(golden_dir):
+    replay_metrics_golden(golden_dir, 'cpu')
