@@ -97,11 +97,12 @@ class DispatchTrace:
     def stop(self):
         torch.cuda.synchronize()
         out = {}
-        buf = torch.zeros(5, dtype=torch.float64)
+        buf = torch.zeros(9, dtype=torch.float64)
         for k, f in self.FAM.items():
+            buf[7], buf[8] = PEAK_BF16_TFLOPS * 1e12, PEAK_HBM_GBS * 1e9
             self.lib.sidlsg_trace_read(f, buf.data_ptr())
-            ms, work, sampled, calls, kernels = buf.tolist()
-            out[k] = dict(launches=int(sampled), calls=int(calls), ms=ms, flops=work, kernels=int(kernels))
+            ms, work, sampled, calls, kernels, nbytes, bound_ms = buf.tolist()[:7]
+            out[k] = dict(launches=int(sampled), calls=int(calls), ms=ms, flops=work, kernels=int(kernels), bytes=nbytes, bound_ms=bound_ms)
         self.lib.sidlsg_trace_enable(0)
         return out
 
@@ -451,7 +452,7 @@ def main():
             # the same for the GROUPED pass of phase B: fake-score network + teacher on the stacked batch of 4b samples, one launch
             # per layer for both (HipUNet2DCondition.forward_pair; sid_step.py)
             pair = None
-            if step.grouped:
+            if step._use_grouped(b) or os.environ.get('SIDLSG_BENCH_PAIR_PASS', '0') == '1':
                 from sid_lsg_amd import ops as _o
 
                 def pair_pass():
@@ -484,7 +485,7 @@ def main():
                                f'batch_gpu={b}, fp32 masters + bf16 MFMA compute, Adam(beta1=0)+EMA, random-init weights',
                    'global_batch': batch_size, 'parallelism': f'dp{world}', 'teacher_weights': args.teacher_weights},
         'step_tflops': value * img_tflop, 'step_mfma_frac': value * img_tflop / (PEAK_BF16_TFLOPS * world),
-        'graph': bool(args.graph), 'grouped_frozen_pass': bool(step.grouped), 'host_enqueue_ms_per_step': t_host, 'loss_fake': float(lf), 'loss_G': float(lg), 'peak_mem_gb': torch.cuda.max_memory_allocated(dev) / 2 ** 30,
+        'graph': bool(args.graph), 'grouped_frozen_pass': bool(step._use_grouped(b)), 'host_enqueue_ms_per_step': t_host, 'loss_fake': float(lf), 'loss_G': float(lg), 'peak_mem_gb': torch.cuda.max_memory_allocated(dev) / 2 ** 30,
     }
     # parity at the BENCH workload: the losses of iteration 0 and of the first timed step against the stored fp32-mode values
     # (tests/golden/bench_loss_reference.json, made by tools/make_bench_loss_reference.py with the HIP fp32-accurate mode, itself
@@ -536,6 +537,11 @@ def main():
             o = {'bound': 'hbm' if hbm else 'mfma', 'kernel': KERNELS[key], 'achieved': ach, 'peak': peak, 'unit': unit, 'frac': ach / peak,
                  'timing': 'per-dispatch start/stop timestamps of every sampled call\'s kernels over the timed region (hipExtLaunchKernelGGL: the '
                            'interval rocprofv3 --kernel-trace reports; all kernels of a call, e.g. split-K GEMM + its finish kernel)',
+                 # every call graded against ITS OWN bound: max(flop / MFMA peak, algorithmic bytes / HBM peak) summed over the sampled calls,
+                 # over their measured time (a K = 320 GEMM is HBM-bound, a K = 5760 conv MFMA-bound) + the family's two plain fractions
+                 'frac_of_per_call_roofline': r['bound_ms'] / r['ms'] if r['ms'] > 0 else 0.0,
+                 'algorithmic_GBps': r['bytes'] / (r['ms'] * 1e-3) / 1e9 if r['ms'] > 0 else 0.0,
+                 'frac_hbm': r['bytes'] / (r['ms'] * 1e-3) / 1e9 / PEAK_HBM_GBS if r['ms'] > 0 else 0.0,
                  'traffic': None, 'launches': r['launches'], 'launches_total': r['calls'], 'kernels_timed': r['kernels'], 'avg_launch_ms': r['ms'] / max(r['launches'], 1),
                  # share of the step: sampled average duration x all launches of the timed region (streams overlap: the shares of all
                  # families add up to more than the wall time)

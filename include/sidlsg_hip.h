@@ -115,8 +115,10 @@ int sidlsg_layernorm_bwd_g2(const void* x, const void* dy, const float* stats, c
  * no extra packets in the stream, unlike events recorded around a launch.  Families: 0 dense GEMM fwd + dgrad, 1 conv3x3 fwd +
  * dgrad, 2 attention forward, 3 attention backward, 4 dense weight gradient, 5 conv weight gradient, 6 GroupNorm forward,
  * 7 GroupNorm backward, 8 LayerNorm forward, 9 LayerNorm backward.  Work = algorithmic flop (0-5) or bytes (6-9) of the call.
- * sidlsg_trace_read (after a device synchronisation): out[0] summed kernel ms of the sampled calls, out[1] their summed work,
- * out[2] sampled calls, out[3] all calls of the family since enable, out[4] timed kernels. */
+ * sidlsg_trace_read (after a device synchronisation; out: 9 doubles, out[7] / out[8] = peak flop/s and bytes/s on input):
+ * out[0] summed kernel ms of the sampled calls, out[1] their summed work, out[2] sampled calls, out[3] all calls of the family since
+ * enable, out[4] timed kernels, out[5] their summed algorithmic bytes, out[6] their summed roofline time in ms (per call
+ * max(flop / peak flop/s, bytes / peak bytes/s): every call is graded against its own bound). */
 int sidlsg_trace_enable(int max_kernels);
 int sidlsg_trace_pause(int paused);
 int sidlsg_trace_set_stride(int family, int stride);

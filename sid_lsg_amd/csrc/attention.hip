@@ -825,7 +825,7 @@ extern "C" {
 int sidlsg_attn_fwd(const void* Q, const void* K, const void* V, void* O, float* LSE, int B, int H, int Nq, int Nk, int D,
                     int ldq, int ldk, int ldv, int ldo, long long bsq, long long bsk, long long bsv, long long bso,
                     void* stream) {
-    SidlsgTraceScope ts(SIDLSG_FAM_ATTN_FWD, 4.0 * B * H * Nq * (double)Nk * D);
+    SidlsgTraceScope ts(SIDLSG_FAM_ATTN_FWD, 4.0 * B * H * Nq * (double)Nk * D, 2.0 * B * H * D * (2.0 * Nq + 2.0 * Nk));
     return attn_fwd_impl(false, Q, K, V, O, LSE, B, H, Nq, Nk, D, ldq, ldk, ldv, ldo, bsq, bsk, bsv, bso, stream);
 }
 
@@ -833,7 +833,7 @@ int sidlsg_attn_fwd(const void* Q, const void* K, const void* V, void* O, float*
 int sidlsg_attn_bwd(const void* Q, const void* K, const void* V, const void* O, const void* dO, const float* LSE, void* dQ,
                     void* dK, void* dV, float* delta, int B, int H, int Nq, int Nk, int D, int ldq, int ldk, int ldv, int ldo,
                     long long bsq, long long bsk, long long bsv, long long bso, void* stream) {
-    SidlsgTraceScope ts(SIDLSG_FAM_ATTN_BWD, ((dK && dV) ? 10.0 : 6.0) * B * H * Nq * (double)Nk * D);
+    SidlsgTraceScope ts(SIDLSG_FAM_ATTN_BWD, ((dK && dV) ? 10.0 : 6.0) * B * H * Nq * (double)Nk * D, 2.0 * B * H * D * (4.0 * Nq + ((dK && dV) ? 4.0 : 2.0) * Nk));
     return attn_bwd_impl(false, Q, K, V, O, dO, LSE, dQ, dK, dV, delta, B, H, Nq, Nk, D, ldq, ldk, ldv, ldo, bsq, bsk, bsv, bso, stream);
 }
 
@@ -844,13 +844,13 @@ int sidlsg_attn_bwd(const void* Q, const void* K, const void* V, const void* O, 
 int sidlsg_attn_fwd_ps(const void* Q, const void* K, const void* V, void* O, float* LSE, int B, int H, int Nq, int Nk, int D,
                        int ldq, int ldk, int ldv, int ldo, long long bsq, long long bsk, long long bsv, long long bso,
                        void* stream) {
-    SidlsgTraceScope ts(SIDLSG_FAM_ATTN_FWD, 4.0 * B * H * Nq * (double)Nk * D);
+    SidlsgTraceScope ts(SIDLSG_FAM_ATTN_FWD, 4.0 * B * H * Nq * (double)Nk * D, 2.0 * B * H * D * (2.0 * Nq + 2.0 * Nk));
     return attn_fwd_impl(true, Q, K, V, O, LSE, B, H, Nq, Nk, D, ldq, ldk, ldv, ldo, bsq, bsk, bsv, bso, stream);
 }
 int sidlsg_attn_bwd_ps(const void* Q, const void* K, const void* V, const void* O, const void* dO, const float* LSE, void* dQ,
                        void* dK, void* dV, float* delta, int B, int H, int Nq, int Nk, int D, int ldq, int ldk, int ldv, int ldo,
                        long long bsq, long long bsk, long long bsv, long long bso, void* stream) {
-    SidlsgTraceScope ts(SIDLSG_FAM_ATTN_BWD, ((dK && dV) ? 10.0 : 6.0) * B * H * Nq * (double)Nk * D);
+    SidlsgTraceScope ts(SIDLSG_FAM_ATTN_BWD, ((dK && dV) ? 10.0 : 6.0) * B * H * Nq * (double)Nk * D, 2.0 * B * H * D * (4.0 * Nq + ((dK && dV) ? 4.0 : 2.0) * Nk));
     return attn_bwd_impl(true, Q, K, V, O, dO, LSE, dQ, dK, dV, delta, B, H, Nq, Nk, D, ldq, ldk, ldv, ldo, bsq, bsk, bsv, bso, stream);
 }
 

@@ -134,12 +134,12 @@ template <typename T> DEVFN void zerov8(T* p) {
 // ---- in-library kernel timing (trace.hip): families of the step's kernels, and the launch macro every family kernel goes through
 enum { SIDLSG_FAM_GEMM = 0, SIDLSG_FAM_CONV, SIDLSG_FAM_ATTN_FWD, SIDLSG_FAM_ATTN_BWD, SIDLSG_FAM_WGRAD, SIDLSG_FAM_CONV_WGRAD,
        SIDLSG_FAM_GN_FWD, SIDLSG_FAM_GN_BWD, SIDLSG_FAM_LN_FWD, SIDLSG_FAM_LN_BWD, SIDLSG_TRACE_FAMILIES };
-bool sidlsg_trace_scope_begin(int family, double work);
+bool sidlsg_trace_scope_begin(int family, double work, double bytes);
 void sidlsg_trace_scope_end();
 bool sidlsg_trace_events(hipEvent_t* e0, hipEvent_t* e1);
 struct SidlsgTraceScope {
     bool open;
-    SidlsgTraceScope(int family, double work) : open(sidlsg_trace_scope_begin(family, work)) {}
+    SidlsgTraceScope(int family, double work, double bytes = 0.0) : open(sidlsg_trace_scope_begin(family, work, bytes)) {}
     ~SidlsgTraceScope() { if (open) sidlsg_trace_scope_end(); }
 };
 #include <hip/hip_ext.h>

@@ -1709,7 +1709,10 @@ template <int MODE>
 static int dispatch_gemm(const GemmParams& pin, hipStream_t s) {
     GemmParams p = pin;
     p.Mtot = p.M;
-    SidlsgTraceScope ts(MODE == 0 ? SIDLSG_FAM_GEMM : SIDLSG_FAM_CONV, 2.0 * p.M * (double)p.N * p.K);
+    // algorithmic bytes: A read once (conv: the image, not its 9-fold im2col), W once per weight set, C written once, + the residual
+    const double a_elems = MODE == 0 ? (double)p.M * p.K : (double)p.M / (p.Ho * p.Wo) * (p.ups ? (p.H / 2) * (p.Wd / 2) : p.H * p.Wd) * p.Cin;
+    SidlsgTraceScope ts(MODE == 0 ? SIDLSG_FAM_GEMM : SIDLSG_FAM_CONV, 2.0 * p.M * (double)p.N * p.K,
+                        2.0 * (a_elems + (double)p.N * p.K * (p.Mg ? 2 : 1) + (double)p.M * p.N * ((p.flags & F_OUT_F32) ? 2 : 1) + (p.res ? (double)p.M * p.N : 0.0)));
     // N multiple of 160 (every SD channel count is a multiple of 320) -> exact 160-wide tiles and, for dense rows /
     // Cin % 64 == 0 convs, the direct-to-LDS kernel (v3); otherwise 128-wide; narrow outputs (conv_out, dgrad of conv_in)
     // -> 64-wide.  Small pixel counts (8x8 / 16x16 stages, small batches) would give < 256 tiles = idle CUs: split K when
@@ -2446,7 +2449,7 @@ int sidlsg_wgrad_bf16(const void* dY, int ldy, const void* A, int lda, float* dW
     const unsigned long long ab = ((unsigned long long)(M - 1) * lda + K) * 2ull, yb = ((unsigned long long)(M - 1) * ldy + N) * 2ull;
     if (!fits31(ab) || !fits31(yb)) return SIDLSG_EINVAL;
     p.a_bytes = (unsigned)ab; p.y_bytes = (unsigned)yb;
-    SidlsgTraceScope ts(SIDLSG_FAM_WGRAD, 2.0 * M * (double)N * K);
+    SidlsgTraceScope ts(SIDLSG_FAM_WGRAD, 2.0 * M * (double)N * K, 2.0 * ((double)M * N + (double)M * K) + 8.0 * N * K);      // dY, A read once; dW read + written (fp32)
     return launch_wgrad<0>(p, (hipStream_t)stream);
 }
 
@@ -2463,7 +2466,8 @@ int sidlsg_conv3x3_wgrad_bf16(const void* dY, int ldy, const void* X, int ldx, f
     const unsigned long long ab = (((unsigned long long)B * Hs * Ws - 1) * ldx + Cin) * 2ull, yb = ((unsigned long long)(p.M - 1) * ldy + Cout) * 2ull;
     if (!fits31(ab) || !fits31(yb)) return SIDLSG_EINVAL;
     p.a_bytes = (unsigned)ab; p.y_bytes = (unsigned)yb;
-    SidlsgTraceScope ts(SIDLSG_FAM_CONV_WGRAD, 2.0 * p.M * (double)p.N * p.K);
+    SidlsgTraceScope ts(SIDLSG_FAM_CONV_WGRAD, 2.0 * p.M * (double)p.N * p.K,
+                        2.0 * ((double)p.M * p.N + (double)B * Hs * Ws * Cin) + 8.0 * p.N * p.K);
     return launch_wgrad<1>(p, (hipStream_t)stream);
 }
 

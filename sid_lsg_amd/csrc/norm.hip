@@ -526,7 +526,8 @@ static int groupnorm_fwd_t(const void* x, const float* gamma, const float* beta,
                            const float* beta1 = nullptr) {
     GnGeom g; if (int e = gn_geom(g, B, HW, C, G)) return e;
     if (gamma1 && ((B & 1) || !beta1)) return SIDLSG_EINVAL;
-    SidlsgTraceScope ts(SIDLSG_FAM_GN_FWD, (double)B * HW * C * (sizeof(T) + (F8 ? 1 : sizeof(T))));      // algorithmic bytes: read x, write y
+    const double tb_ = (double)B * HW * C * (sizeof(T) + (F8 ? 1 : sizeof(T)));
+    SidlsgTraceScope ts(SIDLSG_FAM_GN_FWD, tb_, tb_);      // algorithmic bytes: read x, write y
     hipStream_t s = (hipStream_t)stream;
     const int threads = g.C8 * g.rows;
     SIDLSG_LAUNCH(gn_stats_kernel<T>, dim3(g.nch, B), dim3(threads), (size_t)g.rows * C * 2 * sizeof(float), s,
@@ -543,7 +544,8 @@ static int groupnorm_bwd_t(const void* x, const void* dy, const float* stats, co
                            int silu, void* stream, const float* gamma1 = nullptr, const float* beta1 = nullptr) {
     GnGeom g; if (int e = gn_geom(g, B, HW, C, G)) return e;
     if (gamma1 && ((B & 1) || !beta1 || dgamma || dbeta)) return SIDLSG_EINVAL;      // grouped: frozen networks (no parameter gradients)
-    SidlsgTraceScope ts(SIDLSG_FAM_GN_BWD, (double)B * HW * C * sizeof(T) * (dres ? 4 : 3));                // read x, dy (, dres), write dx
+    const double tb_ = (double)B * HW * C * sizeof(T) * (dres ? 4 : 3);
+    SidlsgTraceScope ts(SIDLSG_FAM_GN_BWD, tb_, tb_);                // read x, dy (, dres), write dx
     hipStream_t s = (hipStream_t)stream;
     const int threads = g.C8 * g.rows;
     SIDLSG_LAUNCH(gn_bwd_stats_kernel<T>, dim3(g.nch, B), dim3(threads), (size_t)g.rows * C * 2 * sizeof(float), s,
@@ -563,7 +565,8 @@ static int layernorm_fwd_t(const void* x, const float* gamma, const float* beta,
                            float eps, void* stream, const float* gamma1 = nullptr, const float* beta1 = nullptr) {
     if (C % 8 || C > 8 * 64 * LN_MAXCH || rows <= 0) return SIDLSG_EINVAL;
     if (gamma1 && ((rows & 1) || !beta1)) return SIDLSG_EINVAL;
-    SidlsgTraceScope ts(SIDLSG_FAM_LN_FWD, (double)rows * C * (sizeof(T) + (F8 ? 1 : sizeof(T))));
+    const double tb_ = (double)rows * C * (sizeof(T) + (F8 ? 1 : sizeof(T)));
+    SidlsgTraceScope ts(SIDLSG_FAM_LN_FWD, tb_, tb_);
     const int nch = (C / 8 + 63) / 64;
     const int R = nch <= 1 ? 4 : 2;
     // rows per wave: enough waves to fill the chip (>= ~4096), at most 16 rows (amortises the gamma/beta loads)
@@ -589,7 +592,8 @@ static int layernorm_bwd_t(const void* x, const void* dy, const float* stats, co
                            float* dgamma, float* dbeta, float* ws, int rows, int C, void* stream, const float* gamma1 = nullptr) {
     if (C % 8 || C > 8 * 64 * LN_MAXCH || rows <= 0) return SIDLSG_EINVAL;
     hipStream_t s = (hipStream_t)stream;
-    SidlsgTraceScope ts(SIDLSG_FAM_LN_BWD, (double)rows * C * sizeof(T) * (dres ? 4 : 3));
+    const double tb_ = (double)rows * C * sizeof(T) * (dres ? 4 : 3);
+    SidlsgTraceScope ts(SIDLSG_FAM_LN_BWD, tb_, tb_);
     int nb = layernorm_bwd_nblocks(rows);
     int rpb = (rows + nb - 1) / nb;
     if (gamma1) {       // grouped launch (frozen networks): blocks must not straddle the halves

@@ -15,7 +15,7 @@
 #include <vector>
 
 namespace {
-struct Rec { int family; double work; int first, count; };
+struct Rec { int family; double work, bytes; int first, count; };
 struct State {
     std::mutex mu;
     bool on = false;
@@ -30,14 +30,14 @@ State& st() { static State s; return s; }
 thread_local int t_cur = -1;          // index of the open sampled record of this thread
 }  // namespace
 
-bool sidlsg_trace_scope_begin(int family, double work) {
+bool sidlsg_trace_scope_begin(int family, double work, double bytes) {
     State& s = st();
     if (!s.on || family < 0 || family >= SIDLSG_TRACE_FAMILIES || t_cur >= 0) return false;
     std::lock_guard<std::mutex> lk(s.mu);
     const long long c = s.calls[family]++;
     if (c % s.stride[family]) return false;
     if (s.used + 16 > s.pool.size()) return false;      // pool exhausted: stop sampling, keep counting
-    s.recs.push_back({family, work, (int)s.used, 0});
+    s.recs.push_back({family, work, bytes, (int)s.used, 0});
     t_cur = (int)s.recs.size() - 1;
     return true;
 }
@@ -95,12 +95,16 @@ int sidlsg_trace_set_stride(int family, int stride) {
 }
 
 // out[0] = summed kernel time of the sampled calls (ms), out[1] = their summed work, out[2] = sampled calls, out[3] = all calls
-// of the family since enable, out[4] = timed kernels.  Call after the device has been synchronised.
+// of the family since enable, out[4] = timed kernels, out[5] = summed algorithmic bytes of the sampled calls (operands read once +
+// outputs written once), out[6] = the sampled calls' summed ROOFLINE time in ms: per call max(flop / peak_flops, bytes / peak_bw)
+// with the peaks the caller passes in out[7] (flop/s) and out[8] (bytes/s) -- a K = 320 GEMM is HBM-bound, a K = 5760 conv is
+// MFMA-bound, and each call is graded against its own bound.  Call after the device has been synchronised; out: 9 doubles.
 int sidlsg_trace_read(int family, double* out) {
     if (family < 0 || family >= SIDLSG_TRACE_FAMILIES || !out) return SIDLSG_EINVAL;
     State& s = st();
     std::lock_guard<std::mutex> lk(s.mu);
-    double ms = 0, work = 0;
+    double ms = 0, work = 0, bytes = 0, bound = 0;
+    const double pf = out[7] > 0 ? out[7] : 2.5e15, pb = out[8] > 0 ? out[8] : 8e12;
     long long sampled = 0, kernels = 0;
     for (const Rec& r : s.recs) {
         if (r.family != family) continue;
@@ -112,9 +116,11 @@ int sidlsg_trace_read(int family, double* out) {
             t += f;
         }
         if (!ok) continue;
-        ms += t; work += r.work; sampled++; kernels += r.count;
+        ms += t; work += r.work; bytes += r.bytes; sampled++; kernels += r.count;
+        bound += 1e3 * ((r.work / pf > r.bytes / pb) ? r.work / pf : r.bytes / pb);
     }
     out[0] = ms; out[1] = work; out[2] = (double)sampled; out[3] = (double)s.calls[family]; out[4] = (double)kernels;
+    out[5] = bytes; out[6] = bound;
     return SIDLSG_OK;
 }
 

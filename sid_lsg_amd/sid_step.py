@@ -91,11 +91,15 @@ class SiDStep:
         # [psi's CFG batch ; phi's CFG batch] -- every contraction / normalisation launch carries both parameter sets and picks
         # one per block, so the grids of the 16x16 / 8x8 stages, the time-embedding MLP and the 77-token K/V projections are
         # twice as large and the frozen passes issue half the launches (forward AND data-gradient backward).
-        # $SIDLSG_GROUPED_FROZEN: 1 = on, 0 = off (the two-stream path above, kept as the A/B control), auto (default) = on unless
-        # gradients are exchanged between ranks: there psi's exchange + optimizer step hide under the teacher's forward, which a
-        # joint pass (psi must be up to date when it starts) would give up.
-        mode = os.environ.get('SIDLSG_GROUPED_FROZEN', 'auto').lower()
-        self.grouped = (mode == '1' or (mode == 'auto' and not self.exchange)) and self._can_group()
+        # Measured on one MI355X (profiles/r04_grouped_ab.md): the grouped pass alone is 1.10x faster than the two networks one after
+        # the other (34.5 vs 2 x 19.0 ms at batch_gpu 8), and inside the step it wins where the grids are small -- batch_gpu 1: 134 ->
+        # 113 ms per iteration, batch_gpu 2: 131 -> 113 -- but at batch_gpu 4 / 8 the two-STREAM path is 1 % / 2 % faster: there both
+        # networks' grids fill the chip on their own, and two concurrent streams also hide each other's kernel tails, which one
+        # stream of twice-as-large kernels cannot.  $SIDLSG_GROUPED_FROZEN: 1 = always, 0 = never (two-stream path), auto (default)
+        # = for rounds of at most 2 samples per rank, and never while gradients are exchanged between ranks (there psi's exchange +
+        # optimizer step hide under the teacher's forward, which a joint pass -- psi must be up to date when it starts -- gives up).
+        self.grouped_mode = os.environ.get('SIDLSG_GROUPED_FROZEN', 'auto').lower()
+        self.grouped = self.grouped_mode == '1' and self._can_group()
         # opt-in: optimizer steps issued segment-wise from inside the backward, on their own stream (_SegmentedUpdate).  Same
         # results; measured NEUTRAL on one MI355X (221.5 / 220.9 vs 221.7 / 220.8 ms per iteration): the trace shows 3.2 of
         # the 4.8-5.5 ms of each optimizer kernel moving under the backward, and the kernels it then shares HBM with
@@ -113,6 +117,13 @@ class SiDStep:
         if not (G.compute_dtype == fake_score.compute_dtype == true_score.compute_dtype):
             raise ValueError('G, fake_score and true_score must share one compute dtype (they share the noisy CFG batch)')
         self.phi.requires_grad_(False)
+
+    def _use_grouped(self, batch):
+        if self.grouped_mode == '0':
+            return False
+        if self.grouped_mode == 'auto' and (batch > 2 or self.exchange):
+            return False
+        return self._can_group()
 
     def _can_group(self):
         from .unet import HipUNet2DCondition
@@ -209,7 +220,7 @@ class SiDStep:
                                    act_dtype=self.psi.compute_dtype)
         k2 = self.k2 if guided else 1.0
         k4 = self.k4 if guided else 1.0
-        if self.grouped and self._can_group():
+        if self._use_grouped(len(r['z'])):
             # one grouped pass over [psi's batch ; phi's batch] (:494-506: two sid_sd_denoise calls on identical inputs)
             if before_fake_eval is not None:
                 before_fake_eval()

@@ -182,7 +182,7 @@ def test_grouped_frozen_pass_changes_nothing_in_the_step(dev, monkeypatch):
         G_ema = phi.clone_network(with_grad_buffers=False)
         step = SiDStep(G, psi, phi, G_ema, DDPMScheduler().to(dev), FusedAdamEMA(psi.parameters(), lr=lr), FusedAdamEMA(G.parameters(), lr=lr),
                        alpha=1.0, cfg_train_fake=1.5, cfg_eval_fake=1.5, cfg_eval_real=4.5, batch_gpu_total=2 * b, init_timestep=625)
-        assert step.grouped == (mode == '1')
+        assert step._use_grouped(b) == (mode == '1')
         gen = torch.Generator().manual_seed(3)
         losses = []
         for it in range(2):

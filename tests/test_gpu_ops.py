@@ -633,9 +633,10 @@ def test_dispatch_trace_reports_kernel_time(dev):
     for _ in range(40):
         ops.gemm(a, w, out=out)
     torch.cuda.synchronize()
-    buf = torch.zeros(5, dtype=torch.float64)
+    buf = torch.zeros(9, dtype=torch.float64)
     lib.sidlsg_trace_read(0, buf.data_ptr())
-    ms, work, sampled, calls, kernels = buf.tolist()
+    ms, work, sampled, calls, kernels, nbytes, bound_ms = buf.tolist()[:7]
+    assert abs(nbytes - 14 * 2.0 * (M * K + N * K + M * N)) < 1e3 and abs(bound_ms - 14 * 1e3 * 2.0 * M * N * K / 2.5e15) < 1e-6
     lib.sidlsg_trace_set_stride(0, 1)
     lib.sidlsg_trace_enable(0)
     print(f'batch of 40: {batch_ms * 1e3:.1f} us per launch; dispatch timestamps: {ms / sampled * 1e3:.1f} us per launch over {int(sampled)} of {int(calls)} calls')
