@@ -229,8 +229,11 @@ def setup_step(arch, b, resolution, kappa, dev, rank=0, world=1, teacher_weights
     psi = phi.clone_network()
     G = phi.clone_network()
     G_ema = phi.clone_network(with_grad_buffers=False)
-    if teacher_weights == 'fp8':
+    if teacher_weights in ('fp8', 'fp8-frozen'):
         phi.enable_fp8_weights()
+    if teacher_weights == 'fp8-frozen':       # + the fake-score network's phase-B evaluation and the generator's no-grad pass
+        psi.enable_fp8_weights(frozen_passes_only=True)
+        G.enable_fp8_weights(frozen_passes_only=True)
     text_encoder.to(torch.bfloat16)          # the text states are bf16 in both compute modes (PyTorch-ROCm CLIP, north_star)
     cond = TextConditioner(tokenizer, text_encoder, out_dtype=compute_dtype)
     opt_f = FusedAdamEMA(psi.parameters(), lr=1e-6, betas=(0.0, 0.999), eps=1e-8)
@@ -294,9 +297,10 @@ def main():
     ap.add_argument('--arch', default='sd15')
     ap.add_argument('--kappa', type=float, default=1.5)
     ap.add_argument('--resolution', type=int, default=512, help='image resolution (latents are resolution/8); 768 for BASELINE config #4')
-    ap.add_argument('--teacher-weights', default='bf16', choices=['bf16', 'fp8'],
+    ap.add_argument('--teacher-weights', default='bf16', choices=['bf16', 'fp8', 'fp8-frozen'],
                     help="fp8: the frozen teacher's forward weights as e4m3 + per-channel scales (BASELINE configs[4] precision; "
-                         "not the headline configuration)")
+                         "not the headline configuration); fp8-frozen: every pass without weight gradients -- teacher, the fake-score "
+                         "network's phase-B evaluation, the generator's no-grad pass of phase A")
     ap.add_argument('--graph', action='store_true',
                     help='run the timed region through SiDStep.iteration_graphed (one HIP graph per iteration); per-kernel event '
                          'timing then happens on eager iterations after the timed region')
@@ -452,7 +456,7 @@ def main():
             # the same for the GROUPED pass of phase B: fake-score network + teacher on the stacked batch of 4b samples, one launch
             # per layer for both (HipUNet2DCondition.forward_pair; sid_step.py)
             pair = None
-            if step._use_grouped(b) or os.environ.get('SIDLSG_BENCH_PAIR_PASS', '0') == '1':
+            if step._can_group():          # (measured whether or not the step itself uses it at this batch size: `grouped_frozen_pass`)
                 from sid_lsg_amd import ops as _o
 
                 def pair_pass():

@@ -426,6 +426,8 @@ def linear(x, weight, bias, w16, w16t, res=None, rowvec=None, rows_per_batch=1, 
         wp, bp = _pair(weight), _pair(bias)
         _frozen(wp, bp)
         return _LinearG2.apply(x, Pair(bp[0], bp[1]) if bp is not None else None, _pair(w16), _pair(w16t), res, rowvec, rows_per_batch, out_f32)
+    if isinstance(w16, Fp8Weight):
+        _mx8_no_weight_grads(weight, None)
     return _Linear.apply(x, weight, bias, w16, w16t, res, rowvec, rows_per_batch, out_f32)
 
 
@@ -533,6 +535,8 @@ def conv3x3_op(x, weight, bias, w16, w16t, res=None, rowvec=None, stride=1, ups=
         _frozen(wp, bp)
         bq = _pair(bias_p) if bias_p is not None else bp        # (conv_out: the zero-padded bias of the padded output channels)
         return _Conv3x3G2.apply(x, Pair(bq[0], bq[1]) if bq is not None else None, _pair(w16), _pair(w16t), res, rowvec, stride, ups, out_f32)
+    if isinstance(w16, Fp8Weight):
+        _mx8_no_weight_grads(weight, None)
     return _Conv3x3.apply(x, weight, bias, w16, w16t, res, rowvec, stride, ups, out_f32, bias_p)
 
 
@@ -786,8 +790,6 @@ class _NormLinearMX8(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, eps, groups, silu, fork, w8, bias, w16t, weight):
         _chk(x, BF16)
-        if _wants_grad(weight) or _wants_grad(gamma):
-            raise RuntimeError('the MX-fp8 path is for frozen networks')
         C = x.shape[-1]
         y8 = torch.empty(x.shape, device=x.device, dtype=torch.uint8)
         if groups:
@@ -847,8 +849,6 @@ class _NormConvMX8(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, eps, groups, fork, w8, bias, w16t, weight, res, rowvec):
         _chk(x, BF16)
-        if _wants_grad(weight) or _wants_grad(gamma):
-            raise RuntimeError('the MX-fp8 path is for frozen networks')
         B, H, W, C = x.shape
         HW = H * W
         n = lib.sidlsg_groupnorm_ws_floats.raw(B, HW, C, groups)
@@ -887,13 +887,21 @@ class _NormConvMX8(torch.autograd.Function):
         return (dx,) + (None,) * 9 + (dres, None)
 
 
+def _mx8_no_weight_grads(weight, gamma):
+    """The e4m3 forward has no weight-gradient backward: fine under no_grad and for frozen parameters, an error otherwise."""
+    if torch.is_grad_enabled() and ((weight is not None and weight.requires_grad) or (gamma is not None and gamma.requires_grad)):
+        raise RuntimeError('the MX-fp8 path is for passes without weight gradients (frozen network, or torch.no_grad())')
+
+
 def norm_conv_mx8(x, gamma, beta, eps, groups, w8, bias, w16t, weight, res=None, rowvec=None, fork=False):
     """conv3x3(SiLU(GroupNorm(x))) for a frozen network, e4m3 in between."""
+    _mx8_no_weight_grads(weight, gamma)
     return _NormConvMX8.apply(x, gamma, beta, eps, groups, fork, w8, bias, w16t, weight, res, rowvec)
 
 
 def norm_linear_mx8(x, gamma, beta, eps, w8, bias, w16t, weight, groups=0, silu=False, fork=False):
     """Linear(GroupNorm(x)) (groups > 0) or Linear(LayerNorm(x)) (groups = 0) for a frozen network, e4m3 in between."""
+    _mx8_no_weight_grads(weight, gamma)
     return _NormLinearMX8.apply(x, gamma, beta, eps, groups, silu, fork, w8, bias, w16t, weight)
 
 

@@ -141,7 +141,9 @@ class SiDStep:
     # ---- phase A: fake-score network -----------------------------------------------------------
     def fake_round(self, r):
         """r: dict(z, noise, t, cond, uncond) (fp32 NCHW / int64 / bf16 text states)."""
-        with torch.no_grad():                                                       # :406-411
+        # (fp8_forward: the e4m3 forward copies of a network converted with enable_fp8_weights(frozen_passes_only=True) --
+        # BASELINE.json configs[4]; a no-op otherwise)
+        with torch.no_grad(), self.G.fp8_forward():                                 # :406-411
             images = hip_generate(self.G, r['z'], r['cond'], self._init_t(len(r['z']), r['z'].device), self.sched)
         prep = hip_prepare_denoise(images, r['noise'], r['t'], r['cond'], r.get('uncond'), self.sched, self.k1 != 1,
                                    act_dtype=self.psi.compute_dtype)
@@ -245,7 +247,8 @@ class SiDStep:
             y_real.record_stream(cur)
         if before_fake_eval is not None:
             before_fake_eval()
-        y_fake = hip_denoise(self.psi, prep, k2, predict_x0=True)                   # :496-499
+        with self.psi.fp8_forward():        # psi is frozen here: data gradient only (through its bf16 backward-data operands)
+            y_fake = hip_denoise(self.psi, prep, k2, predict_x0=True)               # :496-499
         if self.side is not None:
             torch.cuda.current_stream().wait_stream(self.side)
         loss = ops.sid_generator_loss(images, y_real, y_fake, self.alpha, self.lsg / self.bgt)   # :508-530

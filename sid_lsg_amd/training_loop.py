@@ -153,10 +153,13 @@ def training_loop(
     # network_kwargs.teacher_weights = 'fp8': the frozen teacher's forward GEMM / conv weights as e4m3 + per-channel scales
     # (BASELINE.json configs[4]; HipUNet2DCondition.enable_fp8_weights).  The networks that train stay bf16.
     tw = dict(network_kwargs).get('teacher_weights', 'bf16')
-    if tw not in ('bf16', 'fp8'):
-        raise ValueError(f"network_kwargs.teacher_weights must be 'bf16' or 'fp8', got {tw!r}")
-    if tw == 'fp8':
+    if tw not in ('bf16', 'fp8', 'fp8-frozen'):
+        raise ValueError(f"network_kwargs.teacher_weights must be 'bf16', 'fp8' or 'fp8-frozen', got {tw!r}")
+    if tw in ('fp8', 'fp8-frozen'):
         dist.print0(f'teacher: {true_score.enable_fp8_weights()} layers with fp8 (e4m3) weights')
+    if tw == 'fp8-frozen':      # + every other pass without weight gradients (fake score in phase B, the generator's no-grad pass)
+        for net in (fake_score, G):
+            net.enable_fp8_weights(frozen_passes_only=True)
     dist.print0('Setting up optimizer...')
     opt_f = construct_class_by_name(params=fake_score.parameters(), **_hip_opt(fake_score_optimizer_kwargs))
     opt_g = construct_class_by_name(params=G.parameters(), **_hip_opt(g_optimizer_kwargs))

@@ -63,7 +63,7 @@ OPTIONS = [
     (('--init_timestep',), dict(type=int, default=625, show_default=True, metavar='INT', help='t_init, in [0,999]')),
     (('--fp16',), dict(type=bool, default=False, show_default=True, metavar='BOOL', help='Reference fp16 recipe (optimizer eps 1e-6)')),
     (('--precision',), dict(type=click.Choice(['bf16', 'fp32']), default='bf16', show_default=True, help='Compute dtype of the HIP path (not a reference option)')),
-    (('--teacher-weights', 'teacher_weights'), dict(type=click.Choice(['bf16', 'fp8']), default='bf16', show_default=True, help='fp8: frozen teacher forward weights as e4m3 + per-channel scales (not a reference option)')),
+    (('--teacher-weights', 'teacher_weights'), dict(type=click.Choice(['bf16', 'fp8', 'fp8-frozen']), default='bf16', show_default=True, help='fp8: frozen teacher forward weights as e4m3 + per-channel scales; fp8-frozen: every pass without weight gradients (not a reference option)')),
     (('--ls',), dict(type=click.FloatRange(min=0, min_open=True), default=1, show_default=True, help='Loss scaling')),
     (('--lsg',), dict(type=click.FloatRange(min=0, min_open=True), default=1, show_default=True, help='Loss scaling G')),
     (('--alpha',), dict(type=click.FloatRange(min=-1000, min_open=True), default=1, show_default=True, help='L2-alpha*L1')),

@@ -358,3 +358,64 @@ def test_step_with_fp8_teacher(dev):
     agree = float((torch.sign(a['dG']) == torch.sign(f['dG'])).float().mean())
     print(f'generator loss deviation {rel_g:.3e}; update-sign agreement of G {agree:.4f}')
     assert rel_g < 0.2 and agree > 0.85
+
+
+def test_fp8_copies_of_a_trainable_network_serve_its_frozen_passes(dev):
+    """enable_fp8_weights(frozen_passes_only=True) on a network that trains: (a) outside `fp8_forward()` nothing changes -- forward and
+    all gradients are bit-equal to a network without e4m3 copies; (b) inside, the forward is bit-equal to a frozen clone whose e4m3
+    weights are always active (the teacher's mode) and the input gradient still flows through the bf16 backward-data operands;
+    (c) after an optimizer step the e4m3 copies follow the new weights (re-quantised by refresh_compute_weights)."""
+    from sid_lsg_amd.optim import FusedAdamEMA
+    from sid_lsg_amd.unet import CONFIGS, HipUNet2DCondition
+    cfg = CONFIGS['tiny40']
+    net = HipUNet2DCondition(cfg).materialize(dev, seed=3).requires_grad_(True)
+    plain = net.clone_network().requires_grad_(True)
+    assert net.enable_fp8_weights(frozen_passes_only=True) > 20
+    g = torch.Generator().manual_seed(0)
+    B, lat = 2, 16
+    x = torch.zeros(B, lat, lat, 8)
+    x[..., :4] = torch.randn(B, lat, lat, 4, generator=g)
+    x = x.to(dev).to(BF16)
+    t = torch.tensor([625, 37], device=dev)
+    ctx = torch.randn(B, cfg.text_len, cfg.cross_attention_dim, generator=g).to(dev).to(BF16)
+    dy = torch.randn(B, lat * lat, 8, generator=g).to(dev)
+    # (a) training pass: untouched
+    xa, xb = x.clone().requires_grad_(), x.clone().requires_grad_()
+    ya, yb = net.forward_nhwc(xa, t, ctx), plain.forward_nhwc(xb, t, ctx)
+    ya.backward(dy)
+    yb.backward(dy)
+    assert torch.equal(ya, yb) and torch.equal(xa.grad, xb.grad)
+    assert float((net.flat_grads - plain.flat_grads).abs().max()) <= 1e-5 * float(plain.flat_grads.abs().max())     # fp32 atomics order
+    # (b) frozen pass through the e4m3 copies == an always-active frozen clone
+    frozen = net.clone_network(with_grad_buffers=False).requires_grad_(False)
+    frozen.enable_fp8_weights()
+    net.requires_grad_(False)
+    xc, xd = x.clone().requires_grad_(), x.clone().requires_grad_()
+    with net.fp8_forward():
+        yc = net.forward_nhwc(xc, t, ctx)
+    yd = frozen.forward_nhwc(xd, t, ctx)
+    yc.backward(dy)
+    yd.backward(dy)
+    assert torch.equal(yc, yd) and torch.equal(xc.grad, xd.grad)
+    assert not torch.equal(yc, ya), 'the e4m3 forward must differ from the bf16 one'
+    assert float((yc - ya).norm() / ya.norm()) < 0.2
+    # a forward that wants weight gradients through the e4m3 copies is refused
+    net.requires_grad_(True)
+    with pytest.raises(RuntimeError, match='without weight gradients'):
+        with net.fp8_forward():
+            net.forward_nhwc(x, t, ctx)
+    with torch.no_grad(), net.fp8_forward():          # ... but fine under no_grad (the generator's pass of phase A)
+        assert torch.equal(net.forward_nhwc(x, t, ctx), yc)
+    # (c) an optimizer step moves the weights; the e4m3 copies follow
+    opt = FusedAdamEMA(net.parameters(), lr=1e-3)
+    opt.attach(w16=net.flat_w16, owner=net)
+    net.flat_grads.copy_(torch.randn(net.flat_grads.shape, generator=torch.Generator().manual_seed(1)).to(dev))
+    opt.step()
+    net.refresh_compute_weights(cast=False)
+    frozen2 = net.clone_network(with_grad_buffers=False).requires_grad_(False)
+    frozen2.enable_fp8_weights()
+    with torch.no_grad(), net.fp8_forward():
+        ye = net.forward_nhwc(x, t, ctx)
+    with torch.no_grad():
+        yf = frozen2.forward_nhwc(x, t, ctx)
+    assert torch.equal(ye, yf) and not torch.equal(ye, yc)

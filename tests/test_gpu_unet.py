@@ -233,6 +233,7 @@ def test_sid_iteration_full_size_batch2(dev):
 # teacher: its error is the e4m3 quantisation noise of ~170 contractions (3 mantissa bits, per-output-channel weight scales,
 # unit-scale activations) propagated through the teacher and amplified by the guidance like the bf16 noise is.
 TOL_LOSS_FP8_TEACHER = (2e-3, 2e-2)      # observed on MI355X: 1.3e-4 / 3.7e-3
+TOL_LOSS_FP8_FROZEN = (5e-3, 5e-2)       # + e4m3 generator (phase A) and fake-score evaluation (phase B)
 
 
 def test_sid_iteration_full_size_config5_fp8_teacher(dev):
@@ -245,7 +246,20 @@ def test_sid_iteration_full_size_config5_fp8_teacher(dev):
         torch.set_num_threads(min(8, os.cpu_count() or 8))
 
 
-def _iteration_parity(dev, cfg_name, lat, b, rounds, lr, kappa, alpha, iters, ema_names, modes=(BF16,), teacher_fp8=False, teacher_forced=False):
+def test_sid_iteration_full_size_config5_fp8_all_frozen_passes(dev):
+    """configs[4] with e4m3 forward weights on EVERY pass that needs no weight gradients (`--teacher-weights fp8-frozen`): the teacher,
+    the fake-score network's phase-B evaluation and the generator's no-grad pass of phase A; the passes that train (fake-score step,
+    generator step) and every backward stay bf16.  Full-size SD2.1-base, kappa 1.5, one iteration vs the fp32 oracle; the fake-score
+    loss now sees the e4m3 generator (x_hat) and the generator loss two e4m3 CFG networks."""
+    try:
+        _iteration_parity(dev, 'sd21-base', lat=64, b=1, rounds=1, lr=1e-6, kappa=1.5, alpha=1.0, iters=1,
+                          ema_names=('conv_in.weight', 'conv_out.bias'), modes=(BF16,), teacher_fp8=True, frozen_fp8=True)
+    finally:
+        torch.set_num_threads(min(8, os.cpu_count() or 8))
+
+
+def _iteration_parity(dev, cfg_name, lat, b, rounds, lr, kappa, alpha, iters, ema_names, modes=(BF16,), teacher_fp8=False, teacher_forced=False,
+                      frozen_fp8=False):
     from oracle import fixtures, sid_ref
     from oracle.scheduler_ref import DDPMSchedulerRef
     from oracle.unet_ref import CONFIGS as RC
@@ -270,6 +284,8 @@ def _iteration_parity(dev, cfg_name, lat, b, rounds, lr, kappa, alpha, iters, em
             n8 = phi.requires_grad_(False).enable_fp8_weights()
             print(f'teacher: {n8} layers with e4m3 weights')
             assert n8 > 100
+        if frozen_fp8:
+            assert psi.enable_fp8_weights(frozen_passes_only=True) > 100 and G.enable_fp8_weights(frozen_passes_only=True) > 100
         opt_f = FusedAdamEMA(psi.parameters(), lr=lr, betas=(0.0, 0.999), eps=1e-8)
         opt_g = FusedAdamEMA(G.parameters(), lr=lr, betas=(0.0, 0.999), eps=1e-8)
         step = SiDStep(G, psi, phi, G_ema, DDPMScheduler().to(dev), opt_f, opt_g, alpha=alpha, cfg_train_fake=kappa,
@@ -305,7 +321,7 @@ def _iteration_parity(dev, cfg_name, lat, b, rounds, lr, kappa, alpha, iters, em
             rg = abs(float(lg) - out_r['loss_G']) / abs(out_r['loss_G'])
             print(f'{cfg_name} kappa {kappa} iter {it} [{cd}]: loss_fake {float(lf):.5f} vs {out_r["loss_fake"]:.5f} (rel {rf:.1e}); '
                   f'loss_G {float(lg):.5f} vs {out_r["loss_G"]:.5f} (rel {rg:.1e})')
-            tol = TOL_LOSS_FP8_TEACHER if teacher_fp8 else TOL_LOSS[cd]
+            tol = TOL_LOSS_FP8_FROZEN if frozen_fp8 else TOL_LOSS_FP8_TEACHER if teacher_fp8 else TOL_LOSS[cd]
             gs = abs(float(lg) - out_r['loss_G']) / abs(out_r['loss_fake'])      # generator loss error in units of the loss scale
             curve.setdefault(cd, []).append((rf, gs))
             assert rf <= tol[0], f'fake-score loss [{cd}]: rel {rf:.3g}'
@@ -332,7 +348,7 @@ def _iteration_parity(dev, cfg_name, lat, b, rounds, lr, kappa, alpha, iters, em
             print(f'{name} [{cd}]: update-sign agreement {frac:.4f} over {total} weights')
             # bf16 at kappa = 4.5: the guidance multiplies the bf16 difference of the two CFG branches (observed 0.969 / 0.978)
             # e4m3 teacher: G's gradient comes through the quantised teacher (bound set from the observed agreement)
-            assert frac > (0.96 if (teacher_fp8 and name == 'G') else 0.96 if (cd == BF16 and kappa > 2) else TOL_SIGN[cd])
+            assert frac > (0.93 if frozen_fp8 else 0.96 if (teacher_fp8 and name == 'G') else 0.96 if (cd == BF16 and kappa > 2) else TOL_SIGN[cd])
         ema_r = dict(Gema_r.named_parameters())
         for n, p in hip[cd]['G_ema'].named_parameters():
             if n in ema_names:
