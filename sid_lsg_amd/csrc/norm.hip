@@ -16,6 +16,7 @@
 //   colsum_reduce: dgamma/dbeta (+=) from the per-channel partials
 #include "common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 constexpr int GN_MAX_C = 2560;
 #ifndef SIDLSG_GN_U
@@ -487,6 +488,220 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ x, co
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// ONE-PASS GroupNorm for the 32x32 / 16x16 / 8x8 stages (bf16): a block owns the channels of a few WHOLE groups of one sample
+// (GPB groups = CW channels, CW % 8 == 0), loads its [HW][CW] slab ONCE into registers, reduces the group statistics inside the
+// block (deterministic: per-thread partials -> LDS -> fixed-order sums) and normalises from the registers: x is read once, there is
+// one launch instead of gn_stats + gn_apply, and no statistics workspace.  Fits when the slab is small enough for registers
+// (P = ceil(HW / pixel rows in flight) 16-byte chunks per thread): 43 of the 61 GroupNorms of the SD UNet (every shape at <= 32x32
+// except the 960- / 1920-channel concats at 32x32); the 64x64 shapes (1.3 MB per group range) keep the two-kernel path.
+// Channel ranges of neighbouring blocks share cache lines (80-byte runs at a 1280-byte pitch): the block order keeps a sample's
+// ranges on one XCD (blocks are numbered XCD-contiguously), so the shared lines meet in that XCD's L2.
+struct GnSmall {
+    int B, HW, C, G, cpg, GPB, CW8, rows, ngr;     // ngr = G / GPB channel ranges per sample
+};
+
+DEVFN int gn_small_block(const GnSmall& g, int& b, int& gr) {     // XCD-contiguous logical order: consecutive ids = (sample, range) row-major
+    int bid = blockIdx.x;
+    const int nblk = g.B * g.ngr;
+    const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    b = bid / g.ngr; gr = bid - b * g.ngr;
+    return bid;
+}
+
+// deterministic block reduction of per-thread per-channel pairs: sm[(rl * CW + ch) * 2 + {0,1}] -> out pairs per channel in
+// sm[ch * 2 + ..] of row 0 (every (channel, stat) summed over the pixel rows by ONE thread, 4 independent chains)
+DEVFN void gn_small_fold_rows(float* sm, int CW, int rows) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < CW * 2; i += blockDim.x) {
+        float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
+        int r = 0;
+        for (; r + 3 < rows; r += 4) {
+            t0 += sm[(size_t)r * CW * 2 + i]; t1 += sm[(size_t)(r + 1) * CW * 2 + i];
+            t2 += sm[(size_t)(r + 2) * CW * 2 + i]; t3 += sm[(size_t)(r + 3) * CW * 2 + i];
+        }
+        for (; r < rows; r++) t0 += sm[(size_t)r * CW * 2 + i];
+        sm[i] = (t0 + t1) + (t2 + t3);       // row 0 is only read by its own (channel, stat) thread above
+    }
+    __syncthreads();
+}
+
+template <int P, bool F8>
+__global__ __launch_bounds__(512) void gn_small_fwd_kernel(const bf16* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           bf16* __restrict__ y, float* __restrict__ stats, GnSmall g, float eps, int act,
+                                                           const float* __restrict__ gamma1, const float* __restrict__ beta1, int split) {
+    extern __shared__ float sm[];      // [rows][CW][2] partials, then [2 * GPB] mean / rstd behind them
+    int b, gr;
+    gn_small_block(g, b, gr);
+    if (gamma1 && b >= split) { gamma = gamma1; beta = beta1; }
+    const int CW = g.CW8 * 8;
+    const int cc = threadIdx.x % g.CW8, rl = threadIdx.x / g.CW8;
+    const bool live = rl < g.rows;
+    const int c0 = gr * CW + cc * 8;                 // first of this thread's 8 channels
+    const bf16* xb = x + (size_t)b * g.HW * g.C + c0;
+    bf16x8 v[P];
+    float s[8], q[8];
+#pragma unroll
+    for (int e = 0; e < 8; e++) s[e] = q[e] = 0.f;
+#pragma unroll
+    for (int i = 0; i < P; i++) {
+        const int p = rl + i * g.rows;
+        v[i] = (live && p < g.HW) ? ld8(xb + (size_t)p * g.C) : zero8();
+    }
+#pragma unroll
+    for (int i = 0; i < P; i++)
+#pragma unroll
+        for (int e = 0; e < 8; e++) { const float f = bf2f(v[i][e]); s[e] += f; q[e] += f * f; }
+    if (live) {
+        float* row = sm + ((size_t)rl * CW + cc * 8) * 2;
+#pragma unroll
+        for (int e = 0; e < 8; e++) { row[e * 2] = s[e]; row[e * 2 + 1] = q[e]; }
+    }
+    gn_small_fold_rows(sm, CW, g.rows);
+    float* mr = sm + (size_t)g.rows * CW * 2;        // mean[GPB], rstd[GPB]
+    if ((int)threadIdx.x < g.GPB) {
+        float a = 0.f, c = 0.f;
+        for (int ch = threadIdx.x * g.cpg; ch < ((int)threadIdx.x + 1) * g.cpg; ch++) { a += sm[ch * 2]; c += sm[ch * 2 + 1]; }
+        const float n = (float)g.cpg * (float)g.HW;
+        const float mean = a / n;
+        const float rstd = rsqrtf(fmaxf(c / n - mean * mean, 0.f) + eps);
+        mr[threadIdx.x] = mean; mr[g.GPB + threadIdx.x] = rstd;
+        if (stats) { float* o = stats + ((size_t)b * g.G + gr * g.GPB + threadIdx.x) * 2; o[0] = mean; o[1] = rstd; }
+    }
+    __syncthreads();
+    if (!live) return;
+    float sc[8], sh[8];
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+        const int lg = (cc * 8 + e) / g.cpg;
+        sc[e] = mr[g.GPB + lg] * gamma[c0 + e];
+        sh[e] = beta[c0 + e] - mr[lg] * sc[e];
+    }
+    const size_t base = (size_t)b * g.HW * g.C + c0;
+#pragma unroll
+    for (int i = 0; i < P; i++) {
+        const int p = rl + i * g.rows;
+        if (p >= g.HW) break;
+        float o[8];
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            float f = bf2f(v[i][e]) * sc[e] + sh[e];
+            if (act) f = silu_t<bf16>(f);
+            o[e] = f;
+        }
+        st8_out<bf16, F8>(y, base + (size_t)p * g.C, o);
+    }
+}
+
+// backward of the same: x and dy of the block's slab are read once; dx = rstd * (d * gamma - s1 / n - xhat * s2 / n) (+ add);
+// dgamma / dbeta (trainable networks): per-channel block totals added with one fp32 atomic per channel and block.
+template <int P>
+__global__ __launch_bounds__(512) void gn_small_bwd_kernel(const bf16* __restrict__ x, const bf16* __restrict__ dy, const float* __restrict__ stats,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           const bf16* __restrict__ add, bf16* __restrict__ dx, float* __restrict__ dgamma,
+                                                           float* __restrict__ dbeta, GnSmall g, int act,
+                                                           const float* __restrict__ gamma1, const float* __restrict__ beta1, int split) {
+    extern __shared__ float sm[];
+    int b, gr;
+    gn_small_block(g, b, gr);
+    if (gamma1 && b >= split) { gamma = gamma1; beta = beta1; }
+    const int CW = g.CW8 * 8;
+    const int cc = threadIdx.x % g.CW8, rl = threadIdx.x / g.CW8;
+    const bool live = rl < g.rows;
+    const int c0 = gr * CW + cc * 8;
+    const size_t base = (size_t)b * g.HW * g.C + c0;
+    float mu[8], rs[8], ga[8], be[8], a[8], c[8];
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+        const int grp = (c0 + e) / g.cpg;
+        mu[e] = stats[((size_t)b * g.G + grp) * 2]; rs[e] = stats[((size_t)b * g.G + grp) * 2 + 1];
+        ga[e] = gamma[c0 + e]; be[e] = beta[c0 + e]; a[e] = c[e] = 0.f;
+    }
+    bf16x8 xv[P], dv[P];
+#pragma unroll
+    for (int i = 0; i < P; i++) {
+        const int p = rl + i * g.rows;
+        const bool ok = live && p < g.HW;
+        xv[i] = ok ? ld8(x + base + (size_t)p * g.C) : zero8();
+        dv[i] = ok ? ld8(dy + base + (size_t)p * g.C) : zero8();
+    }
+#pragma unroll
+    for (int i = 0; i < P; i++)
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            const float xh = (bf2f(xv[i][e]) - mu[e]) * rs[e];
+            float d = bf2f(dv[i][e]);                                   // rows past HW hold zeros: d = 0
+            if (act) d *= silu_grad_t<bf16>(xh * ga[e] + be[e]);
+            a[e] += d * xh; c[e] += d;
+        }
+    if (live) {
+        float* row = sm + ((size_t)rl * CW + cc * 8) * 2;
+#pragma unroll
+        for (int e = 0; e < 8; e++) { row[e * 2] = a[e]; row[e * 2 + 1] = c[e]; }
+    }
+    gn_small_fold_rows(sm, CW, g.rows);
+    if (dgamma && dbeta) {
+        for (int i = threadIdx.x; i < CW; i += blockDim.x) {
+            unsafeAtomicAdd(dgamma + gr * CW + i, sm[i * 2]);
+            unsafeAtomicAdd(dbeta + gr * CW + i, sm[i * 2 + 1]);
+        }
+    }
+    float* ms = sm + (size_t)g.rows * CW * 2;        // s1 / n [GPB], s2 / n [GPB]
+    if ((int)threadIdx.x < g.GPB) {
+        float s1 = 0.f, s2 = 0.f;
+        for (int ch = threadIdx.x * g.cpg; ch < ((int)threadIdx.x + 1) * g.cpg; ch++) {
+            const float gm = gamma[gr * CW + ch];
+            s2 += gm * sm[ch * 2]; s1 += gm * sm[ch * 2 + 1];
+        }
+        const float n = (float)g.cpg * (float)g.HW;
+        ms[threadIdx.x] = s1 / n; ms[g.GPB + threadIdx.x] = s2 / n;
+    }
+    __syncthreads();
+    if (!live) return;
+    float m1[8], m2[8];
+#pragma unroll
+    for (int e = 0; e < 8; e++) { const int lg = (cc * 8 + e) / g.cpg; m1[e] = ms[lg]; m2[e] = ms[g.GPB + lg]; }
+#pragma unroll
+    for (int i = 0; i < P; i++) {
+        const int p = rl + i * g.rows;
+        if (p >= g.HW) break;
+        float o[8], av[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (add) ldv8<bf16>(add + base + (size_t)p * g.C, av);
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            const float xh = (bf2f(xv[i][e]) - mu[e]) * rs[e];
+            float d = bf2f(dv[i][e]);
+            if (act) d *= silu_grad_t<bf16>(xh * ga[e] + be[e]);
+            o[e] = rs[e] * (d * ga[e] - m1[e] - xh * m2[e]) + av[e];
+        }
+        stv8<bf16>(dx + base + (size_t)p * g.C, o);
+    }
+}
+
+// Geometry of the one-pass kernels for a shape, or false: pmax = the largest per-thread chunk count the caller has a kernel for.
+static bool gn_small_geom(GnSmall& g, int& threads, int& P, int B, int HW, int C, int G, int pmax) {
+    static const bool on = !(getenv("SIDLSG_GN_ONEPASS") && atoi(getenv("SIDLSG_GN_ONEPASS")) == 0);      // A/B switch
+    if (!on || C % 8 || C % G || B <= 0 || HW <= 0) return false;
+    g.B = B; g.HW = HW; g.C = C; g.G = G; g.cpg = C / G;
+    int gpb = 0;
+    for (int t = 1; t <= 8; t *= 2)
+        if (G % t == 0 && (t * g.cpg) % 8 == 0) { gpb = t; break; }
+    if (!gpb) return false;
+    g.GPB = gpb; g.CW8 = gpb * g.cpg / 8; g.ngr = G / gpb;
+    if (g.CW8 > 256) return false;
+    for (int th = 256; th <= 512; th *= 2) {
+        int rows = th / g.CW8; if (rows > HW) rows = HW; if (rows < 1) continue;
+        const int p = (HW + rows - 1) / rows;
+        if (p <= pmax) {
+            g.rows = rows; threads = (g.CW8 * rows + 63) / 64 * 64; P = p;
+            return ((size_t)rows * g.CW8 * 8 * 2 + 2 * gpb) * sizeof(float) <= 60000;
+        }
+    }
+    return false;
+}
+
 static int gn_geom(GnGeom& g, int B, int HW, int C, int G) {
     if (C % 8 || C % G || C > GN_MAX_C || B <= 0 || HW <= 0) return SIDLSG_EINVAL;
     g.C = C; g.HW = HW; g.G = G; g.cpg = C / G; g.C8 = C / 8;
@@ -529,6 +744,16 @@ static int groupnorm_fwd_t(const void* x, const float* gamma, const float* beta,
     const double tb_ = (double)B * HW * C * (sizeof(T) + (F8 ? 1 : sizeof(T)));
     SidlsgTraceScope ts(SIDLSG_FAM_GN_FWD, tb_, tb_);      // algorithmic bytes: read x, write y
     hipStream_t s = (hipStream_t)stream;
+    if constexpr (std::is_same<T, bf16>::value) {
+        GnSmall gs; int th, P;
+        if (gn_small_geom(gs, th, P, B, HW, C, G, 24)) {       // one-pass kernel (small spatial sizes): x read once, one launch
+            const size_t lds = ((size_t)gs.rows * gs.CW8 * 8 * 2 + 2 * gs.GPB) * sizeof(float);
+#define GN_SF(PP) SIDLSG_LAUNCH((gn_small_fwd_kernel<PP, F8>), dim3(B * gs.ngr), dim3(th), lds, s, (const bf16*)x, gamma, beta, (bf16*)y, stats, gs, eps, silu, gamma1, beta1, B / 2)
+            if (P <= 2) GN_SF(2); else if (P <= 4) GN_SF(4); else if (P <= 8) GN_SF(8); else if (P <= 12) GN_SF(12); else if (P <= 16) GN_SF(16); else GN_SF(24);
+#undef GN_SF
+            return sidlsg_last_error();
+        }
+    }
     const int threads = g.C8 * g.rows;
     SIDLSG_LAUNCH(gn_stats_kernel<T>, dim3(g.nch, B), dim3(threads), (size_t)g.rows * C * 2 * sizeof(float), s,
                        (const T*)x, ws, g);
@@ -547,6 +772,16 @@ static int groupnorm_bwd_t(const void* x, const void* dy, const float* stats, co
     const double tb_ = (double)B * HW * C * sizeof(T) * (dres ? 4 : 3);
     SidlsgTraceScope ts(SIDLSG_FAM_GN_BWD, tb_, tb_);                // read x, dy (, dres), write dx
     hipStream_t s = (hipStream_t)stream;
+    if constexpr (std::is_same<T, bf16>::value) {
+        GnSmall gs; int th, P;
+        if (gn_small_geom(gs, th, P, B, HW, C, G, 12)) {       // one-pass kernel: x and dy read once, one launch (+ atomics for dgamma / dbeta)
+            const size_t lds = ((size_t)gs.rows * gs.CW8 * 8 * 2 + 2 * gs.GPB) * sizeof(float);
+#define GN_SB(PP) SIDLSG_LAUNCH((gn_small_bwd_kernel<PP>), dim3(B * gs.ngr), dim3(th), lds, s, (const bf16*)x, (const bf16*)dy, stats, gamma, beta, (const bf16*)dres, (bf16*)dx, dgamma, dbeta, gs, silu, gamma1, beta1, B / 2)
+            if (P <= 2) GN_SB(2); else if (P <= 4) GN_SB(4); else if (P <= 8) GN_SB(8); else GN_SB(12);
+#undef GN_SB
+            return sidlsg_last_error();
+        }
+    }
     const int threads = g.C8 * g.rows;
     SIDLSG_LAUNCH(gn_bwd_stats_kernel<T>, dim3(g.nch, B), dim3(threads), (size_t)g.rows * C * 2 * sizeof(float), s,
                        (const T*)x, (const T*)dy, stats, gamma, beta, ws, g, silu, gamma1, beta1, B / 2);

@@ -171,8 +171,12 @@ def test_linear_autograd(dev):
     close(bm.grad, br.grad, 2e-3, 'db')
 
 
+# (the shapes at <= 32x32 take the one-pass kernels -- gn_small_fwd / gn_small_bwd: whole groups per block, slab in registers --
+# with 1 / 2 / 4 groups per block, 256 and 512 threads, ragged pixel counts; 64x64 and the wide 32x32 concats the two-kernel path)
 @pytest.mark.parametrize('B,HW,C,G,silu', [(2, 64, 32, 8, 1), (3, 1024, 320, 32, 1), (2, 256, 1920, 32, 1), (2, 4096, 320, 32, 0),
-                                           (1, 64, 2560, 32, 1), (2, 100, 80, 8, 0)])
+                                           (1, 64, 2560, 32, 1), (2, 100, 80, 8, 0), (16, 64, 1280, 32, 1), (4, 256, 1280, 32, 0),
+                                           (3, 1024, 640, 32, 1), (2, 1024, 1280, 32, 1), (2, 256, 640, 32, 1), (2, 256, 2560, 32, 1),
+                                           (2, 1024, 960, 32, 1), (1, 1, 64, 8, 1), (2, 7, 320, 32, 0), (5, 333, 640, 32, 1)])
 def test_groupnorm(dev, B, HW, C, G, silu):
     from sid_lsg_amd import ops
     x = (rnd(B, HW, C, seed=1).float() * 1.5 + 0.3).to(BF16)
