@@ -564,18 +564,21 @@ def main():
                                                 'region with the same stream concurrency: includes the two barrier packets and the dispatch gap'}
             return o
         objs = {k: roof(k) for k in timers}
-        # HBM-side bytes per launch: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, gfx950-corrected) of the SAME
-        # entry point on the SAME layer shapes, collected with the kernel micro-benchmark (tools/bench_kernels.py, batch 16) -- not
-        # inside this timed step (PMC passes serialise kernels); the committed summaries say so themselves
-        for key, names, field in (('conv', ('r03_conv_pmc.json', 'r02_conv_pmc.json'), 'avg_hbm_side_bytes_per_launch'),
-                                  ('gn', ('r03_gn_pmc.json', 'r02_gn_pmc.json'), 'avg_hbm_side_bytes_fwd_per_launch'),
-                                  ('gemm', ('r03_gemm_pmc.json',), 'avg_hbm_side_bytes_per_launch')):
-            for name in names:
-                pmc = os.path.join(ROOT, 'profiles', name)
-                if os.path.isfile(pmc):
-                    objs[key]['traffic'] = json.load(open(pmc)).get(field)
-                    objs[key]['traffic_source'] = f'profiles/{name} (micro-benchmark of the step\'s shapes, batch 16)'
-                    break
+        # HBM-side bytes per call: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, gfx950-corrected) of the SAME entry point
+        # on the SAME layer shapes, collected with the kernel micro-benchmark (tools/collect_traffic.sh -> tools/bench_kernels.py, batch
+        # 16: kernels alone) -- not inside this timed step (PMC passes serialise kernels); the committed summaries say so themselves
+        TRAFFIC = {'gemm': ('gemm', 'gemm'), 'conv': ('conv', 'conv'), 'wgrad': ('wgrad', 'wgrad'), 'conv_wgrad': ('wgrad', 'conv_wgrad'),
+                   'attn': ('attn', 'attn'), 'attn_bwd': ('attn', 'attn_bwd'), 'gn': ('norm', 'gn'), 'gn_bwd': ('norm', 'gn_bwd'),
+                   'ln': ('norm', 'ln'), 'ln_bwd': ('norm', 'ln_bwd')}
+        for key, (mode, fam) in TRAFFIC.items():
+            pmc = os.path.join(ROOT, 'profiles', f'r04_traffic_{mode}.json')
+            if key in objs and os.path.isfile(pmc):
+                ent = json.load(open(pmc)).get('families', {}).get(fam)
+                if ent and ent.get('calls'):
+                    objs[key]['traffic'] = ent['avg_hbm_side_bytes_per_call']
+                    objs[key]['traffic_over_algorithmic'] = ent.get('traffic_over_algorithmic')      # both of the micro-benchmark's calls
+                    objs[key]['traffic_source'] = (f'profiles/r04_traffic_{mode}.json: HBM-side bytes per call, micro-benchmark of the step\'s shapes at '
+                                                   'batch 16 (compare with the same benchmark\'s algorithmic bytes, not with this step\'s mix)')
         # `roofline` = the family that takes the largest share of the step (dense GEMM since round 2's conv work; the MFMA
         # families are compared by est_ms_per_step); every family keeps its own object
         mfma = ['conv', 'gemm', 'attn_bwd', 'attn', 'wgrad', 'conv_wgrad']

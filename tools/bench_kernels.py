@@ -131,7 +131,7 @@ def bench_norm(B):
     """Raw C-ABI calls on preallocated buffers (kernel time, not Python/autograd overhead)."""
     print('--- GroupNorm+SiLU / LayerNorm: us and GB/s of algorithmic bytes (fwd: x,y; bwd: x,dy,dx; bf16)')
     F32 = torch.float32
-    for HW, C in ((4096, 320), (4096, 640), (1024, 640), (1024, 1920), (256, 1280), (64, 2560)):
+    for HW, C in ((4096, 320), (4096, 640), (1024, 640), (1024, 1280), (1024, 1920), (256, 1280), (256, 2560), (64, 1280), (64, 2560)):
         x, dy = r(B, HW, C), r(B, HW, C)
         y, dx = torch.empty_like(x), torch.empty_like(x)
         g, b = torch.ones(C, device=dev), torch.zeros(C, device=dev)
@@ -169,12 +169,30 @@ def bench_geglu(B):
 
 
 if __name__ == '__main__':
-    args = [a for a in sys.argv[1:] if not a.startswith('--')]
+    args = [a for a in sys.argv[1:] if not a.startswith('--') and not a.endswith('.json')]
     B = 16
     if '--batch' in sys.argv:
         B = int(sys.argv[sys.argv.index('--batch') + 1])
         args = [a for a in args if a != str(B)]
     which = args or ['conv', 'gemm', 'wgrad', 'attn', 'norm']
     lib.load()
+    trace_json = sys.argv[sys.argv.index('--trace-json') + 1] if '--trace-json' in sys.argv else None
+    if trace_json:       # the library's own per-dispatch timing + ALGORITHMIC bytes of exactly these launches (include/sidlsg_hip.h)
+        lib.sidlsg_trace_enable(1 << 16)
     for w in which:
-        globals()['bench_' + w](B)
+        if not w.endswith('.json'):
+            globals()['bench_' + w](B)
+    if trace_json:
+        import json
+        torch.cuda.synchronize()
+        FAM = dict(gemm=0, conv=1, attn=2, attn_bwd=3, wgrad=4, conv_wgrad=5, gn=6, gn_bwd=7, ln=8, ln_bwd=9)
+        buf = torch.zeros(9, dtype=torch.float64)
+        out = {}
+        for k, f in FAM.items():
+            lib.sidlsg_trace_read(f, buf.data_ptr())
+            ms, work, sampled, calls, kernels, nbytes, bound = buf.tolist()[:7]
+            if sampled:
+                out[k] = dict(calls=int(sampled), algorithmic_bytes_per_call=nbytes / sampled, work_per_call=work / sampled, ms_per_call=ms / sampled)
+        lib.sidlsg_trace_enable(0)
+        json.dump(out, open(trace_json, 'w'), indent=1)
+        print('trace:', {k: (v['calls'], round(v['algorithmic_bytes_per_call'] / 1e6, 1), round(v['ms_per_call'] * 1e3, 1)) for k, v in out.items()})
