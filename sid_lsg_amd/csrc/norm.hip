@@ -494,8 +494,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ x, co
 // (GPB groups = CW channels, CW % 8 == 0), loads its [HW][CW] slab ONCE into registers, reduces the group statistics inside the
 // block (deterministic: per-thread partials -> LDS -> fixed-order sums) and normalises from the registers: x is read once, there is
 // one launch instead of gn_stats + gn_apply, and no statistics workspace.  Fits when the slab is small enough for registers
-// (P = ceil(HW / pixel rows in flight) 16-byte chunks per thread): 43 of the 61 GroupNorms of the SD UNet (every shape at <= 32x32
-// except the 960- / 1920-channel concats at 32x32); the 64x64 shapes (1.3 MB per group range) keep the two-kernel path.
+// (P = ceil(HW / pixel rows in flight) 16-byte chunks per thread) AND measured faster: the 16x16 and 8x8 stages (30 of the 61
+// GroupNorms of the SD UNet forward, the 8x8 stage and the 1280-channel 16x16 layers backward); 32x32 fits but is slower (the slab
+// costs occupancy), 64x64 (1.3 MB per group range) does not fit: both keep the two-kernel path.
 // Channel ranges of neighbouring blocks share cache lines (80-byte runs at a 1280-byte pitch): the block order keeps a sample's
 // ranges on one XCD (blocks are numbered XCD-contiguously), so the shared lines meet in that XCD's L2.
 struct GnSmall {
@@ -746,10 +747,13 @@ static int groupnorm_fwd_t(const void* x, const float* gamma, const float* beta,
     hipStream_t s = (hipStream_t)stream;
     if constexpr (std::is_same<T, bf16>::value) {
         GnSmall gs; int th, P;
-        if (gn_small_geom(gs, th, P, B, HW, C, G, 24)) {       // one-pass kernel (small spatial sizes): x read once, one launch
+        // one-pass kernel where it measured faster than stats + apply (tools/bench_kernels.py norm, SIDLSG_GN_ONEPASS=0/1, B = 8 / 16 / 32):
+        // <= 12 chunks per thread = the 16x16 and 8x8 stages (13.6 -> 9.7 us, 22.1 -> 13.4 us at B = 16); at 32x32 (21 chunks) the register
+        // slab costs occupancy and the two streaming kernels win (19.9 vs 24.2 us)
+        if (gn_small_geom(gs, th, P, B, HW, C, G, 12)) {
             const size_t lds = ((size_t)gs.rows * gs.CW8 * 8 * 2 + 2 * gs.GPB) * sizeof(float);
 #define GN_SF(PP) SIDLSG_LAUNCH((gn_small_fwd_kernel<PP, F8>), dim3(B * gs.ngr), dim3(th), lds, s, (const bf16*)x, gamma, beta, (bf16*)y, stats, gs, eps, silu, gamma1, beta1, B / 2)
-            if (P <= 2) GN_SF(2); else if (P <= 4) GN_SF(4); else if (P <= 8) GN_SF(8); else if (P <= 12) GN_SF(12); else if (P <= 16) GN_SF(16); else GN_SF(24);
+            if (P <= 2) GN_SF(2); else if (P <= 4) GN_SF(4); else if (P <= 8) GN_SF(8); else GN_SF(12);
 #undef GN_SF
             return sidlsg_last_error();
         }
@@ -774,10 +778,12 @@ static int groupnorm_bwd_t(const void* x, const void* dy, const float* stats, co
     hipStream_t s = (hipStream_t)stream;
     if constexpr (std::is_same<T, bf16>::value) {
         GnSmall gs; int th, P;
-        if (gn_small_geom(gs, th, P, B, HW, C, G, 12)) {       // one-pass kernel: x and dy read once, one launch (+ atomics for dgamma / dbeta)
+        // one-pass kernel: x and dy read once, one launch (+ atomics for dgamma / dbeta); <= 8 chunks of x AND dy per thread (256 VGPRs
+        // without spills): 8x8 stage 22.7 -> 9.0 us, 16x16 at 1280 channels 32.0 -> 15.6 us; beyond that the two-kernel path is faster
+        if (gn_small_geom(gs, th, P, B, HW, C, G, 8)) {
             const size_t lds = ((size_t)gs.rows * gs.CW8 * 8 * 2 + 2 * gs.GPB) * sizeof(float);
 #define GN_SB(PP) SIDLSG_LAUNCH((gn_small_bwd_kernel<PP>), dim3(B * gs.ngr), dim3(th), lds, s, (const bf16*)x, (const bf16*)dy, stats, gamma, beta, (const bf16*)dres, (bf16*)dx, dgamma, dbeta, gs, silu, gamma1, beta1, B / 2)
-            if (P <= 2) GN_SB(2); else if (P <= 4) GN_SB(4); else if (P <= 8) GN_SB(8); else GN_SB(12);
+            if (P <= 2) GN_SB(2); else if (P <= 4) GN_SB(4); else GN_SB(8);
 #undef GN_SB
             return sidlsg_last_error();
         }

@@ -236,30 +236,22 @@ TOL_LOSS_FP8_TEACHER = (2e-3, 2e-2)      # observed on MI355X: 1.3e-4 / 3.7e-3
 TOL_LOSS_FP8_FROZEN = (5e-3, 5e-2)       # + e4m3 generator (phase A) and fake-score evaluation (phase B)
 
 
-def test_sid_iteration_full_size_config5_fp8_teacher(dev):
-    """configs[4] at full size: SD2.1-base (865.9 M parameters), kappa = 1.5, batch 1, 64x64x4 latents, e4m3 teacher: one complete
-    iteration (fake-score step, generator step through the e4m3 teacher's data-gradient backward, Adam, EMA) vs the fp32 oracle."""
+def test_sid_iteration_full_size_config5_fp8(dev):
+    """configs[4] at full size: SD2.1-base (865.9 M parameters), kappa = 1.5, batch 1, 64x64x4 latents, one complete iteration (fake-score
+    step, generator step through the e4m3 networks' data-gradient backward, Adam, EMA) vs the fp32 ORACLE (one oracle run, two HIP
+    variants): `fp8-teacher` = e4m3 teacher (`--teacher-weights fp8`); `fp8-frozen` = e4m3 forward weights on EVERY pass without weight
+    gradients (`--teacher-weights fp8-frozen`): + the fake-score network's phase-B evaluation and the generator's no-grad pass of
+    phase A -- the fake-score loss then sees the e4m3 generator (x_hat), the generator loss two e4m3 CFG networks; the passes that
+    train and every backward stay bf16."""
     try:
         _iteration_parity(dev, 'sd21-base', lat=64, b=1, rounds=1, lr=1e-6, kappa=1.5, alpha=1.0, iters=1,
-                          ema_names=('conv_in.weight', 'conv_out.bias'), modes=(BF16,), teacher_fp8=True)
+                          ema_names=('conv_in.weight', 'conv_out.bias'), modes=((BF16, 'fp8-teacher'), (BF16, 'fp8-frozen')))
     finally:
         torch.set_num_threads(min(8, os.cpu_count() or 8))
 
 
-def test_sid_iteration_full_size_config5_fp8_all_frozen_passes(dev):
-    """configs[4] with e4m3 forward weights on EVERY pass that needs no weight gradients (`--teacher-weights fp8-frozen`): the teacher,
-    the fake-score network's phase-B evaluation and the generator's no-grad pass of phase A; the passes that train (fake-score step,
-    generator step) and every backward stay bf16.  Full-size SD2.1-base, kappa 1.5, one iteration vs the fp32 oracle; the fake-score
-    loss now sees the e4m3 generator (x_hat) and the generator loss two e4m3 CFG networks."""
-    try:
-        _iteration_parity(dev, 'sd21-base', lat=64, b=1, rounds=1, lr=1e-6, kappa=1.5, alpha=1.0, iters=1,
-                          ema_names=('conv_in.weight', 'conv_out.bias'), modes=(BF16,), teacher_fp8=True, frozen_fp8=True)
-    finally:
-        torch.set_num_threads(min(8, os.cpu_count() or 8))
-
-
-def _iteration_parity(dev, cfg_name, lat, b, rounds, lr, kappa, alpha, iters, ema_names, modes=(BF16,), teacher_fp8=False, teacher_forced=False,
-                      frozen_fp8=False):
+def _iteration_parity(dev, cfg_name, lat, b, rounds, lr, kappa, alpha, iters, ema_names, modes=(BF16,), teacher_forced=False):
+    """modes: compute dtypes, or (dtype, variant) pairs with variant in {'fp8-teacher', 'fp8-frozen'} -- all run against ONE oracle iteration."""
     from oracle import fixtures, sid_ref
     from oracle.scheduler_ref import DDPMSchedulerRef
     from oracle.unet_ref import CONFIGS as RC
@@ -276,7 +268,11 @@ def _iteration_parity(dev, cfg_name, lat, b, rounds, lr, kappa, alpha, iters, em
     Gema_r = copy.deepcopy(G_r)
     nets_r = dict(true_score=phi_r, fake_score=psi_r, G=G_r, G_ema=Gema_r)
     hip = {}
-    for cd in modes:
+    modes = tuple(m if isinstance(m, tuple) else (m, '') for m in modes)
+    for mode in modes:
+        cd, variant = mode
+        teacher_fp8, frozen_fp8 = variant in ('fp8-teacher', 'fp8-frozen'), variant == 'fp8-frozen'
+
         def hipnet(r):
             return HipUNet2DCondition(CONFIGS[cfg_name], compute_dtype=cd).materialize(dev, source=r.state_dict())
         phi, psi, G, G_ema = hipnet(phi_r), hipnet(psi_r), hipnet(G_r), hipnet(G_r)
@@ -290,7 +286,7 @@ def _iteration_parity(dev, cfg_name, lat, b, rounds, lr, kappa, alpha, iters, em
         opt_g = FusedAdamEMA(G.parameters(), lr=lr, betas=(0.0, 0.999), eps=1e-8)
         step = SiDStep(G, psi, phi, G_ema, DDPMScheduler().to(dev), opt_f, opt_g, alpha=alpha, cfg_train_fake=kappa,
                        cfg_eval_fake=kappa, cfg_eval_real=kappa, batch_gpu_total=b * rounds, init_timestep=625)
-        hip[cd] = dict(step=step, psi=psi, G=G, G_ema=G_ema)
+        hip[mode] = dict(step=step, psi=psi, G=G, G_ema=G_ema)
     st = dict(fake_score=[{} for _ in psi_r.parameters()], G=[{} for _ in G_r.parameters()])
     hp = dict(alpha=alpha, kappa1=kappa, kappa2=kappa, kappa4=kappa, ls=1.0, lsg=1.0, batch_gpu_total=b * rounds, lr=lr, glr=lr,
               betas=(0.0, 0.999), eps=1e-8, init_t=625, batch_size=b * rounds, ema_halflife_kimg=50, ema_rampup_ratio=0.05)
@@ -307,23 +303,25 @@ def _iteration_parity(dev, cfg_name, lat, b, rounds, lr, kappa, alpha, iters, em
                                        uncond=torch.randn(1, cfg.text_len, cfg.cross_attention_dim, generator=gen).to(BF16).float().expand(b, -1, -1).contiguous()))
         hp['cur_nimg'] = cur_nimg
         if teacher_forced:       # every iteration starts from the ORACLE's current weights: the loss error is the per-step error alone
-            for cd in modes:
+            for mode in modes:
                 for key, net_r in (('psi', psi_r), ('G', G_r)):
-                    hip[cd][key].load_state_dict(net_r.state_dict())
-                    hip[cd][key].refresh_compute_weights()
+                    hip[mode][key].load_state_dict(net_r.state_dict())
+                    hip[mode][key].refresh_compute_weights()
         out_r = sid_ref.sid_iteration_ref(nets_r, st, DDPMSchedulerRef(), inputs, hp)
         beta = sid_ref.ema_beta_ref(b * rounds, cur_nimg, 50, 0.05)
-        for cd in modes:
+        for mode in modes:
+            cd, variant = mode
+            teacher_fp8, frozen_fp8 = variant in ('fp8-teacher', 'fp8-frozen'), variant == 'fp8-frozen'
             dinp = {ph: [{k: (v.to(dev).to(cd).contiguous() if k in ('cond', 'uncond') else v.to(dev)) for k, v in r.items()}
                          for r in inputs[ph]] for ph in inputs}
-            lf, lg = hip[cd]['step'].iteration(dinp, ema_beta=beta)
+            lf, lg = hip[mode]['step'].iteration(dinp, ema_beta=beta)
             rf = abs(float(lf) - out_r['loss_fake']) / abs(out_r['loss_fake'])
             rg = abs(float(lg) - out_r['loss_G']) / abs(out_r['loss_G'])
-            print(f'{cfg_name} kappa {kappa} iter {it} [{cd}]: loss_fake {float(lf):.5f} vs {out_r["loss_fake"]:.5f} (rel {rf:.1e}); '
+            print(f'{cfg_name} kappa {kappa} iter {it} [{cd} {variant}]: loss_fake {float(lf):.5f} vs {out_r["loss_fake"]:.5f} (rel {rf:.1e}); '
                   f'loss_G {float(lg):.5f} vs {out_r["loss_G"]:.5f} (rel {rg:.1e})')
             tol = TOL_LOSS_FP8_FROZEN if frozen_fp8 else TOL_LOSS_FP8_TEACHER if teacher_fp8 else TOL_LOSS[cd]
             gs = abs(float(lg) - out_r['loss_G']) / abs(out_r['loss_fake'])      # generator loss error in units of the loss scale
-            curve.setdefault(cd, []).append((rf, gs))
+            curve.setdefault(cd if not variant else mode, []).append((rf, gs))
             assert rf <= tol[0], f'fake-score loss [{cd}]: rel {rf:.3g}'
             if teacher_forced:       # the generator loss crosses zero along a trajectory: bound its error on the loss scale
                 assert gs <= tol[1], f'generator loss [{cd}]: {gs:.3g} of the loss scale'
@@ -334,8 +332,10 @@ def _iteration_parity(dev, cfg_name, lat, b, rounds, lr, kappa, alpha, iters, em
         return curve
     # parameters: Adam(beta1=0) moves every weight by ~lr*sign(g); compare the UPDATE direction statistically
     init = {name: dict(fixtures.make_unet(cfg_name, seed=seed).named_parameters()) for name, seed in (('fake_score', 77), ('G', 1234))}
-    for cd in modes:
-        for net, net_r, name in ((hip[cd]['psi'], psi_r, 'fake_score'), (hip[cd]['G'], G_r, 'G')):
+    for mode in modes:
+        cd, variant = mode
+        teacher_fp8, frozen_fp8 = variant in ('fp8-teacher', 'fp8-frozen'), variant == 'fp8-frozen'
+        for net, net_r, name in ((hip[mode]['psi'], psi_r, 'fake_score'), (hip[mode]['G'], G_r, 'G')):
             agree, total = 0, 0
             by_name_r, by_name_0 = dict(net_r.named_parameters()), init[name]
             for n, p in net.named_parameters():
@@ -345,12 +345,12 @@ def _iteration_parity(dev, cfg_name, lat, b, rounds, lr, kappa, alpha, iters, em
                 agree += int((torch.sign(du[big]) == torch.sign(dr[big])).sum())
                 total += int(big.sum())
             frac = agree / max(total, 1)
-            print(f'{name} [{cd}]: update-sign agreement {frac:.4f} over {total} weights')
+            print(f'{name} [{cd} {variant}]: update-sign agreement {frac:.4f} over {total} weights')
             # bf16 at kappa = 4.5: the guidance multiplies the bf16 difference of the two CFG branches (observed 0.969 / 0.978)
             # e4m3 teacher: G's gradient comes through the quantised teacher (bound set from the observed agreement)
             assert frac > (0.93 if frozen_fp8 else 0.96 if (teacher_fp8 and name == 'G') else 0.96 if (cd == BF16 and kappa > 2) else TOL_SIGN[cd])
         ema_r = dict(Gema_r.named_parameters())
-        for n, p in hip[cd]['G_ema'].named_parameters():
+        for n, p in hip[mode]['G_ema'].named_parameters():
             if n in ema_names:
                 e, _ = rel_err(p, ema_r[n])
                 # max-norm relative error; the only source of difference is the ~0.1 % of weights whose +-lr Adam step
