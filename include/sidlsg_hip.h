@@ -46,6 +46,16 @@ int sidlsg_conv3x3_bf16(const void* X, int ldx, const void* W, void* Y, int ldc,
                         const float* rowvec, int ld_rowvec, int B, int H, int Wd, int Cin, int Cout, int stride, int ups,
                         float alpha, int flags, void* stream);
 
+/* diffusers GEGLU (`FeedForward.net[0]`: proj -> chunk(2) -> hidden * gelu(gate)) with its projection, in ONE kernel: the GEMM's
+ * output tile holds 80 features of the value half and the same 80 features of the gate half, so the epilogue emits
+ * Y[M][F] = h[:, :F] * gelu(h[:, F:]) next to h[M][N2] = A W^T + bias (N2 = 2 F).  h is what the backward needs (sidlsg_geglu_bwd);
+ * H = NULL skips it (a pass without backward).  Y is computed from the bf16-rounded h: bit for bit sidlsg_geglu_fwd(h).  Saves the
+ * separate GEGLU pass over h (335 MB read at the 64x64 stage of SD1.5, batch 16).  sidlsg_gemm_geglu_ok: host query -- the fused kernel
+ * takes a shape only where the direct-to-LDS GEMM would be dispatched without split-K. */
+int sidlsg_gemm_geglu_ok(int M, int N2, int K);
+int sidlsg_gemm_geglu_bf16(const void* A, int lda, const void* W, void* H, int ldh, void* Y, int ldy, const float* bias, int M, int N2,
+                           int K, void* stream);
+
 /* Optional fp32 scratch (device memory owned by the caller): per-split partial-sum slabs for split-K GEMMs/convs with few
  * output tiles and long K (8x8 / 16x16 stages) and for the pixel-split weight gradients (without it they fall back to
  * fp32 atomics, ~2-3x slower on MI355X).  Default for every stream without a private workspace (below): launches sharing

@@ -54,6 +54,11 @@ struct GemmParams {
     const bf16* W1;
     const float* bias1;
     int Mg, Mtot;
+    // fused GEGLU (sidlsg_gemm_geglu_bf16: the transformer's FF-in projection): geglu = F = N / 2 > 0 -> an output tile holds 80
+    // features of the "a" half (rows [80 t, +80) of W) and the SAME 80 features of the gate half (rows [F + 80 t, +80)), the
+    // epilogue writes h (natural column order, C may be null) and Y[m][f] = a * gelu(g)
+    bf16* Y;
+    int ldy, geglu;
 };
 
 // m-tiles of a launch: each set of a grouped launch starts on a tile boundary of its own (Mg need not be a multiple of BM)
@@ -849,6 +854,9 @@ DEVFN void gemm_v3_body(GemmParams& p) {
     const int li = lane & 15, lg = lane >> 4;
     const int lrow = lane >> 3, lslot = lane & 7;
 
+    // first output column of this wave's half of the tile (fused GEGLU: the a half / the gate half live F columns apart)
+    const int wcol0 = p.geglu ? (wn0 ? p.geglu + nt * 80 : nt * 80) : n0 + wn0;
+
     // Loader: buffer_load_dwordx4 ... lds.  Per row ONE 32-bit byte offset (VGPR) that already contains the lane's
     // swizzled chunk; the K position of the tile is the wave-uniform soffset.  Invalid rows (m >= M, n >= N, conv halo)
     // carry an out-of-range offset and the buffer unit writes zeros: no pointer arithmetic, selects or zero page in the
@@ -909,7 +917,7 @@ DEVFN void gemm_v3_body(GemmParams& p) {
         const int g = wave + 4 * j;                 // 20 groups of 8 weight rows, 5 per wave
         const int r = g * 8 + lrow;
         const int kcs = lslot ^ wsw(r);
-        const int n = n0 + r;
+        const int n = p.geglu ? (r < 80 ? nt * 80 + r : p.geglu + nt * 80 + (r - 80)) : n0 + r;      // fused GEGLU: a rows | gate rows
         boff[j] = n < p.N ? ((unsigned)n * (unsigned)p.K + kcs * 8) * 2u : OOB;
     }
     const int kt_begin = p.kt_per_split ? split * p.kt_per_split : 0;
@@ -1011,7 +1019,7 @@ DEVFN void gemm_v3_body(GemmParams& p) {
     if constexpr (STAGES == 2) {
     TRACE(0); TRACE_HWID();
     issue(kt_begin, 0);
-    if (!p.kt_per_split) epilogue_prefetch<NT>(p, pre, n0 + wn0, lg);     // behind the first tile's DMA, used after the loop
+    if (!p.kt_per_split) epilogue_prefetch<NT>(p, pre, wcol0, lg);        // behind the first tile's DMA, used after the loop
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
@@ -1083,9 +1091,36 @@ DEVFN void gemm_v3_body(GemmParams& p) {
         constexpr int LDR = BN + 8;             // 336-byte rows: the 16 rows of a b128 write phase fall on distinct banks
         __syncthreads();                        // every wave is done with the last K-tile: the ring becomes the tile image
         TRACE(2);
-        gemm_epilogue<MT, NT>(p, acc, m0 + wm0, n0 + wn0, li, lg, pre, ring, m0, n0, LDR);
+        gemm_epilogue<MT, NT>(p, acc, m0 + wm0, wcol0, li, lg, pre, ring, m0, wcol0 - wn0, LDR);
         __syncthreads();
         TRACE(3);
+        if (MODE == 0 && p.geglu) {       // (dense kernel only: the conv instantiation does not carry this code)
+            // the staged tile holds h[.., 0:80) = a and h[.., 80:160) = gate of features [80 nt, +80): write both (natural
+            // columns; skipped when the caller keeps no h: a pass without backward) and y = a * gelu(gate) -- from the bf16-ROUNDED
+            // values, i.e. bit for bit what sidlsg_geglu_fwd computes from the stored h
+            constexpr int CPR = 10;                 // 16-byte chunks of the 80 features
+            bf16* H = reinterpret_cast<bf16*>(p.C);
+#pragma unroll
+            for (int i = 0; i < (BM * CPR + NTHREADS - 1) / NTHREADS; i++) {
+                const int c = tid + i * NTHREADS;
+                const int row = c / CPR, col = (c - row * CPR) * 8;
+                const int m = m0 + row;
+                if (row < BM && m < p.M) {
+                    const bf16x8 av = *reinterpret_cast<const bf16x8*>(ring + row * LDR + col);
+                    const bf16x8 gv = *reinterpret_cast<const bf16x8*>(ring + row * LDR + 80 + col);
+                    const int f = nt * 80 + col;
+                    if (H) {
+                        st8(H + (size_t)m * p.ldc + f, av);
+                        st8(H + (size_t)m * p.ldc + p.geglu + f, gv);
+                    }
+                    bf16x8 o;
+#pragma unroll
+                    for (int e = 0; e < 8; e++) o[e] = f2bf(bf2f(av[e]) * gelu_t<bf16>(bf2f(gv[e])));
+                    st8(p.Y + (size_t)m * p.ldy + f, o);
+                }
+            }
+            return;
+        }
         gemm_store_rows<BM, BN>(p, ring, m0, n0, LDR, tid);
         TRACE(4);
 #ifdef SIDLSG_EXP_TRACE
@@ -2389,6 +2424,28 @@ int sidlsg_gemm_bf16_g2(const void* A, int lda, const void* W, const void* W1, v
     if (!fits31(ab) || !fits31(wb)) return SIDLSG_EINVAL;
     p.a_bytes = (unsigned)ab; p.w_bytes = (unsigned)wb;
     return dispatch_gemm<0>(p, (hipStream_t)stream);
+}
+
+// FF-in projection + GEGLU in one kernel: h[M][N2] = A W^T + bias (N2 = 2 F; H may be NULL: not stored),
+// Y[M][F] = h[:, :F] * gelu(h[:, F:]).  Runs on the direct-to-LDS kernel only: returns SIDLSG_EINVAL for shapes it would not take
+// (F % 80, K % 64, fewer output tiles than the kernel is dispatched for) -- sidlsg_gemm_geglu_ok tells beforehand.
+int sidlsg_gemm_geglu_ok(int M, int N2, int K) {
+    static const bool on = !(getenv("SIDLSG_GEMM_GEGLU") && atoi(getenv("SIDLSG_GEMM_GEGLU")) == 0);      // A/B switch
+    if (!on || M <= 0 || N2 <= 0 || K <= 0 || (N2 % 160) || (K & 7)) return 0;
+    return (long long)((M + 127) / 128) * (N2 / 160) >= 256 ? 1 : 0;
+}
+int sidlsg_gemm_geglu_bf16(const void* A, int lda, const void* W, void* H, int ldh, void* Y, int ldy, const float* bias, int M, int N2,
+                           int K, void* stream) {
+    if (!sidlsg_gemm_geglu_ok(M, N2, K) || !Y || (ldy & 7) || (ldh & 7) || (lda & 7)) return SIDLSG_EINVAL;
+    GemmParams p{};
+    p.A = (const bf16*)A; p.W = (const bf16*)W; p.C = H; p.bias = bias; p.Y = (bf16*)Y; p.ldy = ldy; p.geglu = N2 / 2;
+    p.ldrv = N2; p.M = M; p.N = N2; p.K = K; p.lda = lda; p.ldc = ldh; p.rows_per_batch = 1; p.alpha = 1.f; p.Mtot = M;
+    if (!A || !W) return SIDLSG_EINVAL;
+    const unsigned long long ab = ((unsigned long long)(M - 1) * lda + K) * 2ull, wb = (unsigned long long)N2 * K * 2ull;
+    if (!fits31(ab) || !fits31(wb)) return SIDLSG_EINVAL;
+    p.a_bytes = (unsigned)ab; p.w_bytes = (unsigned)wb;
+    SidlsgTraceScope ts(SIDLSG_FAM_GEMM, 2.0 * M * (double)N2 * K, 2.0 * ((double)M * K + (double)N2 * K + (double)M * N2 * (H ? 1.5 : 0.5)));
+    return launch_gemm_v3<0>(p, (hipStream_t)stream);
 }
 
 // Grouped 3x3 convolution: samples [0, B/2) use (W, bias), samples [B/2, B) use (W1, bias1) (B even).

@@ -992,6 +992,51 @@ def geglu(h):
     return _GEGLU.apply(h)
 
 
+class _LinearGEGLU(torch.autograd.Function):
+    """y = GEGLU(x W^T + b) with the projection and the gating in ONE kernel (sidlsg_gemm_geglu_bf16): the separate GEGLU pass over
+    h = x W^T + b [M, 2F] -- at the 64x64 stage of SD1.5 a 335 MB read that took longer than the projection itself -- disappears.
+    h is still written when a backward will need it (GEGLU's derivative needs both halves); under no_grad it is not even stored.
+    Backward = sidlsg_geglu_bwd followed by the ordinary Linear backward (data gradient through w16t, weight + bias gradient)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, w16, w16t, keep_h):
+        _chk(x, BF16)
+        M, K = x.shape
+        N2 = w16.shape[0]
+        y = torch.empty((M, N2 // 2), device=x.device, dtype=BF16)
+        h = torch.empty((M, N2), device=x.device, dtype=BF16) if keep_h else None
+        lib.sidlsg_gemm_geglu_bf16(_p(x), x.stride(0), _p(w16), _p(h), N2, _p(y), N2 // 2, _p(bias), M, N2, K, _s())
+        if keep_h:
+            ctx.save_for_backward(x, weight, bias, w16t, h)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, bias, w16t, h = ctx.saved_tensors
+        F2 = h.shape[-1]
+        dh = torch.empty_like(h)
+        lib.sidlsg_geglu_bwd(_p(h), _p(dy.contiguous().to(BF16)), _p(dh), h.shape[0], F2 // 2, _s())
+        dx = gemm(dh, w16t) if ctx.needs_input_grad[0] else None
+        if _wants_grad(weight):
+            M, K = x.shape
+            need_b = _wants_grad(bias)
+            with _OnWgradStream(dh, x):
+                lib.sidlsg_wgrad_bf16(_p(dh), dh.stride(0), _p(x), x.stride(0), _p(weight.grad), _p(bias.grad) if need_b else None,
+                                      M, weight.shape[0], K, _s())
+        elif _wants_grad(bias):
+            colsum(dh, dh.shape[0], total=bias.grad)
+        return dx, None, None, None, None, None
+
+
+def linear_geglu(x, weight, bias, w16, w16t):
+    """GEGLU(Linear(x)): the fused kernel where it applies (bf16, a shape the direct-to-LDS GEMM takes), else the two ops."""
+    if (_dual is None and x.dtype == BF16 and isinstance(w16, torch.Tensor) and w16.dtype == BF16 and x.is_contiguous()
+            and lib.sidlsg_gemm_geglu_ok.raw(x.shape[0], w16.shape[0], w16.shape[1])):
+        keep_h = torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad or (bias is not None and bias.requires_grad))
+        return _LinearGEGLU.apply(x, weight, bias, w16, w16t, keep_h)
+    return geglu(linear(x, weight, bias, w16, w16t))
+
+
 class _SiLU(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):

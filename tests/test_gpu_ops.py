@@ -650,3 +650,39 @@ def test_dispatch_trace_reports_kernel_time(dev):
     ops.gemm(a, w, out=out)
     lib.sidlsg_trace_read(0, buf.data_ptr())
     assert buf[3] == 0
+
+
+@pytest.mark.parametrize('M,F,K', [(32768, 1280, 320), (16384, 2560, 640), (4096, 5120, 1280), (33000, 1280, 320), (256, 1280, 320)])
+def test_linear_geglu_fused_equals_two_kernels(dev, M, F, K):
+    """The transformer's FF-in projection with GEGLU in the GEMM's epilogue (sidlsg_gemm_geglu_bf16) against the two kernels it
+    replaces (sidlsg_gemm_bf16 then sidlsg_geglu_fwd): y is computed from the bf16-rounded h, so forward, stored h and all
+    gradients must be BIT-equal; under no_grad h is not stored at all; shapes the fused kernel does not take fall back."""
+    from sid_lsg_amd import ops
+    from sid_lsg_amd._lib import lib
+    x = rnd(M, K, seed=1).to(dev)
+    w = torch.nn.Parameter(rnd(2 * F, K, seed=2, scale=K ** -0.5).float().to(dev))
+    b = torch.nn.Parameter(rnd(2 * F, seed=3).float().to(dev))
+    w16 = w.detach().to(BF16).contiguous()
+    w16t = w16.t().contiguous()
+    dy = rnd(M, F, seed=4).to(dev)
+    fused = bool(lib.sidlsg_gemm_geglu_ok.raw(M, 2 * F, K))
+    assert fused == (M >= 4096)
+    res = {}
+    for name in ('fused', 'split'):
+        for p_ in (w, b):
+            p_.grad = torch.zeros_like(p_)
+        xd = x.clone().requires_grad_()
+        y = ops.linear_geglu(xd, w, b, w16, w16t) if name == 'fused' else ops.geglu(ops.linear(xd, w, b, w16, w16t))
+        y.backward(dy)
+        torch.cuda.synchronize()
+        res[name] = (y.detach(), xd.grad, w.grad.clone(), b.grad.clone())
+    assert torch.equal(res['fused'][0], res['split'][0]), 'y'
+    assert torch.equal(res['fused'][1], res['split'][1]), 'dx'
+    # the weight gradient is a pixel-split sum (fixed order) and the bias gradient comes out of the same kernel: identical inputs -> equal
+    assert torch.equal(res['fused'][2], res['split'][2]) and torch.equal(res['fused'][3], res['split'][3])
+    with torch.no_grad():
+        assert torch.equal(ops.linear_geglu(x, w, b, w16, w16t), res['split'][0])
+    # against plain torch (loose: bf16 h)
+    hr = x.float() @ w16.float().t() + b.detach()
+    yr = hr[:, :F].to(BF16).float() * torch.nn.functional.gelu(hr[:, F:].to(BF16).float())
+    close(res['fused'][0], yr, 1.5e-2, 'y vs torch')

@@ -233,7 +233,7 @@ def test_sid_iteration_full_size_batch2(dev):
 # teacher: its error is the e4m3 quantisation noise of ~170 contractions (3 mantissa bits, per-output-channel weight scales,
 # unit-scale activations) propagated through the teacher and amplified by the guidance like the bf16 noise is.
 TOL_LOSS_FP8_TEACHER = (2e-3, 2e-2)      # observed on MI355X: 1.3e-4 / 3.7e-3
-TOL_LOSS_FP8_FROZEN = (5e-3, 5e-2)       # + e4m3 generator (phase A) and fake-score evaluation (phase B)
+TOL_LOSS_FP8_FROZEN = (2e-3, 2e-2)       # + e4m3 generator (phase A) and fake-score evaluation (phase B); observed 6.0e-5 / 4.3e-3
 
 
 def test_sid_iteration_full_size_config5_fp8(dev):
@@ -348,7 +348,7 @@ def _iteration_parity(dev, cfg_name, lat, b, rounds, lr, kappa, alpha, iters, em
             print(f'{name} [{cd} {variant}]: update-sign agreement {frac:.4f} over {total} weights')
             # bf16 at kappa = 4.5: the guidance multiplies the bf16 difference of the two CFG branches (observed 0.969 / 0.978)
             # e4m3 teacher: G's gradient comes through the quantised teacher (bound set from the observed agreement)
-            assert frac > (0.93 if frozen_fp8 else 0.96 if (teacher_fp8 and name == 'G') else 0.96 if (cd == BF16 and kappa > 2) else TOL_SIGN[cd])
+            assert frac > (0.96 if frozen_fp8 else 0.96 if (teacher_fp8 and name == 'G') else 0.96 if (cd == BF16 and kappa > 2) else TOL_SIGN[cd])
         ema_r = dict(Gema_r.named_parameters())
         for n, p in hip[mode]['G_ema'].named_parameters():
             if n in ema_names:
