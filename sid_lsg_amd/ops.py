@@ -1033,7 +1033,11 @@ def linear_geglu(x, weight, bias, w16, w16t):
     if (_dual is None and x.dtype == BF16 and isinstance(w16, torch.Tensor) and w16.dtype == BF16 and x.is_contiguous()
             and lib.sidlsg_gemm_geglu_ok.raw(x.shape[0], w16.shape[0], w16.shape[1])):
         keep_h = torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad or (bias is not None and bias.requires_grad))
-        return _LinearGEGLU.apply(x, weight, bias, w16, w16t, keep_h)
+        # measured (tools/ab/geglu_fused.py, MI355X, batch 16): K = 640 / 1280 (32x32 / 16x16 stages) 177 -> 165 us / 134 -> 120 us with h
+        # kept; K = 320 (64x64 stage) only pays when h is NOT kept (251 -> 190 us): with h the A-stationary GEMM + the stand-alone
+        # GEGLU kernel (164 + 87 us) beat the fused direct-to-LDS kernel (262 us)
+        if not keep_h or w16.shape[1] >= 640:
+            return _LinearGEGLU.apply(x, weight, bias, w16, w16t, keep_h)
     return geglu(linear(x, weight, bias, w16, w16t))
 
 

@@ -672,14 +672,17 @@ def test_linear_geglu_fused_equals_two_kernels(dev, M, F, K):
         for p_ in (w, b):
             p_.grad = torch.zeros_like(p_)
         xd = x.clone().requires_grad_()
-        y = ops.linear_geglu(xd, w, b, w16, w16t) if name == 'fused' else ops.geglu(ops.linear(xd, w, b, w16, w16t))
+        # (_LinearGEGLU directly: ops.linear_geglu applies a measured policy -- at K = 320 it fuses only when h is not kept)
+        y = (ops._LinearGEGLU.apply(xd, w, b, w16, w16t, True) if fused else ops.linear_geglu(xd, w, b, w16, w16t)) if name == 'fused' \
+            else ops.geglu(ops.linear(xd, w, b, w16, w16t))
         y.backward(dy)
         torch.cuda.synchronize()
         res[name] = (y.detach(), xd.grad, w.grad.clone(), b.grad.clone())
     assert torch.equal(res['fused'][0], res['split'][0]), 'y'
     assert torch.equal(res['fused'][1], res['split'][1]), 'dx'
-    # the weight gradient is a pixel-split sum (fixed order) and the bias gradient comes out of the same kernel: identical inputs -> equal
-    assert torch.equal(res['fused'][2], res['split'][2]) and torch.equal(res['fused'][3], res['split'][3])
+    # the weight gradient is a pixel-split sum in a fixed order: identical inputs -> equal; the bias gradient is accumulated with atomics
+    assert torch.equal(res['fused'][2], res['split'][2])
+    close(res['fused'][3], res['split'][3], 1e-5, 'bias gradient (fp32 atomics: order)')
     with torch.no_grad():
         assert torch.equal(ops.linear_geglu(x, w, b, w16, w16t), res['split'][0])
     # against plain torch (loose: bf16 h)
