@@ -2016,15 +2016,21 @@ __global__ __launch_bounds__(NTHREADS) void wgrad_bf16_kernel(WgradParams p) {
 // else 128.  The k (X column) extent stays 128.
 template <int TN> DEVFN int wg_yswz(int row) { return TN == 128 ? wg_swz(row) : ((row >> 3) & 1); }
 
-template <int MODE, int TN>
+// TK = k (X column) extent of the tile: 128, or (dense only, round 4) 160 -- with N and K multiples of 160 a 160 x 160 tile wastes no
+// MFMA work on padding (320 = 2 x 160 instead of 3 x 128) and the operands are re-read 2 + 2 instead of 3 + 3 times per split
+// (L2 -> LDS bytes -44 % at 320 x 320); the X tile is then staged exactly like the dY tile (same chunk grid, same swizzle).
+template <int MODE, int TN, int TK>
 DEVFN void wgrad_v2_body(const WgradParams& p) {
+    static_assert(TK == WG_T || (TK == 160 && MODE == 0), "160-wide k tiles: dense operands only");
+    constexpr int KI = TK / 32;             // 16-column X fragments per wave (wave = TN/2 x TK/2 of the tile)
+    constexpr int XC = TK / 8;              // 16-byte chunks per X row (TK = 160 staging)
     constexpr int NI = TN / 32;             // 16-column dY fragments per wave (wave = TN/2 x 64 of the tile)
     constexpr int YI = TN / 32;             // dY DMA instructions per wave and stage (64 rows x TN/8 chunks / 256 lanes)
     constexpr int YC = TN / 8;              // 16-byte chunks per dY row
-    constexpr int STAGE = WG_MB * (TN + WG_T);
+    constexpr int STAGE = WG_MB * (TN + TK);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16* ring = reinterpret_cast<bf16*>(smem);
-    const int tiles_k = (p.K + WG_T - 1) / WG_T;
+    const int tiles_k = (p.K + TK - 1) / TK;
     const int tiles = ((p.N + TN - 1) / TN) * tiles_k;
     int bid = blockIdx.x;
     {
@@ -2033,13 +2039,13 @@ DEVFN void wgrad_v2_body(const WgradParams& p) {
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
     const int split = bid / tiles, tile = bid - split * tiles;
-    const int n0 = (tile / tiles_k) * TN, k0 = (tile % tiles_k) * WG_T;
+    const int n0 = (tile / tiles_k) * TN, k0 = (tile % tiles_k) * TK;
     const int mbeg = split * p.m_per_split;
     const int mend = min(p.M, mbeg + p.m_per_split);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, lg = lane >> 4;
-    const int wn0 = (wave >> 1) * (TN / 2), wk0 = (wave & 1) * 64;
+    const int wn0 = (wave >> 1) * (TN / 2), wk0 = (wave & 1) * (TK / 2);
     const int q16 = tid & 15, r0 = tid >> 4;            // LDS chunk position and first row of this lane
     const int c16 = (((q16 >> 1) ^ wg_swz(r0)) << 1) | (q16 & 1);   // source chunk (wg_swz(r0 + 16 i) == wg_swz(r0))
     const int kA = k0 + c16 * 8;
@@ -2068,6 +2074,17 @@ DEVFN void wgrad_v2_body(const WgradParams& p) {
         const unsigned m = (unsigned)(mbeg + r0 + 16 * i);
         xoff[i] = (MODE == 0 && kok) ? (m * (unsigned)p.lda + (unsigned)kA) * 2u : OOB;
     }
+    unsigned xoffw[TK == WG_T ? 1 : KI];         // TK = 160: the dY scheme for X (KI DMA instructions per wave and stage)
+    if constexpr (TK != WG_T) {
+#pragma unroll
+        for (int j = 0; j < KI; j++) {
+            const int idx = (wave * KI + j) * 64 + lane;
+            const int row = idx / XC, cpos = idx - row * XC;
+            const int chunk = (((cpos >> 1) ^ wg_yswz<TK>(row)) << 1) | (cpos & 1);
+            const int kX = k0 + chunk * 8;
+            xoffw[j] = kX < p.K ? ((unsigned)(mbeg + row) * (unsigned)p.lda + (unsigned)kX) * 2u : OOB;
+        }
+    }
 
     int pb[4], pho[4], pwo[4];
     const int d_b = WG_MB / hw, d_rem = WG_MB - d_b * hw;
@@ -2093,6 +2110,14 @@ DEVFN void wgrad_v2_body(const WgradParams& p) {
             if (SIDLSG_WGRAD_ASM_DMA) dma16_asm(ry, ys + (wave * YI + j) * 512, mok ? yoff[j] : OOB, ysoff);
             else __builtin_amdgcn_raw_ptr_buffer_load_lds(ry, (lptr_t)(ys + (wave * YI + j) * 512), 16, mok ? yoff[j] : OOB, ysoff, 0, 0);
         }
+        if constexpr (TK != WG_T) {
+#pragma unroll
+            for (int j = 0; j < KI; j++) {
+                const bool mok = !tail || (mb + ((wave * KI + j) * 64 + lane) / XC < mend);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lptr_t)(xs + (wave * KI + j) * 512), 16, mok ? xoffw[j] : OOB, xsoff, 0, 0);
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             const bool mok = !tail || (mb + r0 + 16 * i < mend);
@@ -2116,11 +2141,11 @@ DEVFN void wgrad_v2_body(const WgradParams& p) {
         }
     };
 
-    f32x4 acc[NI][4];   // [n tile][k tile]
+    f32x4 acc[NI][KI];   // [n tile][k tile]
 #pragma unroll
     for (int i = 0; i < NI; i++)
 #pragma unroll
-        for (int j = 0; j < 4; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < KI; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const bool do_bias = p.dB != nullptr && k0 == 0 && wk0 == 0;
     f32x4 accb[NI];
 #pragma unroll
@@ -2133,7 +2158,7 @@ DEVFN void wgrad_v2_body(const WgradParams& p) {
     const int rA = 8 * lg + (li >> 2), rB = rA + 4;
     // kk*32 does not change the swizzle bits.  X tile: 256-byte rows, 3-bit granule XOR; dY tile: TN*2-byte rows (320 B
     // rows alias the banks of rows 8 apart only -> 1-bit XOR with (row>>3)&1 for TN = 160)
-    const int sxA = wg_swz(rA), sxB = wg_swz(rB), syA = wg_yswz<TN>(rA), syB = wg_yswz<TN>(rB);
+    const int sxA = wg_yswz<TK>(rA), sxB = wg_yswz<TK>(rB), syA = wg_yswz<TN>(rA), syB = wg_yswz<TN>(rB);
     typedef short s16x8 __attribute__((ext_vector_type(8)));
     auto tr_frag = [&](const bf16* tilebase, int pitch, int sA, int sB, int kk, int colbase) -> bf16x8 {
         const int g = colbase >> 4;
@@ -2143,19 +2168,19 @@ DEVFN void wgrad_v2_body(const WgradParams& p) {
         s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
         return __builtin_bit_cast(bf16x8, v);
     };
-    auto read_frags = [&](int buf, int kk, bf16x8 (&fy)[NI], bf16x8 (&fx)[4]) {
+    auto read_frags = [&](int buf, int kk, bf16x8 (&fy)[NI], bf16x8 (&fx)[KI]) {
         const bf16* ys = ring + buf * STAGE;
         const bf16* xs = ys + WG_MB * TN;
 #pragma unroll
         for (int i = 0; i < NI; i++) fy[i] = tr_frag(ys, TN, syA, syB, kk, wn0 + i * 16);
 #pragma unroll
-        for (int j = 0; j < 4; j++) fx[j] = tr_frag(xs, WG_T, sxA, sxB, kk, wk0 + j * 16);
+        for (int j = 0; j < KI; j++) fx[j] = tr_frag(xs, TK, sxA, sxB, kk, wk0 + j * 16);
     };
-    auto mfma_block = [&](const bf16x8 (&fy)[NI], const bf16x8 (&fx)[4]) {
+    auto mfma_block = [&](const bf16x8 (&fy)[NI], const bf16x8 (&fx)[KI]) {
 #pragma unroll
         for (int i = 0; i < NI; i++)
 #pragma unroll
-            for (int j = 0; j < 4; j++)
+            for (int j = 0; j < KI; j++)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fy[i], fx[j], acc[i][j], 0, 0, 0);
         if (do_bias) {
 #pragma unroll
@@ -2165,7 +2190,7 @@ DEVFN void wgrad_v2_body(const WgradParams& p) {
 
     const int nsteps = (mend - mbeg + WG_MB - 1) / WG_MB;
     if (nsteps <= 0) return;
-    bf16x8 fy0[NI], fx0[4], fy1[NI], fx1[4];
+    bf16x8 fy0[NI], fx0[KI], fy1[NI], fx1[KI];
     WTRACE(0);
     issue(mbeg, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -2213,7 +2238,7 @@ DEVFN void wgrad_v2_body(const WgradParams& p) {
     // a launch have equal work, reach this point together and write tiles x splits x 64 KB of slabs (31 MB for 65536x320x320)
     // with nothing left to overlap it.
     if (p.nsplits == 1 || p.ws) {
-        constexpr int LDW = WG_T + 4;
+        constexpr int LDW = TK + 4;
         float* img = reinterpret_cast<float*>(smem);
         float* dst = p.nsplits == 1 ? p.dW : p.ws + (size_t)split * p.N * p.K;
         const bool accum = p.nsplits == 1;
@@ -2224,13 +2249,13 @@ DEVFN void wgrad_v2_body(const WgradParams& p) {
 #pragma unroll
                 for (int i = 0; i < NI; i++)
 #pragma unroll
-                    for (int j = 0; j < 4; j++)
+                    for (int j = 0; j < KI; j++)
 #pragma unroll
                         for (int r = 0; r < 4; r++) img[(16 * i + lg * 4 + r) * LDW + wk0 + 16 * j + li] = acc[i][j][r];
             }
             __syncthreads();
-            for (int c = tid; c < (TN / 2) * 32; c += NTHREADS) {
-                const int row = c >> 5, k4 = (c & 31) * 4;
+            for (int c = tid; c < (TN / 2) * (TK / 4); c += NTHREADS) {
+                const int row = c / (TK / 4), k4 = (c - row * (TK / 4)) * 4;
                 const int n = n0 + h * (TN / 2) + row, k = k0 + k4;
                 if (n < p.N && k < p.K) {
                     f32x4 v = *reinterpret_cast<const f32x4*>(img + row * LDW + k4);
@@ -2244,7 +2269,7 @@ DEVFN void wgrad_v2_body(const WgradParams& p) {
 #pragma unroll
         for (int i = 0; i < NI; i++)
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
+            for (int j = 0; j < KI; j++) {
                 const int k = k0 + wk0 + 16 * j + li;
                 if (k >= p.K) continue;
 #pragma unroll
@@ -2264,9 +2289,10 @@ DEVFN void wgrad_v2_body(const WgradParams& p) {
 // (two plain kernels over one body: a kernel template with the second non-type parameter did not get a host stub from
 // hipcc 7.2 -- undefined symbol at load time, no diagnostic)
 template <int MODE>
-__global__ __launch_bounds__(NTHREADS, 2) void wgrad_v2_kernel(WgradParams p) { wgrad_v2_body<MODE, 128>(p); }
+__global__ __launch_bounds__(NTHREADS, 2) void wgrad_v2_kernel(WgradParams p) { wgrad_v2_body<MODE, 128, WG_T>(p); }
 template <int MODE>
-__global__ __launch_bounds__(NTHREADS, 2) void wgrad_v2w_kernel(WgradParams p) { wgrad_v2_body<MODE, 160>(p); }
+__global__ __launch_bounds__(NTHREADS, 2) void wgrad_v2w_kernel(WgradParams p) { wgrad_v2_body<MODE, 160, WG_T>(p); }
+__global__ __launch_bounds__(NTHREADS, 2) void wgrad_v2s_kernel(WgradParams p) { wgrad_v2_body<0, 160, 160>(p); }      // dense, 160 x 160 tiles
 
 // dW[i] += sum_s slab[s][i]
 __global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dW, size_t n, int splits) {
@@ -2303,8 +2329,12 @@ static int launch_wgrad(WgradParams p, hipStream_t s) {
     // 160-wide n tiles: measured faster only where they cut the tile count by a third (conv, Cout = 320: 216 -> 178 us);
     // for N = 640 (5 -> 4 tiles) and the dense shapes the leaner 128 kernel wins
     static const bool tn160_dense = getenv("SIDLSG_WGRAD_TN160_DENSE") && atoi(getenv("SIDLSG_WGRAD_TN160_DENSE"));   // A/B switch
-    const int tn = (v2 && tn160_on && (MODE == 1 || tn160_dense) && p.N == 320) ? 160 : WG_T;
-    const int tiles = ((p.N + tn - 1) / tn) * ((p.K + WG_T - 1) / WG_T);
+    // dense, N and K multiples of 160 (every Linear of the SD transformer blocks): 160 x 160 tiles (wgrad_v2s_kernel)
+    static const bool sq160_on = !(getenv("SIDLSG_WGRAD_SQ160") && atoi(getenv("SIDLSG_WGRAD_SQ160")) == 0);       // A/B switch
+    const bool sq160 = v2 && sq160_on && MODE == 0 && p.N % 160 == 0 && p.K % 160 == 0;
+    const int tn = sq160 ? 160 : (v2 && tn160_on && (MODE == 1 || tn160_dense) && p.N == 320) ? 160 : WG_T;
+    const int tk = sq160 ? 160 : WG_T;
+    const int tiles = ((p.N + tn - 1) / tn) * ((p.K + tk - 1) / tk);
     // Split the pixel contraction so the grid fills the chip in whole rounds of 512 resident blocks (256 CUs x 2).
     // Small cost model (us): rounds * (rows per block * 24 ns + 3 us block overhead) + slab reduction at ~4 TB/s;
     // e.g. 69 tiles: ceil(768/69) = 12 splits ran 1.6 rounds, the model picks a whole number of rounds.
@@ -2347,14 +2377,16 @@ static int launch_wgrad(WgradParams p, hipStream_t s) {
     p.m_per_split = mps;
     p.nsplits = splits;
     if (v2) {
-        const size_t lds = (size_t)2 * WG_MB * (tn + WG_T) * sizeof(bf16);
+        const size_t lds = (size_t)2 * WG_MB * (tn + tk) * sizeof(bf16);
         static bool attr_done = false;
         if (!attr_done) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_v2_kernel<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * WG_MB * (128 + WG_T) * 2);
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_v2w_kernel<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * WG_MB * (160 + WG_T) * 2);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_v2s_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * WG_MB * (160 + 160) * 2);
             attr_done = true;
         }
-        if (tn == 160) SIDLSG_LAUNCH((wgrad_v2w_kernel<MODE>), dim3(tiles * splits), dim3(NTHREADS), lds, s, p);
+        if (sq160) SIDLSG_LAUNCH(wgrad_v2s_kernel, dim3(tiles * splits), dim3(NTHREADS), lds, s, p);
+        else if (tn == 160) SIDLSG_LAUNCH((wgrad_v2w_kernel<MODE>), dim3(tiles * splits), dim3(NTHREADS), lds, s, p);
         else SIDLSG_LAUNCH((wgrad_v2_kernel<MODE>), dim3(tiles * splits), dim3(NTHREADS), lds, s, p);
     } else
     SIDLSG_LAUNCH((wgrad_bf16_kernel<MODE>), dim3(tiles, splits), dim3(NTHREADS), 0, s, p);

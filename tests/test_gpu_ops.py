@@ -103,7 +103,9 @@ def test_conv3x3(dev, B, H, W, Cin, Cout, stride, ups):
     close(got, ref + bias + res.float() + rv[:, None, None, :], 1.2e-2, 'conv+epilogue')
 
 
-@pytest.mark.parametrize('M,N,K', [(512, 128, 128), (1000, 320, 72), (4096, 64, 2880), (333, 8, 320), (8192, 960, 320)])
+# (N and K multiples of 160 take the 160 x 160-tile kernel: wgrad_v2s_kernel; incl. ragged row counts and one-split launches)
+@pytest.mark.parametrize('M,N,K', [(512, 128, 128), (1000, 320, 72), (4096, 64, 2880), (333, 8, 320), (8192, 960, 320), (65536, 320, 320),
+                                   (3000, 320, 1280), (777, 640, 640), (100, 2560, 320), (16384, 1280, 1280)])
 def test_wgrad_dense(dev, M, N, K):
     from sid_lsg_amd._lib import lib
     from sid_lsg_amd.ops import _p, _s
