@@ -71,6 +71,7 @@ int sidlsg_set_stream_workspace(void* stream, void* ptr, long long bytes);
  * same kernel (one extra MFMA against a vector of ones per dY fragment) instead of a separate column-sum pass. */
 int sidlsg_wgrad_bf16(const void* dY, int ldy, const void* A, int lda, float* dW, float* dBias, int M, int N, int K,
                       void* stream);
+int sidlsg_debug_wgrad_blocks_per_cu(int which); /* host diagnostic: resident blocks per CU of the weight-gradient kernels (0: 128x128, 1: 160x128, 2: 160x160 tiles) */
 int sidlsg_conv3x3_wgrad_bf16(const void* dY, int ldy, const void* X, int ldx, float* dW, float* dBias, int B, int H, int Wd,
                               int Cin, int Cout, int stride, int ups, void* stream);
 

@@ -2331,7 +2331,12 @@ static int launch_wgrad(WgradParams p, hipStream_t s) {
     static const bool tn160_dense = getenv("SIDLSG_WGRAD_TN160_DENSE") && atoi(getenv("SIDLSG_WGRAD_TN160_DENSE"));   // A/B switch
     // dense, N and K multiples of 160 (every Linear of the SD transformer blocks): 160 x 160 tiles (wgrad_v2s_kernel)
     static const bool sq160_on = !(getenv("SIDLSG_WGRAD_SQ160") && atoi(getenv("SIDLSG_WGRAD_SQ160")) == 0);       // A/B switch
-    const bool sq160 = v2 && sq160_on && MODE == 0 && p.N % 160 == 0 && p.K % 160 == 0;
+    // measured per shape (tools/ab/wgrad_sweep.py, MI355X): faster on every non-square layer of the transformer blocks at M >= 4096
+    // (2560 x 320: 192 -> 157 us, 5120 x 640: 145 -> 120, 10240 x 1280: 139 -> 112; a backward pass's dense weight gradients 1025 -> 927 us
+    // at CFG batch 16), slower on the square C x C layers (fewer, larger tiles need more pixel splits = more slab traffic: 36.7 -> 39.9 us)
+    // and at small pixel counts unless the weight is very large
+    const bool sq160 = v2 && sq160_on && MODE == 0 && p.N % 160 == 0 && p.K % 160 == 0 && p.N != p.K &&
+                       (p.M >= 4096 || (long long)p.N * p.K >= (8ll << 20));
     const int tn = sq160 ? 160 : (v2 && tn160_on && (MODE == 1 || tn160_dense) && p.N == 320) ? 160 : WG_T;
     const int tk = sq160 ? 160 : WG_T;
     const int tiles = ((p.N + tn - 1) / tn) * ((p.K + tk - 1) / tk);
@@ -2398,6 +2403,17 @@ static int launch_wgrad(WgradParams p, hipStream_t s) {
 static bool fits31(unsigned long long bytes) { return bytes < 0x7FFFFFFFull; }
 
 extern "C" {
+
+// (diagnostic) resident blocks per CU of the weight-gradient kernels with their dynamic LDS: 0 = 128x128, 1 = 160x128, 2 = 160x160
+int sidlsg_debug_wgrad_blocks_per_cu(int which) {
+    int n = -1;
+    const size_t lds = (size_t)2 * WG_MB * ((which ? 160 : 128) + (which == 2 ? 160 : 128)) * 2;
+    const void* f = which == 2 ? reinterpret_cast<const void*>(&wgrad_v2s_kernel)
+                               : which ? reinterpret_cast<const void*>(&wgrad_v2w_kernel<0>) : reinterpret_cast<const void*>(&wgrad_v2_kernel<0>);
+    (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, f, NTHREADS, lds) != hipSuccess) return -1;
+    return n;
+}
 
 // Optional scratch for split-K GEMMs and weight gradients: `ptr` = device memory of `bytes` bytes, owned by the
 // caller, used by every later sidlsg_gemm_bf16 / sidlsg_conv3x3_bf16 call of this process (one stream at a time).
