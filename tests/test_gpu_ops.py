@@ -77,7 +77,8 @@ def test_gemm_short_k_a_stationary(dev):
 
 CONV_CASES = [(2, 16, 16, 64, 160, 1, 0), (2, 16, 16, 64, 128, 2, 0), (1, 8, 8, 128, 64, 1, 1), (2, 12, 20, 8, 320, 1, 0),
               (2, 8, 8, 320, 8, 1, 0), (1, 64, 64, 320, 320, 1, 0), (3, 9, 7, 72, 40, 2, 0),
-              (2, 8, 8, 1280, 320, 1, 0), (1, 16, 16, 640, 160, 1, 1)]      # last two: split-K conv (8x8 / 16x16 stages)
+              (2, 8, 8, 1280, 320, 1, 0), (1, 16, 16, 640, 160, 1, 1),      # these two: split-K conv (8x8 / 16x16 stages)
+              (1, 16, 16, 320, 640, 1, 1), (2, 16, 16, 640, 640, 2, 0), (3, 9, 7, 160, 160, 1, 0)]   # weight gradient: 160 x 160 tiles
 
 
 def conv_ref(x, w, stride, ups):

@@ -1,6 +1,7 @@
 #!/usr/bin/env python
 """Dense weight-gradient shapes of one SD1.5 backward pass (CFG batch 16 and generator batch 8) under the current dispatch:
-SIDLSG_WGRAD_SQ160=0/1 python tools/ab/wgrad_sweep.py"""
+SIDLSG_WGRAD_SQ160=0/1 python tools/ab/wgrad_sweep.py            (dense layers)
+SIDLSG_WGRAD_CONV160=0/1/2 python tools/ab/wgrad_sweep.py conv   (3x3 convs, weighted by their count in the UNet)"""
 import os
 import sys
 
@@ -27,6 +28,25 @@ def timeit(fn, iters=10, warm=3):
     torch.cuda.synchronize()
     return e0.elapsed_time(e1) / iters * 1e3
 
+
+# (output H, Cin, Cout, stride, fused 2x upsample, count in the SD1.5 UNet)
+CONVS = [(64, 320, 320, 1, 0, 7), (32, 320, 320, 2, 0, 1), (32, 320, 640, 1, 0, 1), (32, 640, 640, 1, 0, 6), (16, 640, 640, 2, 0, 1),
+         (16, 640, 1280, 1, 0, 1), (16, 1280, 1280, 1, 0, 6), (8, 1280, 1280, 2, 0, 1), (8, 1280, 1280, 1, 0, 11), (8, 2560, 1280, 1, 0, 3),
+         (16, 1280, 1280, 1, 1, 1), (16, 2560, 1280, 1, 0, 2), (16, 1920, 1280, 1, 0, 1), (32, 1280, 1280, 1, 1, 1), (32, 1920, 640, 1, 0, 1),
+         (32, 1280, 640, 1, 0, 1), (32, 960, 640, 1, 0, 1), (64, 640, 640, 1, 1, 1), (64, 960, 320, 1, 0, 1), (64, 640, 320, 1, 0, 2)]
+if 'conv' in sys.argv[1:]:
+    tot = {}
+    for B in (16, 8):
+        for H, cin, cout, stride, ups, cnt in CONVS:
+            Hi = H * stride // (2 if ups else 1)           # stored input extent
+            x, dy = torch.randn(B, Hi, Hi, cin, device=dev).bfloat16(), torch.randn(B, H, H, cout, device=dev).bfloat16()
+            dw, db = torch.zeros(cout, 9 * cin, device=dev), torch.zeros(cout, device=dev)
+            Hl = Hi * (2 if ups else 1)                    # logical input extent
+            t = timeit(lambda: lib.sidlsg_conv3x3_wgrad_bf16(dy.data_ptr(), cout, x.data_ptr(), cin, dw.data_ptr(), db.data_ptr(), B, Hl, Hl, cin, cout, stride, ups, ops._s()))
+            print(f'B {B:2d} out {H:2d}x{H:2d} {cin:5d}->{cout:5d} s{stride} u{ups} x{cnt:2d}: {t:8.1f} us  {2.0 * B * H * H * cout * 9 * cin / t / 1e6:7.1f} TF/s')
+            tot[B] = tot.get(B, 0) + t * cnt
+    print('weighted sum', {k: round(v, 1) for k, v in tot.items()})
+    sys.exit(0)
 
 tot = {}
 for B in (16, 8):
