@@ -579,6 +579,21 @@ def main():
                     objs[key]['traffic_over_algorithmic'] = ent.get('traffic_over_algorithmic')      # both of the micro-benchmark's calls
                     objs[key]['traffic_source'] = (f'profiles/r04_traffic_{mode}.json: HBM-side bytes per call, micro-benchmark of the step\'s shapes at '
                                                    'batch 16 (compare with the same benchmark\'s algorithmic bytes, not with this step\'s mix)')
+        # the same family under `rocprofv3 --kernel-trace --stats` (committed run of this command, profiles/): the profiler's interception slows
+        # the host, the streams overlap less and every kernel's begin -> end interval shrinks towards its stand-alone duration -- the figure the
+        # committed kernel_stats CSV reproduces, next to this run's in-region (`frac`) and stand-alone (`isolated.frac`) figures
+        ref = os.path.join(ROOT, 'profiles', 'r04_bench_under_rocprof.json')
+        if os.path.isfile(ref):
+            try:
+                refd = json.loads(open(ref).read().strip().splitlines()[-1])
+                for key in objs:
+                    e = refd.get('roofline_' + key)
+                    if e:
+                        objs[key]['under_rocprofv3'] = {'frac': e['frac'], 'avg_launch_ms': e['avg_launch_ms'], 'est_ms_per_step': e['est_ms_per_step'],
+                                                        'source': 'profiles/r04_bench_under_rocprof.json (this command under rocprofv3 --kernel-trace --stats; '
+                                                                  'kernel durations: profiles/r04_bench_step_kernel_stats.csv)'}
+            except (ValueError, KeyError):
+                pass
         # `roofline` = the family that takes the largest share of the step (dense GEMM since round 2's conv work; the MFMA
         # families are compared by est_ms_per_step); every family keeps its own object
         mfma = ['conv', 'gemm', 'attn_bwd', 'attn', 'wgrad', 'conv_wgrad']
