@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Summarise the passes of tools/attn_pmc.sh: python tools/attn_pmc_json.py OUTDIR > attn_pmc.json"""
+"""Summarise the passes of tools/attn_pmc.sh / tools/sq_pmc.sh: python tools/attn_pmc_json.py OUTDIR [name-filter[,name-filter...]] [workload text] > pmc.json"""
 import collections
 import csv
 import glob
@@ -8,12 +8,14 @@ import os
 import sys
 
 out = sys.argv[1]
+filters = sys.argv[2].split(',') if len(sys.argv) > 2 else ['attn_']
+workload = sys.argv[3] if len(sys.argv) > 3 else ('tools/attn_pmc_driver.py (self-attention B=16: N4096 h8 d40, N4096 h5 d64; plain and pre-scaled-query kernels)')
 agg = collections.defaultdict(lambda: collections.defaultdict(float))
 disp = collections.defaultdict(set)
 for f in glob.glob(os.path.join(out, 'p*', '**', '*counter_collection.csv'), recursive=True):
     for r in csv.DictReader(open(f)):
         k = r['Kernel_Name']
-        if 'attn_' not in k:
+        if not any(x in k for x in filters):
             continue
         agg[k][r['Counter_Name']] += float(r['Counter_Value'])
         disp[(k, f)].add(r['Dispatch_Id'])
@@ -46,7 +48,6 @@ for k, c in sorted(agg.items()):
          'mfma_busy_cycles_per_simd_over_gui_active': g('SQ_VALU_MFMA_BUSY_CYCLES') / 1024.0 / g('GRBM_GUI_ACTIVE') if g('GRBM_GUI_ACTIVE') else None,
          'lds_bank_conflict_frac': g('SQ_LDS_BANK_CONFLICT') / g('SQ_LDS_IDX_ACTIVE') if g('SQ_LDS_IDX_ACTIVE') else None}
     res[k] = d
-print(json.dumps({'source': 'tools/attn_pmc.sh: rocprofv3 --pmc (two passes of 8 SQ counters, --kernel-trace only) + a --stats pass on tools/attn_pmc_driver.py '
-                            '(self-attention B=16: N4096 h8 d40, N4096 h5 d64; plain and pre-scaled-query kernels)',
+print(json.dumps({'source': 'rocprofv3 --pmc (two passes of 8 SQ counters, --kernel-trace only) + a --stats pass on ' + workload,
                   'units': 'SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* are quad-cycles summed over waves; SQ_VALU_MFMA_BUSY_CYCLES in cycles; per dispatch',
                   'kernels': res}, indent=1))
