@@ -46,6 +46,9 @@ for k, c in sorted(agg.items()):
          'profiled_avg_us': (sum(dur[k]) / len(dur[k]) / 1e3) if dur.get(k) else None,
          'effective_clock_ghz': (g('GRBM_GUI_ACTIVE') / (sum(dur[k]) / len(dur[k]))) if dur.get(k) and g('GRBM_GUI_ACTIVE') else None,
          'mfma_busy_cycles_per_simd_over_gui_active': g('SQ_VALU_MFMA_BUSY_CYCLES') / 1024.0 / g('GRBM_GUI_ACTIVE') if g('GRBM_GUI_ACTIVE') else None,
+         # GRBM_GUI_ACTIVE arrives summed over the 8 XCDs (the 'effective clock' above reads 14-19 GHz = 8 x 1.8-2.4): per-XCD corrected figures
+         'effective_clock_ghz_per_xcd': (g('GRBM_GUI_ACTIVE') / 8.0 / (sum(dur[k]) / len(dur[k]))) if dur.get(k) and g('GRBM_GUI_ACTIVE') else None,
+         'mfma_busy_frac_per_simd': g('SQ_VALU_MFMA_BUSY_CYCLES') / 1024.0 / (g('GRBM_GUI_ACTIVE') / 8.0) if g('GRBM_GUI_ACTIVE') else None,
          'lds_bank_conflict_frac': g('SQ_LDS_BANK_CONFLICT') / g('SQ_LDS_IDX_ACTIVE') if g('SQ_LDS_IDX_ACTIVE') else None}
     res[k] = d
 print(json.dumps({'source': 'rocprofv3 --pmc (two passes of 8 SQ counters, --kernel-trace only) + a --stats pass on ' + workload,
