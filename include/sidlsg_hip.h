@@ -71,6 +71,14 @@ int sidlsg_set_stream_workspace(void* stream, void* ptr, long long bytes);
  * same kernel (one extra MFMA against a vector of ones per dY fragment) instead of a separate column-sum pass. */
 int sidlsg_wgrad_bf16(const void* dY, int ldy, const void* A, int lda, float* dW, float* dBias, int M, int N, int K,
                       void* stream);
+/* The same with dW = (not +=), dBias still +=: for gradient storage whose previous contents are dead.  The fused optimizer
+ * (sidlsg_adam_ema, zero_grad = 0 on the weight ranges) leaves the weight gradients of a network un-zeroed and the first weight
+ * gradient after it overwrites them: 4 B / parameter of zero stores and 4 B / parameter of dW reads less per optimizer step.  Same
+ * summation order as the accumulating entry points on a zeroed dW: bit-identical results. */
+int sidlsg_wgrad_assign_bf16(const void* dY, int ldy, const void* A, int lda, float* dW, float* dBias, int M, int N, int K,
+                             void* stream);
+int sidlsg_conv3x3_wgrad_assign_bf16(const void* dY, int ldy, const void* X, int ldx, float* dW, float* dBias, int B, int H, int Wd,
+                                     int Cin, int Cout, int stride, int ups, void* stream);
 int sidlsg_debug_wgrad_blocks_per_cu(int which); /* host diagnostic: resident blocks per CU of the weight-gradient kernels (0: 128x128, 1: 160x128, 2: 160x160 tiles) */
 int sidlsg_conv3x3_wgrad_bf16(const void* dY, int ldy, const void* X, int ldx, float* dW, float* dBias, int B, int H, int Wd,
                               int Cin, int Cout, int stride, int ups, void* stream);

@@ -1832,6 +1832,7 @@ struct WgradParams {
     float* ws;        // [splits][N][K] slabs when splits > 1 and a workspace is available (else fp32 atomics)
     int nsplits;
     float* dB;        // optional: dB[n] += sum_m dY[m][n] (bias gradient), produced by the k-tile-0 blocks
+    int assign;       // dW = instead of dW +=: the caller knows dW holds nothing to keep (sidlsg_*wgrad_assign_bf16) -- no read of dW
 };
 
 DEVFN int wg_swz(int row) { return (row & 3) | (((row >> 3) & 1) << 2); }
@@ -1995,7 +1996,7 @@ __global__ __launch_bounds__(NTHREADS) void wgrad_bf16_kernel(WgradParams p) {
                 const int n = n0 + wn0 + 16 * i + lg * 4 + r;
                 if (n >= p.N) continue;
                 const size_t e = (size_t)n * p.K + k;
-                if (p.nsplits == 1) p.dW[e] += acc[i][j][r];                                  // sole owner of this element
+                if (p.nsplits == 1) p.dW[e] = p.assign ? acc[i][j][r] : p.dW[e] + acc[i][j][r];   // sole owner of this element
                 else if (p.ws) p.ws[(size_t)blockIdx.y * p.N * p.K + e] = acc[i][j][r];      // slab, reduced by wgrad_reduce_kernel
                 else unsafeAtomicAdd(p.dW + e, acc[i][j][r]);
             }
@@ -2241,7 +2242,7 @@ DEVFN void wgrad_v2_body(const WgradParams& p) {
         constexpr int LDW = TK + 4;
         float* img = reinterpret_cast<float*>(smem);
         float* dst = p.nsplits == 1 ? p.dW : p.ws + (size_t)split * p.N * p.K;
-        const bool accum = p.nsplits == 1;
+        const bool accum = p.nsplits == 1 && !p.assign;
 #pragma unroll
         for (int h = 0; h < 2; h++) {
             __syncthreads();                             // the ring (or the previous half image) is no longer read
@@ -2294,11 +2295,12 @@ template <int MODE>
 __global__ __launch_bounds__(NTHREADS, 2) void wgrad_v2w_kernel(WgradParams p) { wgrad_v2_body<MODE, 160, WG_T>(p); }
 __global__ __launch_bounds__(NTHREADS, 2) void wgrad_v2s_kernel(WgradParams p) { wgrad_v2_body<0, 160, 160>(p); }      // dense, 160 x 160 tiles
 
-// dW[i] += sum_s slab[s][i]
-__global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dW, size_t n, int splits) {
+// dW[i] += sum_s slab[s][i]  (assign: dW[i] = sum_s slab[s][i], summed in the same order from 0 -- bit-identical to the sum onto a zeroed dW)
+__global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dW, size_t n, int splits, int assign) {
     const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
     if (i + 4 <= n) {
-        f32x4 v = *reinterpret_cast<const f32x4*>(dW + i);
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (!assign) v = *reinterpret_cast<const f32x4*>(dW + i);
         int sidx = 0;
         for (; sidx + 3 < splits; sidx += 4) {          // four independent slab loads in flight, fixed summation order
             const f32x4 a = *reinterpret_cast<const f32x4*>(ws + (size_t)sidx * n + i);
@@ -2311,7 +2313,7 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restr
         *reinterpret_cast<f32x4*>(dW + i) = v;
     } else {
         for (size_t j = i; j < n; j++) {
-            float v = dW[j];
+            float v = assign ? 0.f : dW[j];
             for (int sidx = 0; sidx < splits; sidx++) v += ws[(size_t)sidx * n + j];
             dW[j] = v;
         }
@@ -2381,6 +2383,9 @@ static int launch_wgrad(WgradParams p, hipStream_t s) {
     }
     p.m_per_split = mps;
     p.nsplits = splits;
+    if (p.assign && splits > 1 && !p.ws) {          // fp32-atomic fallback (no slab space): the atomics need a zeroed target
+        if (hipMemsetAsync(p.dW, 0, (size_t)nk * sizeof(float), s) != hipSuccess) return sidlsg_last_error();
+    }
     if (v2) {
         const size_t lds = (size_t)2 * WG_MB * (tn + tk) * sizeof(bf16);
         static bool attr_done = false;
@@ -2396,7 +2401,7 @@ static int launch_wgrad(WgradParams p, hipStream_t s) {
     } else
     SIDLSG_LAUNCH((wgrad_bf16_kernel<MODE>), dim3(tiles, splits), dim3(NTHREADS), 0, s, p);
     if (splits > 1 && p.ws)
-        SIDLSG_LAUNCH(wgrad_reduce_kernel, dim3((unsigned)((nk / 4 + 256) / 256)), dim3(256), 0, s, p.ws, p.dW, (size_t)nk, splits);
+        SIDLSG_LAUNCH(wgrad_reduce_kernel, dim3((unsigned)((nk / 4 + 256) / 256)), dim3(256), 0, s, p.ws, p.dW, (size_t)nk, splits, p.assign);
     return sidlsg_last_error();
 }
 
@@ -2547,23 +2552,33 @@ int sidlsg_conv3x3_bf16(const void* X, int ldx, const void* W, void* Y, int ldc,
 }
 
 // dW[N][K] += dY[M][N]^T A[M][K]   (dense: Linear / 1x1 conv weight gradient; fp32 accumulate)
-int sidlsg_wgrad_bf16(const void* dY, int ldy, const void* A, int lda, float* dW, float* dBias, int M, int N, int K, void* stream) {
+static int wgrad_dense_impl(const void* dY, int ldy, const void* A, int lda, float* dW, float* dBias, int M, int N, int K, int assign, void* stream) {
     if (M <= 0 || N <= 0 || K <= 0 || (K & 7) || (lda & 7) || !dY || !A || !dW) return SIDLSG_EINVAL;
     WgradParams p{};
-    p.dY = (const bf16*)dY; p.A = (const bf16*)A; p.dW = dW; p.dB = dBias; p.M = M; p.N = N; p.K = K; p.ldy = ldy; p.lda = lda;
+    p.dY = (const bf16*)dY; p.A = (const bf16*)A; p.dW = dW; p.dB = dBias; p.M = M; p.N = N; p.K = K; p.ldy = ldy; p.lda = lda; p.assign = assign;
     const unsigned long long ab = ((unsigned long long)(M - 1) * lda + K) * 2ull, yb = ((unsigned long long)(M - 1) * ldy + N) * 2ull;
     if (!fits31(ab) || !fits31(yb)) return SIDLSG_EINVAL;
     p.a_bytes = (unsigned)ab; p.y_bytes = (unsigned)yb;
-    SidlsgTraceScope ts(SIDLSG_FAM_WGRAD, 2.0 * M * (double)N * K, 2.0 * ((double)M * N + (double)M * K) + 8.0 * N * K);      // dY, A read once; dW read + written (fp32)
+    SidlsgTraceScope ts(SIDLSG_FAM_WGRAD, 2.0 * M * (double)N * K, 2.0 * ((double)M * N + (double)M * K) + (assign ? 4.0 : 8.0) * N * K);      // dY, A read once; dW (read +) written (fp32)
     return launch_wgrad<0>(p, (hipStream_t)stream);
+}
+int sidlsg_wgrad_bf16(const void* dY, int ldy, const void* A, int lda, float* dW, float* dBias, int M, int N, int K, void* stream) {
+    return wgrad_dense_impl(dY, ldy, A, lda, dW, dBias, M, N, K, 0, stream);
+}
+// dW = dY^T A (dBias still +=): for a gradient buffer whose previous contents are dead -- the fused optimizer leaves the weight
+// gradients un-zeroed (sidlsg_adam_ema with zero_grad = 0 on those ranges) and the first weight gradient after it overwrites them,
+// which saves the optimizer's 4 B / parameter of zero stores and this kernel's (or its reduction's) 4 B / parameter read of dW.
+// Same summation order as the accumulating entry point on a zeroed dW: bit-identical results.
+int sidlsg_wgrad_assign_bf16(const void* dY, int ldy, const void* A, int lda, float* dW, float* dBias, int M, int N, int K, void* stream) {
+    return wgrad_dense_impl(dY, ldy, A, lda, dW, dBias, M, N, K, 1, stream);
 }
 
 // dW[Cout][3][3][Cin] += conv3x3 weight gradient (same geometry arguments as sidlsg_conv3x3_bf16)
-int sidlsg_conv3x3_wgrad_bf16(const void* dY, int ldy, const void* X, int ldx, float* dW, float* dBias, int B, int H, int Wd,
-                              int Cin, int Cout, int stride, int ups, void* stream) {
+static int wgrad_conv_impl(const void* dY, int ldy, const void* X, int ldx, float* dW, float* dBias, int B, int H, int Wd,
+                           int Cin, int Cout, int stride, int ups, int assign, void* stream) {
     if ((stride != 1 && stride != 2) || (Cin & 7) || (ldx & 7) || !dY || !X || !dW) return SIDLSG_EINVAL;
     WgradParams p{};
-    p.dY = (const bf16*)dY; p.A = (const bf16*)X; p.dW = dW; p.dB = dBias; p.ldy = ldy; p.lda = ldx;
+    p.dY = (const bf16*)dY; p.A = (const bf16*)X; p.dW = dW; p.dB = dBias; p.ldy = ldy; p.lda = ldx; p.assign = assign;
     p.H = H; p.Wd = Wd; p.Cin = Cin; p.stride = stride; p.ups = ups;
     p.Ho = (H + 2 - 3) / stride + 1; p.Wo = (Wd + 2 - 3) / stride + 1;
     p.M = B * p.Ho * p.Wo; p.N = Cout; p.K = 9 * Cin;
@@ -2572,8 +2587,16 @@ int sidlsg_conv3x3_wgrad_bf16(const void* dY, int ldy, const void* X, int ldx, f
     if (!fits31(ab) || !fits31(yb)) return SIDLSG_EINVAL;
     p.a_bytes = (unsigned)ab; p.y_bytes = (unsigned)yb;
     SidlsgTraceScope ts(SIDLSG_FAM_CONV_WGRAD, 2.0 * p.M * (double)p.N * p.K,
-                        2.0 * ((double)p.M * p.N + (double)B * Hs * Ws * Cin) + 8.0 * p.N * p.K);
+                        2.0 * ((double)p.M * p.N + (double)B * Hs * Ws * Cin) + (assign ? 4.0 : 8.0) * p.N * p.K);
     return launch_wgrad<1>(p, (hipStream_t)stream);
+}
+int sidlsg_conv3x3_wgrad_bf16(const void* dY, int ldy, const void* X, int ldx, float* dW, float* dBias, int B, int H, int Wd,
+                              int Cin, int Cout, int stride, int ups, void* stream) {
+    return wgrad_conv_impl(dY, ldy, X, ldx, dW, dBias, B, H, Wd, Cin, Cout, stride, ups, 0, stream);
+}
+int sidlsg_conv3x3_wgrad_assign_bf16(const void* dY, int ldy, const void* X, int ldx, float* dW, float* dBias, int B, int H, int Wd,
+                                     int Cin, int Cout, int stride, int ups, void* stream) {
+    return wgrad_conv_impl(dY, ldy, X, ldx, dW, dBias, B, H, Wd, Cin, Cout, stride, ups, 1, stream);
 }
 
 // ---- fp8-weight contractions (see gemm_fp8w_kernel).  W8: e4m3 bytes [N][K]; wscale: fp32 [N].  K % 16 == 0.

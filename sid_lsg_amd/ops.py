@@ -70,6 +70,21 @@ def _wants_grad(p):
     return True
 
 
+def _take_assign(weight, dtype):
+    """True when this weight gradient may OVERWRITE `weight.grad`: the fused optimizer left the view un-zeroed after its last step
+    and marked the parameter (`_grad_assign`, optim.FusedAdamEMA with a network that has an assign plan); the first weight gradient
+    after that step takes the mark.  Saves the optimizer's zero stores and the read of dW here (sidlsg_*wgrad_assign_bf16: bit-identical
+    to accumulating onto zeros).  A launch that cannot overwrite (fp32 activations) zeroes the view instead and accumulates."""
+    if not getattr(weight, '_grad_assign', False):
+        return False
+    weight._grad_assign = False
+    if dtype != BF16:
+        weight.grad.zero_()
+        return False
+    return True
+
+
+
 # ------------------------------------------------------------------------------------------------
 _workspace = {}
 
@@ -379,9 +394,9 @@ class _Linear(torch.autograd.Function):
         fused_b = need_b and not need_rv and _wants_grad(weight) and x.dtype == BF16
         if _wants_grad(weight):
             M, K = x.shape
+            wg = _fn('wgrad_assign', x.dtype, '_bf16') if _take_assign(weight, x.dtype) else _fn('wgrad', x.dtype, '_bf16')
             with _OnWgradStream(dy, x):
-                _fn('wgrad', x.dtype, '_bf16')(_p(dy), dy.stride(0), _p(x), x.stride(0), _p(weight.grad), _p(bias.grad) if fused_b else None,
-                                               M, weight.shape[0], K, _s())
+                wg(_p(dy), dy.stride(0), _p(x), x.stride(0), _p(weight.grad), _p(bias.grad) if fused_b else None, M, weight.shape[0], K, _s())
         drv = None
         if need_rv:
             drv = colsum(dy, ctx.rpb, per_batch=True, total=bias.grad if need_b else None)
@@ -472,6 +487,8 @@ class _Conv3x3(torch.autograd.Function):
         if _wants_grad(weight):
             H, W = (2 * x.shape[1], 2 * x.shape[2]) if ups else (x.shape[1], x.shape[2])
             wgrad = _fn('conv3x3_wgrad', x.dtype, '_bf16')
+            if not padded and _take_assign(weight, x.dtype):
+                wgrad = lib.sidlsg_conv3x3_wgrad_assign_bf16
             if not padded:
                 with _OnWgradStream(dy, x):
                     wgrad(_p(dy), Cout, _p(x), Cin, _p(weight.grad), _p(bias.grad) if fused_b else None,
@@ -1020,9 +1037,9 @@ class _LinearGEGLU(torch.autograd.Function):
         if _wants_grad(weight):
             M, K = x.shape
             need_b = _wants_grad(bias)
+            wg = lib.sidlsg_wgrad_assign_bf16 if _take_assign(weight, BF16) else lib.sidlsg_wgrad_bf16
             with _OnWgradStream(dh, x):
-                lib.sidlsg_wgrad_bf16(_p(dh), dh.stride(0), _p(x), x.stride(0), _p(weight.grad), _p(bias.grad) if need_b else None,
-                                      M, weight.shape[0], K, _s())
+                wg(_p(dh), dh.stride(0), _p(x), x.stride(0), _p(weight.grad), _p(bias.grad) if need_b else None, M, weight.shape[0], K, _s())
         elif _wants_grad(bias):
             colsum(dh, dh.shape[0], total=bias.grad)
         return dx, None, None, None, None, None

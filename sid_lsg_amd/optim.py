@@ -14,6 +14,9 @@ from . import ops
 from ._lib import lib
 
 
+FLAT_LAYOUT = 2     # parameter order of HipUNet2DCondition's flat buffers (2: GEMM / conv weights first inside each gradient segment)
+
+
 def _flat_of(tensors):
     tensors = list(tensors)
     st = tensors[0].untyped_storage()
@@ -70,10 +73,28 @@ class FusedAdamEMA:
         precondition of its next refresh_compute_weights(cast=False)."""
         self.ema, self.w16, self._owner = ema, w16, owner
         self._covered = 0
+        # Weight ranges whose gradients need no zeroing (HipUNet2DCondition.assign_plan): the first weight gradient after a step
+        # OVERWRITES its view (ops._take_assign), so this kernel skips its 4 B / parameter of zero stores there and the weight-gradient
+        # kernels their read of dW.  parts: sorted cover of the flat buffer, (lo, hi, [parameters] | None = small parameters: zeroed)
+        self._parts = None
+        plan = owner.assign_plan() if owner is not None and hasattr(owner, 'assign_plan') else None
+        if plan is not None and self.grad is not None and owner.flat_grads is not None and \
+                owner.flat_grads.data_ptr() == self.grad.data_ptr() and owner.flat_grads.numel() == self.grad.numel():
+            ranges, ws = plan
+            parts, pos = [], 0
+            for lo, hi in sorted(ranges):
+                if lo > pos:
+                    parts.append((pos, lo, None))
+                parts.append((lo, hi, [w for o, w in ws if lo <= o < hi]))
+                pos = hi
+            if pos < self.flat.numel():
+                parts.append((pos, self.flat.numel(), None))
+            self._parts = parts
         return self
 
     _owner = None
     _covered = 0
+    _parts = None
 
     def _w16_written(self, n):
         if self.w16 is None or self._owner is None:
@@ -84,7 +105,7 @@ class FusedAdamEMA:
             self._owner.mark_w16_rewritten()
 
     def zero_grad(self, set_to_none=False):
-        self.grad.zero_()   # normally unnecessary: step() zeroes the gradient buffer
+        self.grad.zero_()   # normally unnecessary: step() zeroes the gradient buffer (or leaves weight ranges to be overwritten)
 
     def set_hyper(self, ema_beta=0.0):
         """Writes the step's scalars to device memory (outside any captured graph)."""
@@ -103,11 +124,8 @@ class FusedAdamEMA:
         self._hyper_evt[k] = evt
 
     def launch(self, use_ema=True, zero_grad=True):
-        lib.sidlsg_adam_ema(self.flat.data_ptr(), self.grad.data_ptr(), ops._p(self.exp_avg), self.exp_avg_sq.data_ptr(),
-                            ops._p(self.ema) if use_ema else None, ops._p(self.w16), self.hyper.data_ptr(), self.flat.numel(),
-                            1 if zero_grad else 0, ops._s())
         self._covered = 0
-        self._w16_written(self.flat.numel())
+        self._launch_parts(0, self.flat.numel(), use_ema, zero_grad)
 
     def launch_range(self, lo, hi, use_ema=True, zero_grad=True):
         """The same kernel on elements [lo, hi) of the flat buffers (the update is elementwise: any partition of the buffer
@@ -117,6 +135,26 @@ class FusedAdamEMA:
             return
         if lo % 4:
             raise ValueError('range start must be a multiple of 4 elements (16-byte vector accesses)')
+        self._launch_parts(lo, hi, use_ema, zero_grad)
+
+    def _launch_parts(self, lo, hi, use_ema, zero_grad):
+        if self._parts is None or not zero_grad:
+            return self._kernel(lo, hi, use_ema, zero_grad)
+        for a, b, ws in self._parts:
+            s, e = max(a, lo), min(b, hi)
+            if e <= s:
+                continue
+            if ws is None or s != a or e != b:        # small parameters (or a weight range cut by the caller): zeroed as ever
+                self._kernel(s, e, use_ema, True)
+                continue
+            for w in ws:
+                if getattr(w, '_grad_assign', False) and w.grad is not None:
+                    w.grad.zero_()                    # no weight gradient since the last step took the mark: this step's gradient is zero
+            self._kernel(s, e, use_ema, False)
+            for w in ws:
+                w._grad_assign = True
+
+    def _kernel(self, lo, hi, use_ema, zero_grad):
         off = lambda t, sz: None if t is None else t.data_ptr() + sz * lo      # noqa: E731
         lib.sidlsg_adam_ema(off(self.flat, 4), off(self.grad, 4), off(self.exp_avg, 4), off(self.exp_avg_sq, 4),
                             off(self.ema, 4) if use_ema else None, off(self.w16, 2), self.hyper.data_ptr(), hi - lo,
@@ -141,9 +179,14 @@ class FusedAdamEMA:
 
     def state_dict(self):
         return dict(step=self.step_count, exp_avg_sq=self.exp_avg_sq, exp_avg=self.exp_avg, lr=self.lr, betas=self.betas,
-                    eps=self.eps, weight_decay=self.weight_decay)
+                    eps=self.eps, weight_decay=self.weight_decay, flat_layout=FLAT_LAYOUT)
 
     def load_state_dict(self, sd):
+        # the moments are stored in the order of the network's flat buffer: a file written under another parameter order would load
+        # without an error and pair every parameter with some other parameter's second moment
+        if sd.get('flat_layout', 1) != FLAT_LAYOUT:
+            raise ValueError(f"optimizer state of flat-buffer layout {sd.get('flat_layout', 1)}, this build uses layout {FLAT_LAYOUT} "
+                             '(weights first inside each gradient segment): restart the optimizer state or convert the file')
         self.step_count = int(sd['step'])
         self.exp_avg_sq.copy_(sd['exp_avg_sq'])
         if self.exp_avg is not None and sd.get('exp_avg') is not None:

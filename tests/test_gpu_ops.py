@@ -123,6 +123,43 @@ def test_wgrad_dense(dev, M, N, K):
     close(dw2, ref, 2e-3, 'wgrad (no bias)')
 
 
+@pytest.mark.parametrize('M,N,K', [(512, 128, 128), (1000, 320, 72), (333, 8, 320), (8192, 960, 320), (65536, 320, 320), (100, 2560, 320),
+                                   (16384, 1280, 1280), (700, 12, 64), (9000, 20, 128)])      # last two: the register-staged kernel (N % 8 != 0)
+def test_wgrad_assign_is_bit_equal_to_accumulating_onto_zeros(dev, M, N, K):
+    """sidlsg_wgrad_assign_bf16 / sidlsg_conv3x3_wgrad_assign_bf16 overwrite dW (whatever it held) with exactly what the accumulating
+    entry points leave on a zeroed dW: one-split launches, slab reductions and the unaligned kernel alike; dBias still accumulates."""
+    from sid_lsg_amd import ops
+    from sid_lsg_amd._lib import lib
+    from sid_lsg_amd.ops import _p, _s
+    ops.ensure_workspace(dev)      # pixel-split partial sums through slabs (deterministic); without a workspace both entry points use fp32 atomics
+    dyd, ad = rnd(M, N, seed=1).to(dev), rnd(M, K, seed=2).to(dev)
+    ref = torch.zeros((N, K), device=dev, dtype=F32)
+    lib.sidlsg_wgrad_bf16(_p(dyd), N, _p(ad), K, _p(ref), None, M, N, K, _s())
+    got = torch.full((N, K), float('nan'), device=dev, dtype=F32)
+    db = torch.full((N,), 0.25, device=dev, dtype=F32)
+    lib.sidlsg_wgrad_assign_bf16(_p(dyd), N, _p(ad), K, _p(got), _p(db), M, N, K, _s())
+    assert torch.equal(got, ref)
+    close(db - 0.25, dyd.float().sum(0).cpu(), 2e-3, 'bias gradient still accumulates')
+
+
+@pytest.mark.parametrize('B,H,W,Cin,Cout,stride,ups', [(1, 64, 64, 320, 320, 1, 0), (2, 16, 16, 640, 640, 2, 0), (1, 16, 16, 320, 640, 1, 1),
+                                                       (3, 9, 7, 72, 40, 2, 0), (2, 8, 8, 1280, 320, 1, 0)])
+def test_conv_wgrad_assign_is_bit_equal_to_accumulating_onto_zeros(dev, B, H, W, Cin, Cout, stride, ups):
+    from sid_lsg_amd import ops
+    from sid_lsg_amd._lib import lib
+    from sid_lsg_amd.ops import _p, _s
+    ops.ensure_workspace(dev)
+    x = rnd(B, H, W, Cin, seed=1).to(dev)
+    Hl, Wl = (2 * H, 2 * W) if ups else (H, W)
+    Ho, Wo = (Hl + 2 - 3) // stride + 1, (Wl + 2 - 3) // stride + 1
+    dy = rnd(B, Ho, Wo, Cout, seed=2).to(dev)
+    ref = torch.zeros((Cout, 9 * Cin), device=dev, dtype=F32)
+    lib.sidlsg_conv3x3_wgrad_bf16(_p(dy), Cout, _p(x), Cin, _p(ref), None, B, Hl, Wl, Cin, Cout, stride, ups, _s())
+    got = torch.full((Cout, 9 * Cin), float('nan'), device=dev, dtype=F32)
+    lib.sidlsg_conv3x3_wgrad_assign_bf16(_p(dy), Cout, _p(x), Cin, _p(got), None, B, Hl, Wl, Cin, Cout, stride, ups, _s())
+    assert torch.equal(got, ref)
+
+
 @pytest.mark.parametrize('B,H,W,Cin,Cout,stride,ups', CONV_CASES)
 def test_conv_autograd(dev, B, H, W, Cin, Cout, stride, ups):
     """dx, dW, db, d(rowvec), d(res) of the conv op against torch autograd."""

@@ -982,6 +982,72 @@ def test_side_streams_change_nothing_in_the_step(dev):
         assert float(d.max()) <= 2.01 * lr * iters and frac_same > 0.98
 
 
+def test_unzeroed_weight_gradients_change_nothing_in_the_step(dev, monkeypatch):
+    """Round 4: the fused optimizer leaves the GEMM / conv weight gradients un-zeroed and the first weight gradient after a step
+    overwrites them (HipUNet2DCondition.assign_plan, ops._take_assign, sidlsg_*wgrad_assign_bf16).  Three iterations with the
+    scheme on and off (SIDLSG_GRAD_ASSIGN=0: every gradient zeroed by the optimizer kernel, every weight gradient accumulating)
+    must agree like two runs of one configuration do (fp32-atomics ordering noise of the bias / norm gradients only)."""
+    from sid_lsg_amd.optim import FusedAdamEMA
+    from sid_lsg_amd.scheduler import DDPMScheduler
+    from sid_lsg_amd.sid_step import SiDStep
+    from sid_lsg_amd.unet import CONFIGS, HConv3x3, HLinear, HipUNet2DCondition
+    cfg_name, lat, b, lr, iters = 'tiny40', 16, 4, 2e-5, 3
+    cfg = CONFIGS[cfg_name]
+    results = {}
+    for on in (False, True):
+        monkeypatch.setenv('SIDLSG_GRAD_ASSIGN', '1' if on else '0')
+        phi = HipUNet2DCondition(cfg).materialize(dev, seed=1)
+        psi = HipUNet2DCondition(cfg).materialize(dev, seed=2)
+        G, G_ema = phi.clone_network(), phi.clone_network(with_grad_buffers=False)
+        opt_f = FusedAdamEMA(psi.parameters(), lr=lr, betas=(0.0, 0.999), eps=1e-8)
+        opt_g = FusedAdamEMA(G.parameters(), lr=lr, betas=(0.0, 0.999), eps=1e-8)
+        step = SiDStep(G, psi, phi, G_ema, DDPMScheduler().to(dev), opt_f, opt_g, alpha=1.0, cfg_train_fake=1.5, cfg_eval_fake=1.5,
+                       cfg_eval_real=1.5, batch_gpu_total=b, init_timestep=625)
+        assert (opt_f._parts is not None) == on and (opt_g._parts is not None) == on
+        gen = torch.Generator().manual_seed(3)
+        losses = []
+        for it in range(iters):
+            inputs = {ph: [dict(z=torch.randn(b, 4, lat, lat, generator=gen).to(dev), noise=torch.randn(b, 4, lat, lat, generator=gen).to(dev),
+                                t=torch.randint(20, 980, (b,), generator=gen).to(dev),
+                                cond=torch.randn(b, cfg.text_len, cfg.cross_attention_dim, generator=gen).to(dev).to(BF16),
+                                uncond=torch.randn(b, cfg.text_len, cfg.cross_attention_dim, generator=gen).to(dev).to(BF16))]
+                      for ph in ('A', 'B')}
+            lf, lg = step.iteration(inputs, ema_beta=0.9)
+            losses += [float(lf), float(lg)]
+        torch.cuda.synchronize()
+        results[on] = dict(losses=np.array(losses), G=G.flat_params.clone(), psi=psi.flat_params.clone(), ema=G_ema.flat_params.clone())
+        if on:
+            # the plan: weight ranges hold only GEMM / conv weights, every such parameter is marked for overwriting after the step,
+            # the gradients of the small parameters are zero and those of the weights are not
+            ranges, ws = psi.assign_plan()
+            fl = psi._flat
+            big = torch.zeros(fl['total'], dtype=torch.bool)
+            for lo, hi in ranges:
+                big[lo:hi] = True
+            for name, p in psi.named_parameters():
+                mod = dict(psi.named_modules())[name.rsplit('.', 1)[0]]
+                o = fl['offs'][name]
+                is_w = name.endswith('.weight') and isinstance(mod, (HLinear, HConv3x3)) and p.shape[0] % 8 == 0 and p.shape[1] % 8 == 0
+                assert bool(big[o]) == is_w, name
+            assert all(getattr(w, '_grad_assign', False) for _, w in ws)
+            g = psi.flat_grads
+            assert float(g[~big.to(dev)].abs().max()) == 0.0 and float(g[big.to(dev)].abs().max()) > 0.0
+            # a step without any backward in between: the marks are still set -> the stale gradients are zeroed, not applied again
+            before = psi.flat_params.clone()
+            opt_f.step()
+            torch.cuda.synchronize()
+            assert torch.equal(before, psi.flat_params) and float(psi.flat_grads.abs().max()) == 0.0
+    a, bb = results[False], results[True]
+    rel = np.abs(a['losses'] - bb['losses']) / np.abs(a['losses'])
+    print(f'losses zeroed {a["losses"]} overwritten {bb["losses"]} rel {rel}')
+    assert rel.max() < 2e-4
+    for k in ('G', 'psi', 'ema'):
+        d = (a[k] - bb[k]).abs()
+        frac_same = float((d < 1e-9).float().mean())
+        print(f'{k}: {frac_same:.5f} of the weights bit-equal, max difference {float(d.max()):.2e} (lr {lr})')
+        assert float(d.max()) <= 2.01 * lr * iters and frac_same > 0.98
+
+
 def _graph_vs_eager(dev, reducer_factory=None, iters=4):
     """Runs `iters` iterations twice from identical initial state and inputs: eagerly and through SiDStep.iteration_graphed
     (first call eager, second captures + replays, later ones replay).  Returns the two result dicts."""
