@@ -38,7 +38,24 @@ struct AttnParams {
     long long bsq, bsk, bsv, bso;  // batch strides (elements)
     float scale2;                  // d^-0.5 * log2(e)
     float scale;                   // d^-0.5
+    int xcd;                       // 1: blocks renumbered so that all blocks of one (batch, head) run on ONE XCD (attn_block_coords)
 };
+
+// Hardware workgroup L (x fastest) runs on XCD L % 8, so the query / key blocks of one (batch, head) -- neighbours in x -- were spread
+// over all 8 XCDs and each XCD's L2 fetched that head's whole K, V (forward, dQ pass) or Q, dO (dK/dV pass) for itself: the HBM-side traffic
+// of the N = 4096 self-attention was 3.7x (forward) / 4.9x (backward) the algorithmic bytes (profiles/r04_traffic_attn.json).  With the
+// XCD-contiguous renumbering of the GEMM kernels an XCD works through whole heads: the streamed operand is fetched once per head.
+DEVFN void attn_block_coords(const AttnParams& p, int& bx, int& h, int& b) {
+    bx = blockIdx.x; h = blockIdx.y; b = blockIdx.z;
+    if (!p.xcd) return;
+    const unsigned nx = gridDim.x, ny = gridDim.y, total = nx * ny * gridDim.z;
+    unsigned L = blockIdx.x + nx * (blockIdx.y + ny * blockIdx.z);
+    const unsigned q = total >> 3, r = total & 7, xcd = L & 7, idx = L >> 3;
+    L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    bx = (int)(L % nx);
+    const unsigned t = L / nx;
+    h = (int)(t % ny); b = (int)(t / ny);
+}
 
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 constexpr unsigned A_OOB = 0x80000000u;
@@ -289,9 +306,11 @@ __global__ __launch_bounds__(256, (DP <= 48 && MODE == 0) ? 4 : ((DP <= 48 && MO
     constexpr int TE = lds_tile_elems<DP, AT_KT>();
     __shared__ __attribute__((aligned(16))) bf16 Ks[2][TE];
     __shared__ __attribute__((aligned(16))) bf16 Vs[2][TE];
-    const int b = blockIdx.z, h = blockIdx.y;
+    int bx_, h_, b_;
+    attn_block_coords(p, bx_, h_, b_);
+    const int b = b_, h = h_;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lg = lane >> 4;
-    const int q0 = (blockIdx.x * 4 + wave) * (QT * 16);
+    const int q0 = (bx_ * 4 + wave) * (QT * 16);
     const bf16* Qb = p.Q + b * p.bsq + (long long)h * p.D;
     const __amdgpu_buffer_rsrc_t rk = mk_rsrc_rows(p.K + b * p.bsk + (long long)h * p.D, p.Nk, p.ldk, p.D);
     const __amdgpu_buffer_rsrc_t rv = mk_rsrc_rows(p.V + b * p.bsv + (long long)h * p.D, p.Nk, p.ldv, p.D);
@@ -592,9 +611,11 @@ __global__ __launch_bounds__(256) void attn_dkdv_kernel(AttnParams p) {
     __shared__ __attribute__((aligned(16))) float lse_s[2][ST], dl_s[2][ST];
 #pragma unroll
     for (int i = 0; i < 2; i++) { lds_tile_init<DP, ST>(Qs2[i]); lds_tile_init<DP, ST>(dOs2[i]); }
-    const int b = blockIdx.z, h = blockIdx.y;
+    int bx_, h_, b_;
+    attn_block_coords(p, bx_, h_, b_);
+    const int b = b_, h = h_;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lg = lane >> 4;
-    const int key0 = (blockIdx.x * 4 + wave) * (KT * 16);
+    const int key0 = (bx_ * 4 + wave) * (KT * 16);
     const __amdgpu_buffer_rsrc_t rq = mk_rsrc_rows(p.Q + b * p.bsq + (long long)h * p.D, p.Nq, p.ldq, p.D);
     const __amdgpu_buffer_rsrc_t rdo = mk_rsrc_rows(p.dO + b * p.bso + (long long)h * p.D, p.Nq, p.ldo, p.D);
     const float* LSEb = p.LSE + ((long long)b * p.H + h) * p.Nq;
@@ -759,8 +780,21 @@ template <int DP, int QT, int KT, bool PS>
 static int launch_attn(const AttnParams& p, int mode, hipStream_t s) {
     return mode == 2 ? launch_attn_dkdv<DP, KT, PS>(p, s) : launch_attn_q<DP, QT, PS>(p, mode, s);
 }
+// Which passes renumber (measured, MI355X, B = 16, rocprofv3 per-kernel averages with / without): forward 314 -> 312 us (N 4096, d 40), 46.2 -> 44.0
+// (N 1024, d 80), 19.0 -> 17.0 (N 256, d 160); dQ pass 816 -> 827 / 91.4 -> 86.7 / 26.6 -> 25.0; dK/dV pass 1110 -> 1174 / 119 -> 115 / 36.9 -> 30.5:
+// the backward passes of the 4096-token layers lose (all resident blocks of an XCD then walk the same Q / dO rows in lockstep and meet in
+// the same L2 channels), everything else gains -> forward always, backward passes up to 1024 tokens.  HBM-side bytes per call of the
+// micro-benchmark with everything renumbered: forward 364 -> 107 MB (3.66x -> 1.08x the algorithmic bytes), backward 1134 -> 436 MB (4.9x -> 1.9x).
+// SIDLSG_ATTN_XCD: bit mask of the passes that may renumber (1 forward, 2 dQ, 4 dK/dV; 8: also the long backward passes); default 7.
+static int attn_xcd_on(int mode, const AttnParams& p) {
+    static const int mask = getenv("SIDLSG_ATTN_XCD") ? atoi(getenv("SIDLSG_ATTN_XCD")) : 7;
+    if (!((mask >> mode) & 1)) return 0;
+    return mode == 0 || (mask & 8) || (p.Nq <= 1024 && p.Nk <= 1024);
+}
 template <bool PS>
-static int dispatch_attn(const AttnParams& p, int mode, hipStream_t s) {
+static int dispatch_attn(const AttnParams& p_in, int mode, hipStream_t s) {
+    AttnParams p = p_in;
+    p.xcd = attn_xcd_on(mode, p);
     if (p.D % 8 || p.D <= 0 || p.D > 160) return SIDLSG_EINVAL;
     const int dp = (p.D + 15) / 16 * 16;
     // 32 queries per wave (forward / dQ) and 16 keys per wave (dK/dV) keep 2-3 blocks per CU resident; 64 queries per
