@@ -528,7 +528,7 @@ def main():
                    'attn': f'flash attention forward, self + cross ({ATTN_FWD}: attn_q_kernel<*,*,0,*,*>)',
                    'attn_bwd': f'flash attention backward ({ATTN_BWD}: attn_q_kernel<*,*,1,*,*> + attn_dkdv_kernel)',
                    'wgrad': 'dense weight gradient dW += dY^T A (wgrad_v2_kernel<0>, wgrad_v2s_kernel + wgrad_reduce_kernel)',
-                   'conv_wgrad': 'conv3x3 weight gradient (wgrad_v2_kernel<1>, wgrad_v2w_kernel<1> + wgrad_reduce_kernel)',
+                   'conv_wgrad': 'conv3x3 weight gradient (wgrad_v2f_kernel / wgrad_v2wf_kernel, wgrad_v2_kernel<1>, wgrad_v2w_kernel<1> + wgrad_reduce_kernel)',
                    'gn': 'GroupNorm(32)+SiLU forward (gn_stats_kernel + gn_apply_kernel, one entry point)',
                    'gn_bwd': 'GroupNorm(32)+SiLU backward (gn_bwd_stats_kernel + gn_bwd_apply_kernel [+ colsum_reduce2_kernel])',
                    'ln': 'LayerNorm forward (ln_fwd_kernel)', 'ln_bwd': 'LayerNorm backward (ln_bwd_kernel [+ colsum_reduce2_kernel])'}

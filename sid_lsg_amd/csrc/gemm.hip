@@ -1832,6 +1832,7 @@ struct WgradParams {
     float* ws;        // [splits][N][K] slabs when splits > 1 and a workspace is available (else fp32 atomics)
     int nsplits;
     float* dB;        // optional: dB[n] += sum_m dY[m][n] (bias gradient), produced by the k-tile-0 blocks
+    int slow_gather;  // conv: 1 = per-stage recomputation of the gather offsets also where the constant-advance path applies (A/B switch)
     int assign;       // dW = instead of dW +=: the caller knows dW holds nothing to keep (sidlsg_*wgrad_assign_bf16) -- no read of dW
 };
 
@@ -2020,7 +2021,7 @@ template <int TN> DEVFN int wg_yswz(int row) { return TN == 128 ? wg_swz(row) : 
 // TK = k (X column) extent of the tile: 128, or (dense only, round 4) 160 -- with N and K multiples of 160 a 160 x 160 tile wastes no
 // MFMA work on padding (320 = 2 x 160 instead of 3 x 128) and the operands are re-read 2 + 2 instead of 3 + 3 times per split
 // (L2 -> LDS bytes -44 % at 320 x 320); the X tile is then staged exactly like the dY tile (same chunk grid, same swizzle).
-template <int MODE, int TN, int TK>
+template <int MODE, int TN, int TK, bool CF = false>      // CF: conv with constant-advance gather offsets (see fastc below; the host checks the conditions)
 DEVFN void wgrad_v2_body(const WgradParams& p) {
     static_assert(TK == WG_T || (TK == 160 && MODE == 0), "160-wide k tiles: dense operands only");
     constexpr int KI = TK / 32;             // 16-column X fragments per wave (wave = TN/2 x TK/2 of the tile)
@@ -2100,6 +2101,27 @@ DEVFN void wgrad_v2_body(const WgradParams& p) {
             pwo[i] = rem - pho[i] * p.Wo;
         }
     }
+    // conv fast path (round 4): when a stage's 64 pixels are whole image rows or whole samples (Wo | 64 or Ho * Wo | 64: every SD shape),
+    // the stride divides the image (H == Ho * stride) and there is no fused upsampling, the input row of a lane's pixel advances by the
+    // SAME number of rows every stage -- also across sample boundaries -- so the gather offset is a per-lane constant plus a wave-uniform
+    // soffset (as in the dense kernel) and only the vertical halo test remains per stage: ~9 instead of ~40 VALU per row and stage
+    // (the conv weight gradient ran 5.3 VALU instructions per MFMA, profiles/r04_wgrad_sq_pmc.json).  The descriptor's base sits one
+    // image row below X so that the offset of a pixel in the top halo row is not negative.
+    const unsigned rowb = (unsigned)Ws * (unsigned)p.lda * 2u;
+    constexpr bool fastc = CF;      // (as a run-time branch beside the general path the kernel lost 35 %: two gather bodies in the stage loop)
+    static_assert(!CF || (MODE == 1 && TK == WG_T), "constant-advance gather: conv, 128-column k tiles");
+    const __amdgpu_buffer_rsrc_t rxf = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(p.A) - (fastc ? (size_t)rowb / 2 : 0), 0,
+                                                                         (int)(p.a_bytes + (fastc ? rowb : 0u)), 0x00020000);
+    const int dstage = fastc ? (d_b * p.H + d_ho * p.stride) * (int)rowb : 0;
+    unsigned xoffc[4];
+    if constexpr (fastc) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int wi = pwo[i] * p.stride - 1 + dw;
+            const bool wok = kok && wi >= 0 && wi < p.Wd;
+            xoffc[i] = wok ? ((unsigned)(pb[i] * p.H + pho[i] * p.stride + dh) * rowb + ((unsigned)wi * (unsigned)p.lda + (unsigned)cA) * 2u) : OOB;
+        }
+    }
     auto issue = [&](int mb, int buf) {      // called with mb = mbeg, mbeg + WG_MB, ... in order; YI + 4 DMA instructions per wave
         bf16* ys = ring + buf * STAGE;
         bf16* xs = ys + WG_MB * TN;
@@ -2125,6 +2147,14 @@ DEVFN void wgrad_v2_body(const WgradParams& p) {
             if (MODE == 0) {
                 if (SIDLSG_WGRAD_ASM_DMA) dma16_asm(rx, xs + (4 * wave + 16 * i) * WG_T, mok ? xoff[i] : OOB, xsoff);
                 else __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lptr_t)(xs + (4 * wave + 16 * i) * WG_T), 16, mok ? xoff[i] : OOB, xsoff, 0, 0);
+            } else if constexpr (fastc) {
+                const int ho = pho[i];
+                const int hi = ho * p.stride - 1 + dh;
+                const bool ok = mok && hi >= 0 && hi < p.H;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rxf, (lptr_t)(xs + (4 * wave + 16 * i) * WG_T), 16, ok ? xoffc[i] : OOB,
+                                                         ((mb - mbeg) / WG_MB) * dstage, 0, 0);
+                const int nho = ho + d_ho;
+                pho[i] = nho >= p.Ho ? nho - p.Ho : nho;
             } else {
                 bool ok = kok && mok;
                 const int b = pb[i], ho = pho[i], wo = pwo[i];
@@ -2294,6 +2324,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad_v2_kernel(WgradParams p) { 
 template <int MODE>
 __global__ __launch_bounds__(NTHREADS, 2) void wgrad_v2w_kernel(WgradParams p) { wgrad_v2_body<MODE, 160, WG_T>(p); }
 __global__ __launch_bounds__(NTHREADS, 2) void wgrad_v2s_kernel(WgradParams p) { wgrad_v2_body<0, 160, 160>(p); }      // dense, 160 x 160 tiles
+__global__ __launch_bounds__(NTHREADS, 2) void wgrad_v2f_kernel(WgradParams p) { wgrad_v2_body<1, 128, WG_T, true>(p); }     // conv, constant-advance gather
+__global__ __launch_bounds__(NTHREADS, 2) void wgrad_v2wf_kernel(WgradParams p) { wgrad_v2_body<1, 160, WG_T, true>(p); }    // the same with 160-wide n tiles
 
 // dW[i] += sum_s slab[s][i]  (assign: dW[i] = sum_s slab[s][i], summed in the same order from 0 -- bit-identical to the sum onto a zeroed dW)
 __global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dW, size_t n, int splits, int assign) {
@@ -2393,9 +2425,20 @@ static int launch_wgrad(WgradParams p, hipStream_t s) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_v2_kernel<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * WG_MB * (128 + WG_T) * 2);
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_v2w_kernel<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * WG_MB * (160 + WG_T) * 2);
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_v2s_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * WG_MB * (160 + 160) * 2);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_v2f_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * WG_MB * (128 + WG_T) * 2);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_v2wf_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * WG_MB * (160 + WG_T) * 2);
             attr_done = true;
         }
+        bool cf = false;
+        if (MODE == 1 && !p.slow_gather && !p.ups && p.H == p.Ho * p.stride) {          // conditions of the constant-advance gather (wgrad_v2_body, fastc)
+            const int hw = p.Ho * p.Wo, d_b = WG_MB / hw, d_rem = WG_MB - d_b * hw;
+            const int d_wo = d_rem - (d_rem / p.Wo) * p.Wo;
+            const unsigned long long rowb = (unsigned long long)p.Wd * p.lda * 2ull;
+            cf = d_wo == 0 && (unsigned long long)p.a_bytes + rowb < 0x7fffffffull;
+        }
         if (sq160) SIDLSG_LAUNCH(wgrad_v2s_kernel, dim3(tiles * splits), dim3(NTHREADS), lds, s, p);
+        else if (cf && tn == 160) SIDLSG_LAUNCH(wgrad_v2wf_kernel, dim3(tiles * splits), dim3(NTHREADS), lds, s, p);
+        else if (cf) SIDLSG_LAUNCH(wgrad_v2f_kernel, dim3(tiles * splits), dim3(NTHREADS), lds, s, p);
         else if (tn == 160) SIDLSG_LAUNCH((wgrad_v2w_kernel<MODE>), dim3(tiles * splits), dim3(NTHREADS), lds, s, p);
         else SIDLSG_LAUNCH((wgrad_v2_kernel<MODE>), dim3(tiles * splits), dim3(NTHREADS), lds, s, p);
     } else
@@ -2579,6 +2622,8 @@ static int wgrad_conv_impl(const void* dY, int ldy, const void* X, int ldx, floa
     if ((stride != 1 && stride != 2) || (Cin & 7) || (ldx & 7) || !dY || !X || !dW) return SIDLSG_EINVAL;
     WgradParams p{};
     p.dY = (const bf16*)dY; p.A = (const bf16*)X; p.dW = dW; p.dB = dBias; p.ldy = ldy; p.lda = ldx; p.assign = assign;
+    static const int slow_gather = getenv("SIDLSG_WGRAD_CONV_FAST") && atoi(getenv("SIDLSG_WGRAD_CONV_FAST")) == 0;      // A/B switch
+    p.slow_gather = slow_gather;
     p.H = H; p.Wd = Wd; p.Cin = Cin; p.stride = stride; p.ups = ups;
     p.Ho = (H + 2 - 3) / stride + 1; p.Wo = (Wd + 2 - 3) / stride + 1;
     p.M = B * p.Ho * p.Wo; p.N = Cout; p.K = 9 * Cin;

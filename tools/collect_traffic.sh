@@ -15,7 +15,7 @@ for mode in gemm conv wgrad attn norm; do python tools/bench_kernels.py $mode --
 P=tools/pmc_traffic_json.py
 python $P $out/gemm_FETCH_SIZE/p_counter_collection.csv $out/gemm_WRITE_SIZE/p_counter_collection.csv $out/traffic_gemm.json gemm $out/alg_gemm.json "gemm=GemmParams+gemm_finish"
 python $P $out/conv_FETCH_SIZE/p_counter_collection.csv $out/conv_WRITE_SIZE/p_counter_collection.csv $out/traffic_conv.json conv $out/alg_conv.json "conv=GemmParams+gemm_finish"
-python $P $out/wgrad_FETCH_SIZE/p_counter_collection.csv $out/wgrad_WRITE_SIZE/p_counter_collection.csv $out/traffic_wgrad.json wgrad $out/alg_wgrad.json "wgrad=wgrad_v2&<0>|wgrad_v2s_kernel" "conv_wgrad=wgrad_v2&<1>" "wgrad_reduce=wgrad_reduce"
+python $P $out/wgrad_FETCH_SIZE/p_counter_collection.csv $out/wgrad_WRITE_SIZE/p_counter_collection.csv $out/traffic_wgrad.json wgrad $out/alg_wgrad.json "wgrad=wgrad_v2&<0>|wgrad_v2s_kernel" "conv_wgrad=wgrad_v2&<1>|wgrad_v2f_kernel|wgrad_v2wf_kernel" "wgrad_reduce=wgrad_reduce"
 python $P $out/attn_FETCH_SIZE/p_counter_collection.csv $out/attn_WRITE_SIZE/p_counter_collection.csv $out/traffic_attn.json attn $out/alg_attn.json "attn=attn_q_kernel&, 0, " "attn_bwd=attn_dkdv_kernel+attn_q_kernel&, 1, "
 python $P $out/norm_FETCH_SIZE/p_counter_collection.csv $out/norm_WRITE_SIZE/p_counter_collection.csv $out/traffic_norm.json norm $out/alg_norm.json "gn=gn_apply_kernel|gn_small_fwd+gn_stats_kernel" "gn_bwd=gn_bwd_apply_kernel|gn_small_bwd+gn_bwd_stats_kernel" "ln=ln_fwd_kernel" "ln_bwd=ln_bwd_kernel" "norm_param_grad_reduce=colsum_reduce2"
 rm -rf $out/*_FETCH_SIZE $out/*_WRITE_SIZE
