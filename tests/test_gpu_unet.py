@@ -1048,6 +1048,21 @@ def test_unzeroed_weight_gradients_change_nothing_in_the_step(dev, monkeypatch):
         assert float(d.max()) <= 2.01 * lr * iters and frac_same > 0.98
 
 
+def test_optimizer_state_of_another_flat_layout_is_refused(dev):
+    """The Adam moments are stored in the order of the flat buffer; round 4 changed that order (weights first inside each gradient
+    segment): a state file without / with another `flat_layout` tag must not load silently."""
+    from sid_lsg_amd.optim import FLAT_LAYOUT, FusedAdamEMA
+    from sid_lsg_amd.unet import CONFIGS, HipUNet2DCondition
+    net = HipUNet2DCondition(CONFIGS['tiny40']).materialize(dev, seed=1).requires_grad_(True)
+    opt = FusedAdamEMA(net.parameters(), lr=1e-5)
+    sd = opt.state_dict()
+    assert sd['flat_layout'] == FLAT_LAYOUT
+    opt.load_state_dict(sd)
+    old = {k: v for k, v in sd.items() if k != 'flat_layout'}
+    with pytest.raises(ValueError, match='flat-buffer layout'):
+        opt.load_state_dict(old)
+
+
 def _graph_vs_eager(dev, reducer_factory=None, iters=4):
     """Runs `iters` iterations twice from identical initial state and inputs: eagerly and through SiDStep.iteration_graphed
     (first call eager, second captures + replays, later ones replay).  Returns the two result dicts."""
