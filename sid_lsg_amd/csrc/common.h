@@ -137,15 +137,36 @@ enum { SIDLSG_FAM_GEMM = 0, SIDLSG_FAM_CONV, SIDLSG_FAM_ATTN_FWD, SIDLSG_FAM_ATT
 bool sidlsg_trace_scope_begin(int family, double work, double bytes);
 void sidlsg_trace_scope_end();
 bool sidlsg_trace_events(hipEvent_t* e0, hipEvent_t* e1);
+#ifdef SIDLSG_EXP_SKIP      // measurement build only (tools/ab/build_skip_variant.sh): the kernels of the families in $SIDLSG_EXP_SKIP_FAMILIES (bit mask)
+#include <cstdlib>          // are not launched -- WRONG results; the step-time difference is the family's exposed cost (tools/family_exposed_cost.sh)
+inline thread_local int sidlsg_cur_family = -1;
+static inline bool sidlsg_exp_skip() {
+    static const long mask = getenv("SIDLSG_EXP_SKIP_FAMILIES") ? strtol(getenv("SIDLSG_EXP_SKIP_FAMILIES"), nullptr, 0) : 0;
+    return sidlsg_cur_family >= 0 && ((mask >> sidlsg_cur_family) & 1);
+}
+#define SIDLSG_SKIP_CHECK if (sidlsg_exp_skip()) break;
+#else
+#define SIDLSG_SKIP_CHECK
+#endif
 struct SidlsgTraceScope {
     bool open;
-    SidlsgTraceScope(int family, double work, double bytes = 0.0) : open(sidlsg_trace_scope_begin(family, work, bytes)) {}
-    ~SidlsgTraceScope() { if (open) sidlsg_trace_scope_end(); }
+    SidlsgTraceScope(int family, double work, double bytes = 0.0) : open(sidlsg_trace_scope_begin(family, work, bytes)) {
+#ifdef SIDLSG_EXP_SKIP
+        sidlsg_cur_family = family;
+#endif
+    }
+    ~SidlsgTraceScope() {
+        if (open) sidlsg_trace_scope_end();
+#ifdef SIDLSG_EXP_SKIP
+        sidlsg_cur_family = -1;
+#endif
+    }
 };
 #include <hip/hip_ext.h>
 // hipLaunchKernelGGL, or -- inside a sampled trace scope -- the same launch with start / stop events bound to ITS dispatch packet
 #define SIDLSG_LAUNCH(kern, grid, block, lds, stream, ...)                                                     \
     do {                                                                                                        \
+        SIDLSG_SKIP_CHECK                                                                                       \
         hipEvent_t te0_, te1_;                                                                                  \
         if (sidlsg_trace_events(&te0_, &te1_)) hipExtLaunchKernelGGL(kern, grid, block, lds, stream, te0_, te1_, 0, __VA_ARGS__); \
         else hipLaunchKernelGGL(kern, grid, block, lds, stream, __VA_ARGS__);                                   \
