@@ -273,6 +273,17 @@ DEVFN float fmax2(float a, float b) { return fmaxf(a, b); }
 
 constexpr int AT_KT = 64;   // keys per LDS tile
 
+// s_setprio around the MFMA clusters (A/B knob, bit mask): 1 = QK^T cluster of attn_q_kernel, 2 = its second contraction (P.V / dS.K,
+// and the dP cluster of the dQ pass), 4 = the dV / dK cluster of attn_dkdv_kernel, 8 = its S / dP cluster.  With several
+// independent waves per SIMD in different phases the arbiter then prefers the wave that feeds the matrix pipe.
+#ifndef SIDLSG_ATTN_PRIO
+#define SIDLSG_ATTN_PRIO 0
+#endif
+// (s_setprio alone does not stay where it is written: MFMAs are register-only and the scheduler moves them across it -- seen in the
+// ISA: both flips of the QK^T cluster ended up in front of its first MFMA.  The two sched_barriers let VALU / VMEM / LDS
+// instructions cross (mask 0x3F2) and pin only the MFMAs and scalar instructions relative to the flip.)
+#define ATTN_PRIO(bit, v) do { if constexpr ((SIDLSG_ATTN_PRIO) & (bit)) { __builtin_amdgcn_sched_barrier(0x3F2); __builtin_amdgcn_s_setprio(v); __builtin_amdgcn_sched_barrier(0x3F2); } } while (0)
+
 // MODE 0: forward (O, LSE).  MODE 1: dQ.   QT = 16-query tiles per wave (block = 4 waves * QT * 16 queries)
 // ONES (forward, D == DP - 8 only): V's first pad column holds 1.0, so O^T row D accumulates the softmax
 // denominator inside the P.V MFMAs (and is rescaled with O); the 16 VALU adds per query tile disappear.
@@ -385,6 +396,7 @@ __global__ __launch_bounds__(256, (DP <= 48 && MODE == 0) ? 4 : ((DP <= 48 && MO
         const bf16* Kt = Ks[buf];
         const bf16* Vt = Vs[buf];
         f32x4 s[4][QT];
+        ATTN_PRIO(1, 1);
 #pragma unroll
         for (int kt = 0; kt < 4; kt++) {
             Frag<DP> fk;
@@ -403,6 +415,7 @@ __global__ __launch_bounds__(256, (DP <= 48 && MODE == 0) ? 4 : ((DP <= 48 && MO
                     s[kt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fk.w[sl], fq[qt].w[sl], sl == 0 ? c0 : s[kt][qt], 0, 0, 0);
                 }
         }
+        ATTN_PRIO(1, 0);
         // scores -> probabilities (keys of this lane: k0 + kt*16 + lg*4 + r).  The softmax is the VALU-bound part
         // at d=40: raw v_exp_f32, scale folded into one FMA (or into Q: PS), masking only on the ragged last tile, and the
         // running-max rescale of O deferred until the max grows by > 2^8 (LSE stays exact: m + log2(l)).
@@ -500,6 +513,7 @@ __global__ __launch_bounds__(256, (DP <= 48 && MODE == 0) ? 4 : ((DP <= 48 && MO
         }
         if (MODE == 1) {
             // dP^T = V dO^T ; dS^T = P^T * (dP^T - delta)   (overwrites s; the constant factor is applied in the epilogue)
+            ATTN_PRIO(2, 1);
 #pragma unroll
             for (int kt = 0; kt < 4; kt++) {
                 Frag<DP> fv;
@@ -519,6 +533,7 @@ __global__ __launch_bounds__(256, (DP <= 48 && MODE == 0) ? 4 : ((DP <= 48 && MO
         }
         // second contraction over keys: forward uses V, dQ uses K
         const bf16* T2 = MODE == 0 ? Vt : Kt;
+        ATTN_PRIO(2, 1);
 #pragma unroll
         for (int kb = 0; kb < 2; kb++) {
             bf16x8 pb[QT];
@@ -535,6 +550,7 @@ __global__ __launch_bounds__(256, (DP <= 48 && MODE == 0) ? 4 : ((DP <= 48 && MO
                 for (int qt = 0; qt < QT; qt++) o[dt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, pb[qt], o[dt][qt], 0, 0, 0);
             }
         }
+        ATTN_PRIO(2, 0);
 #ifndef SIDLSG_EXP_ATTN_NOSTAGE
         if (more) {                      // the other buffer was last read before the previous barrier
             tk.commit(Ks[buf ^ 1], LD);
@@ -665,6 +681,7 @@ __global__ __launch_bounds__(256) void attn_dkdv_kernel(AttnParams p) {
         const float* lse_c = lse_s[pb_] + sub * AK_QT;
         const float* dl_c = dl_s[pb_] + sub * AK_QT;
         f32x4 pp[KT][4], ds[KT][4];
+        ATTN_PRIO(8, 1);
 #pragma unroll
         for (int qt = 0; qt < 4; qt++) {
             Frag<DP> fq, fdo;  // A operands: (row = query, k = d)
@@ -698,6 +715,8 @@ __global__ __launch_bounds__(256) void attn_dkdv_kernel(AttnParams p) {
                 }
             }
         }
+        ATTN_PRIO(8, 0);
+        ATTN_PRIO(4, 1);
 #pragma unroll
         for (int half = 0; half < 2; half++)
 #pragma unroll
@@ -712,6 +731,7 @@ __global__ __launch_bounds__(256) void attn_dkdv_kernel(AttnParams p) {
                     dk[kt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb, dsb, dk[kt][dt], 0, 0, 0);
                 }
             }
+        ATTN_PRIO(4, 0);
         }
         if (more) {          // the other buffer was last read in the previous stage, i.e. before the previous barrier
             pb_ ^= 1;

@@ -803,6 +803,13 @@ extern "C" int sidlsg_exp_set_trace(void* ptr) { return hipMemcpyToSymbol(HIP_SY
 #ifndef SIDLSG_V3_SCHED_FENCE
 #define SIDLSG_V3_SCHED_FENCE 1
 #endif
+#ifndef SIDLSG_V3_PRIO_PIN
+#define SIDLSG_V3_PRIO_PIN 1   // 1: sched_barriers pin the MFMAs and scalar instructions relative to the flip (VALU / VMEM / LDS may cross)
+#endif
+#define V3_SETPRIO(v) do { if (SIDLSG_V3_PRIO_PIN) __builtin_amdgcn_sched_barrier(0x3F2); __builtin_amdgcn_s_setprio(v); if (SIDLSG_V3_PRIO_PIN) __builtin_amdgcn_sched_barrier(0x3F2); } while (0)
+#ifndef SIDLSG_V3_PRIO
+#define SIDLSG_V3_PRIO 0      // A/B knob (bit mask): s_setprio(1) around the MFMA clusters of a K-tile -- 1: gemm_v3 (dense / conv fwd + dgrad), 2: wgrad_v2 (two co-resident blocks per CU in different phases)
+#endif
 // (A 3-buffer ring with counted vmcnt(9) -- every DMA gets two K-tiles of MFMA time, but 108 KiB of LDS = ONE block per CU
 // -- was measured in the same session: 30-50 % SLOWER on every SD shape (e.g. conv 64x64 320->320 124 -> 195 us, FF-in 239 ->
 // 355 us).  Two co-resident blocks per CU hide more than a deeper pipeline in one; the variant is not in the build.)
@@ -1007,11 +1014,13 @@ DEVFN void gemm_v3_body(GemmParams& p) {
         }
     };
     auto mfma_block = [&](const bf16x8 (&fa)[MT], const bf16x8 (&fw)[NT]) {
+        if constexpr ((SIDLSG_V3_PRIO) & 1) V3_SETPRIO(1);
 #pragma unroll
         for (int ni = 0; ni < NT; ni++)
 #pragma unroll
             for (int mi = 0; mi < MT; mi++)
                 acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[ni], fa[mi], acc[ni][mi], 0, 0, 0);
+        if constexpr ((SIDLSG_V3_PRIO) & 1) V3_SETPRIO(0);
     };
 
     bf16x8 fa0[MT], fw0[NT], fa1[MT], fw1[NT];
@@ -2208,6 +2217,7 @@ DEVFN void wgrad_v2_body(const WgradParams& p) {
         for (int j = 0; j < KI; j++) fx[j] = tr_frag(xs, TK, sxA, sxB, kk, wk0 + j * 16);
     };
     auto mfma_block = [&](const bf16x8 (&fy)[NI], const bf16x8 (&fx)[KI]) {
+        if constexpr ((SIDLSG_V3_PRIO) & 2) V3_SETPRIO(1);
 #pragma unroll
         for (int i = 0; i < NI; i++)
 #pragma unroll
@@ -2217,6 +2227,7 @@ DEVFN void wgrad_v2_body(const WgradParams& p) {
 #pragma unroll
             for (int i = 0; i < NI; i++) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fy[i], ones, accb[i], 0, 0, 0);
         }
+        if constexpr ((SIDLSG_V3_PRIO) & 2) V3_SETPRIO(0);
     };
 
     const int nsteps = (mend - mbeg + WG_MB - 1) / WG_MB;
