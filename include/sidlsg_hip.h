@@ -56,6 +56,16 @@ int sidlsg_gemm_geglu_ok(int M, int N2, int K);
 int sidlsg_gemm_geglu_bf16(const void* A, int lda, const void* W, void* H, int ldh, void* Y, int ldy, const float* bias, int M, int N2,
                            int K, void* stream);
 
+/* The backward of the same block (diffusers `FeedForward`: net[2] = Linear(4C -> C) after the GEGLU): data gradient of the FF-out
+ * projection with the GEGLU derivative in its epilogue -- dy = dOut Wt^T (Wt [F][K]: the backward-data operand of the [K][F] FF-out
+ * weight) stays in the output tile (rounded to bf16 there: bit for bit what sidlsg_geglu_bwd computes from a stored dy),
+ * dH[:, :F] = dy * gelu(h[:, F:]), dH[:, F:] = dy * h[:, :F] * gelu'(h[:, F:]); H, dH: [M][ldh], ldh >= 2 F.  Saves the write and
+ * the re-read of dy [M][F] (2 x 168 MB at the 64x64 stage of SD1.5, batch 16) and one launch.  autograd reaches it through
+ * `loss.backward()` (sid_training_loop.py:450,533).  sidlsg_gemm_geglu_bwd_ok: host query, same admission rule as the forward. */
+int sidlsg_gemm_geglu_bwd_ok(int M, int F, int K);
+int sidlsg_gemm_geglu_bwd_bf16(const void* dOut, int lda, const void* Wt, const void* H, void* dH, int ldh, int M, int F, int K,
+                               void* stream);
+
 /* Optional fp32 scratch (device memory owned by the caller): per-split partial-sum slabs for split-K GEMMs/convs with few
  * output tiles and long K (8x8 / 16x16 stages) and for the pixel-split weight gradients (without it they fall back to
  * fp32 atomics, ~2-3x slower on MI355X).  Default for every stream without a private workspace (below): launches sharing

@@ -59,6 +59,11 @@ struct GemmParams {
     // epilogue writes h (natural column order, C may be null) and Y[m][f] = a * gelu(g)
     bf16* Y;
     int ldy, geglu;
+    // fused GEGLU BACKWARD (sidlsg_gemm_geglu_bwd_bf16: the data gradient of the FF-out projection): geglu_bwd = F > 0 -> the output
+    // tile is dy[:, n0 .. n0 + 160) = dOut W2 (never stored); the epilogue reads h[:, n] / h[:, F + n] from Hin and writes
+    // dH[:, n] = dy * gelu(g), dH[:, F + n] = dy * a * gelu'(g) to Y (both [M][ldy], ldy >= 2 F)
+    const bf16* Hin;
+    int geglu_bwd;
 };
 
 // m-tiles of a launch: each set of a grouped launch starts on a tile boundary of its own (Mg need not be a multiple of BM)
@@ -1130,6 +1135,51 @@ DEVFN void gemm_v3_body(GemmParams& p) {
             }
             return;
         }
+#ifndef SIDLSG_EXP_NO_GEGLU_BWD       // (measurement build: the kernel without this epilogue, to price its code size)
+        if (MODE == 0 && p.geglu_bwd) {       // (dense kernel only)
+            // the staged tile holds the bf16-ROUNDED dy of 160 features: bit for bit what sidlsg_geglu_bwd computes from a stored dy.
+            // Every h load of a half is issued before that half's first store (Hin / dH do not alias: __restrict__ locals).
+            constexpr int CPR = BN / 8;                             // 16-byte chunks per tile row
+            constexpr int ITER = BM * CPR / NTHREADS / 2;           // chunks per thread and half
+            static_assert(BM * CPR % (2 * NTHREADS) == 0, "whole passes");
+            const int F = p.geglu_bwd;
+            const bf16* __restrict__ Hin = p.Hin;
+            bf16* __restrict__ dH = p.Y;
+#pragma unroll
+            for (int half = 0; half < 2; half++) {
+                bf16x8 av[ITER], gv[ITER];
+#pragma unroll
+                for (int i = 0; i < ITER; i++) {
+                    const int c = tid + (half * ITER + i) * NTHREADS;
+                    const int row = c / CPR, col = (c - row * CPR) * 8;
+                    const bool ok = m0 + row < p.M && n0 + col < p.N;
+                    const size_t o = (size_t)(m0 + row) * p.ldy + n0 + col;
+                    av[i] = ok ? ld8(Hin + o) : zero8();
+                    gv[i] = ok ? ld8(Hin + o + F) : zero8();
+                }
+#pragma unroll
+                for (int i = 0; i < ITER; i++) {
+                    const int c = tid + (half * ITER + i) * NTHREADS;
+                    const int row = c / CPR, col = (c - row * CPR) * 8;
+                    if (!(m0 + row < p.M && n0 + col < p.N)) continue;
+                    const bf16x8 dv = *reinterpret_cast<const bf16x8*>(ring + row * LDR + col);
+                    bf16x8 da, dg;
+#pragma unroll
+                    for (int e = 0; e < 8; e++) {
+                        float gl, gd;
+                        gelu_pair_t<bf16>(bf2f(gv[i][e]), gl, gd);
+                        const float d = bf2f(dv[e]);
+                        da[e] = f2bf(d * gl);
+                        dg[e] = f2bf(d * bf2f(av[i][e]) * gd);
+                    }
+                    const size_t o = (size_t)(m0 + row) * p.ldy + n0 + col;
+                    st8(dH + o, da);
+                    st8(dH + o + F, dg);
+                }
+            }
+            return;
+        }
+#endif
         gemm_store_rows<BM, BN>(p, ring, m0, n0, LDR, tid);
         TRACE(4);
 #ifdef SIDLSG_EXP_TRACE
@@ -2552,6 +2602,30 @@ int sidlsg_gemm_geglu_bf16(const void* A, int lda, const void* W, void* H, int l
     if (!fits31(ab) || !fits31(wb)) return SIDLSG_EINVAL;
     p.a_bytes = (unsigned)ab; p.w_bytes = (unsigned)wb;
     SidlsgTraceScope ts(SIDLSG_FAM_GEMM, 2.0 * M * (double)N2 * K, 2.0 * ((double)M * K + (double)N2 * K + (double)M * N2 * (H ? 1.5 : 0.5)));
+    return launch_gemm_v3<0>(p, (hipStream_t)stream);
+}
+
+// Data gradient of the FF-out projection + GEGLU derivative in one kernel: dy = dOut Wt^T (Wt = the [F][K] backward-data operand of
+// the [K][F] FF-out weight; dy [M][F] is never stored), dH[:, :F] = dy * gelu(h[:, F:]), dH[:, F:] = dy * h[:, :F] * gelu'(h[:, F:]).
+// Direct-to-LDS kernel only, same admission rule as the forward fusion.
+int sidlsg_gemm_geglu_bwd_ok(int M, int F, int K) {
+    static const bool on = !(getenv("SIDLSG_GEMM_GEGLU_BWD") && atoi(getenv("SIDLSG_GEMM_GEGLU_BWD")) == 0);      // A/B switch
+#ifdef SIDLSG_EXP_NO_GEGLU_BWD
+    return 0;
+#endif
+    if (!on || M <= 0 || F <= 0 || K <= 0 || (F % 160) || (K & 7)) return 0;
+    return (long long)((M + 127) / 128) * (F / 160) >= 256 ? 1 : 0;
+}
+int sidlsg_gemm_geglu_bwd_bf16(const void* dOut, int lda, const void* Wt, const void* H, void* dH, int ldh, int M, int F, int K,
+                               void* stream) {
+    if (!sidlsg_gemm_geglu_bwd_ok(M, F, K) || !dOut || !Wt || !H || !dH || (ldh & 7) || (lda & 7) || ldh < 2 * F) return SIDLSG_EINVAL;
+    GemmParams p{};
+    p.A = (const bf16*)dOut; p.W = (const bf16*)Wt; p.C = nullptr; p.Y = (bf16*)dH; p.Hin = (const bf16*)H; p.ldy = ldh; p.geglu_bwd = F;
+    p.ldrv = F; p.M = M; p.N = F; p.K = K; p.lda = lda; p.ldc = F; p.rows_per_batch = 1; p.alpha = 1.f; p.Mtot = M;
+    const unsigned long long ab = ((unsigned long long)(M - 1) * lda + K) * 2ull, wb = (unsigned long long)F * K * 2ull;
+    if (!fits31(ab) || !fits31(wb)) return SIDLSG_EINVAL;
+    p.a_bytes = (unsigned)ab; p.w_bytes = (unsigned)wb;
+    SidlsgTraceScope ts(SIDLSG_FAM_GEMM, 2.0 * M * (double)F * K, 2.0 * ((double)M * K + (double)F * K + 4.0 * (double)M * F));
     return launch_gemm_v3<0>(p, (hipStream_t)stream);
 }
 

@@ -1016,7 +1016,7 @@ class _LinearGEGLU(torch.autograd.Function):
     Backward = sidlsg_geglu_bwd followed by the ordinary Linear backward (data gradient through w16t, weight + bias gradient)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, w16, w16t, keep_h):
+    def forward(ctx, x, weight, bias, w16, w16t, keep_h, with_h=False):
         _chk(x, BF16)
         M, K = x.shape
         N2 = w16.shape[0]
@@ -1025,14 +1025,27 @@ class _LinearGEGLU(torch.autograd.Function):
         lib.sidlsg_gemm_geglu_bf16(_p(x), x.stride(0), _p(w16), _p(h), N2, _p(y), N2 // 2, _p(bias), M, N2, K, _s())
         if keep_h:
             ctx.save_for_backward(x, weight, bias, w16t, h)
+        if with_h:
+            # h as a second output: the consumer (_GegluLinear) returns the gradient with respect to h itself -- its data-gradient
+            # GEMM applies the GEGLU derivative in the epilogue -- and no gradient for y
+            ctx.set_materialize_grads(False)
+            return y, h
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dh=None):
         x, weight, bias, w16t, h = ctx.saved_tensors
         F2 = h.shape[-1]
-        dh = torch.empty_like(h)
-        lib.sidlsg_geglu_bwd(_p(h), _p(dy.contiguous().to(BF16)), _p(dh), h.shape[0], F2 // 2, _s())
+        if dy is not None:
+            dh_y = torch.empty_like(h)
+            lib.sidlsg_geglu_bwd(_p(h), _p(dy.contiguous().to(BF16)), _p(dh_y), h.shape[0], F2 // 2, _s())
+            dh = dh_y if dh is None else add(dh.contiguous().to(BF16), dh_y)
+        elif dh is None:
+            return None, None, None, None, None, None, None
+        else:
+            dh = dh.contiguous()
+            if dh.dtype != BF16:
+                dh = dh.to(BF16)
         dx = gemm(dh, w16t) if ctx.needs_input_grad[0] else None
         if _wants_grad(weight):
             M, K = x.shape
@@ -1042,11 +1055,13 @@ class _LinearGEGLU(torch.autograd.Function):
                 wg(_p(dh), dh.stride(0), _p(x), x.stride(0), _p(weight.grad), _p(bias.grad) if need_b else None, M, weight.shape[0], K, _s())
         elif _wants_grad(bias):
             colsum(dh, dh.shape[0], total=bias.grad)
-        return dx, None, None, None, None, None
+        return dx, None, None, None, None, None, None
 
 
-def linear_geglu(x, weight, bias, w16, w16t):
-    """GEGLU(Linear(x)): the fused kernel where it applies (bf16, a shape the direct-to-LDS GEMM takes), else the two ops."""
+def linear_geglu(x, weight, bias, w16, w16t, with_h=False):
+    """GEGLU(Linear(x)): the fused kernel where it applies (bf16, a shape the direct-to-LDS GEMM takes), else the two ops.
+    with_h: return (y, h) -- h = None when no backward will run, y = None when the caller has to apply the GEGLU itself
+    (feed_forward_out does, inside the node whose backward fuses the GEGLU derivative into the FF-out data gradient)."""
     if (_dual is None and x.dtype == BF16 and isinstance(w16, torch.Tensor) and w16.dtype == BF16 and x.is_contiguous()
             and lib.sidlsg_gemm_geglu_ok.raw(x.shape[0], w16.shape[0], w16.shape[1])):
         keep_h = torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad or (bias is not None and bias.requires_grad))
@@ -1054,8 +1069,76 @@ def linear_geglu(x, weight, bias, w16, w16t):
         # kept; K = 320 (64x64 stage) only pays when h is NOT kept (251 -> 190 us): with h the A-stationary GEMM + the stand-alone
         # GEGLU kernel (164 + 87 us) beat the fused direct-to-LDS kernel (262 us)
         if not keep_h or w16.shape[1] >= 640:
-            return _LinearGEGLU.apply(x, weight, bias, w16, w16t, keep_h)
-    return geglu(linear(x, weight, bias, w16, w16t))
+            if with_h and keep_h:
+                return _LinearGEGLU.apply(x, weight, bias, w16, w16t, keep_h, True)
+            y = _LinearGEGLU.apply(x, weight, bias, w16, w16t, keep_h)
+            return (y, None) if with_h else y
+    h = linear(x, weight, bias, w16, w16t)
+    return (None, h) if with_h else geglu(h)
+
+
+class _GegluLinear(torch.autograd.Function):
+    """out = GEGLU(h) W^T + b (+ res): the GEGLU and the FF-out projection of a transformer block as ONE autograd node, so that the
+    backward is sidlsg_gemm_geglu_bwd_bf16 -- the projection's data gradient with the GEGLU derivative in its epilogue: dy [M, F]
+    is neither written nor re-read (2 x 168 MB at the 64x64 stage of SD1.5, batch 16) and sidlsg_geglu_bwd is not launched.
+    y: GEGLU(h) when the fused FF-in kernel has already produced it (then no gradient flows back through y), else None."""
+
+    @staticmethod
+    def forward(ctx, h, y, weight, bias, w16, w16t, res):
+        _chk(h, BF16)
+        M, F2 = h.shape
+        if y is None:
+            y = torch.empty((M, F2 // 2), device=h.device, dtype=BF16)
+            lib.sidlsg_geglu_fwd(_p(h), _p(y), M, F2 // 2, _s())
+        out = gemm(y, w16, bias=bias, res=res)
+        wg = weight.requires_grad
+        ctx.save_for_backward(h, y if wg else None, weight, bias, w16t)
+        ctx.has_res = res is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        h, y, weight, bias, w16t = ctx.saved_tensors
+        dout = dout.contiguous()
+        if dout.dtype != BF16:
+            dout = dout.to(BF16)
+        M, F2 = h.shape
+        K = dout.shape[1]
+        dh = None
+        if ctx.needs_input_grad[0]:
+            dh = torch.empty_like(h)
+            lib.sidlsg_gemm_geglu_bwd_bf16(_p(dout), dout.stride(0), _p(w16t), _p(h), _p(dh), F2, M, F2 // 2, K, _s())
+        need_b = _wants_grad(bias)
+        if _wants_grad(weight):
+            wgk = lib.sidlsg_wgrad_assign_bf16 if _take_assign(weight, BF16) else lib.sidlsg_wgrad_bf16
+            with _OnWgradStream(dout, y):
+                wgk(_p(dout), dout.stride(0), _p(y), y.stride(0), _p(weight.grad), _p(bias.grad) if need_b else None, M, weight.shape[0],
+                    F2 // 2, _s())
+        elif need_b:
+            colsum(dout, dout.shape[0], total=bias.grad)
+        dres = dout if (ctx.has_res and ctx.needs_input_grad[6]) else None
+        return dh, None, None, None, None, None, dres
+
+
+def feed_forward(x, w1, b1, w1_16, w1_16t, w2, b2, w2_16, w2_16t, res=None):
+    """diffusers FeedForward (GEGLU projection -> Linear) + the block's residual: out = GEGLU(x W1^T + b1) W2^T + b2 + res."""
+    fused_bwd = (_dual is None and x.dtype == BF16 and torch.is_grad_enabled() and isinstance(w2_16, torch.Tensor) and w2_16.dtype == BF16
+                 and isinstance(w1_16, torch.Tensor)
+                 and lib.sidlsg_gemm_geglu_bwd_ok.raw(x.shape[0], w2_16.shape[1], w2_16.shape[0]))
+    if not fused_bwd:
+        return linear(linear_geglu(x, w1, b1, w1_16, w1_16t), w2, b2, w2_16, w2_16t, res)
+    y, h = linear_geglu(x, w1, b1, w1_16, w1_16t, with_h=True)
+    return geglu_linear(h, y, w2, b2, w2_16, w2_16t, res)
+
+
+def geglu_linear(h, y, weight, bias, w16, w16t, res=None):
+    """GEGLU(h) -> Linear (+ res) with the fused backward where it applies; h = None: y is all there is (no backward will run)."""
+    if h is None:
+        return linear(y, weight, bias, w16, w16t, res)
+    if (_dual is None and h.dtype == BF16 and h.requires_grad and torch.is_grad_enabled() and isinstance(w16, torch.Tensor) and w16.dtype == BF16
+            and h.is_contiguous() and lib.sidlsg_gemm_geglu_bwd_ok.raw(h.shape[0], h.shape[1] // 2, w16.shape[0])):
+        return _GegluLinear.apply(h, y, weight, bias, w16, w16t, res)
+    return linear(y if y is not None else geglu(h), weight, bias, w16, w16t, res)
 
 
 class _SiLU(torch.autograd.Function):

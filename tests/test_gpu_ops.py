@@ -692,6 +692,63 @@ def test_dispatch_trace_reports_kernel_time(dev):
     assert buf[3] == 0
 
 
+@pytest.mark.parametrize('M,C', [(32768, 320), (16384, 640), (4096, 1280), (33000, 320), (256, 320)])
+def test_feed_forward_fused_backward_equals_the_separate_kernels(dev, M, C):
+    """FeedForward (GEGLU projection -> Linear + residual) through ops.feed_forward -- whose backward runs the FF-out data gradient
+    with the GEGLU derivative in its epilogue (sidlsg_gemm_geglu_bwd_bf16: dy is never stored) -- against the composition of the
+    separate ops (linear, geglu, linear).  The epilogue works on the bf16-rounded dy tile, so everything is BIT-equal: output, dx,
+    the residual's gradient, both weight gradients (fixed-order pixel-split sums); the bias gradients come from fp32 atomics.  Also
+    the raw kernel against gemm + sidlsg_geglu_bwd, trainable and frozen weights, and the fall-back for shapes it does not take."""
+    from sid_lsg_amd import ops
+    from sid_lsg_amd._lib import lib
+    F = 4 * C
+    x = rnd(M, C, seed=1).to(dev)
+    res_in = rnd(M, C, seed=7).to(dev)
+    w1 = torch.nn.Parameter(rnd(2 * F, C, seed=2, scale=C ** -0.5).float().to(dev))
+    b1 = torch.nn.Parameter(rnd(2 * F, seed=3).float().to(dev))
+    w2 = torch.nn.Parameter(rnd(C, F, seed=5, scale=F ** -0.5).float().to(dev))
+    b2 = torch.nn.Parameter(rnd(C, seed=6).float().to(dev))
+    w1_16, w2_16 = w1.detach().to(BF16).contiguous(), w2.detach().to(BF16).contiguous()
+    w1_16t, w2_16t = w1_16.t().contiguous(), w2_16.t().contiguous()
+    dout = rnd(M, C, seed=4).to(dev)
+    takes = bool(lib.sidlsg_gemm_geglu_bwd_ok.raw(M, F, C))
+    assert takes == (M >= 4096)
+    if takes:       # the kernel itself
+        h = rnd(M, 2 * F, seed=8).to(dev)
+        dh = torch.empty_like(h)
+        lib.sidlsg_gemm_geglu_bwd_bf16(dout.data_ptr(), C, w2_16t.data_ptr(), h.data_ptr(), dh.data_ptr(), 2 * F, M, F, C, ops._s())
+        dy = ops.gemm(dout, w2_16t)
+        ref = torch.empty_like(h)
+        lib.sidlsg_geglu_bwd(h.data_ptr(), dy.data_ptr(), ref.data_ptr(), M, F, ops._s())
+        assert torch.equal(dh, ref), 'dh of the fused kernel'
+    for trainable in (True, False):
+        params = (w1, b1, w2, b2)
+        for p_ in params:
+            p_.requires_grad_(trainable)
+        out = {}
+        for name in ('fused', 'split'):
+            for p_ in params:
+                p_.grad = torch.zeros_like(p_) if trainable else None
+            xd, rd = x.clone().requires_grad_(), res_in.clone().requires_grad_()
+            if name == 'fused':
+                y = ops.feed_forward(xd, w1, b1, w1_16, w1_16t, w2, b2, w2_16, w2_16t, rd)
+                assert (type(y.grad_fn).__name__ == '_GegluLinearBackward') == takes
+            else:
+                y = ops.linear(ops.geglu(ops.linear(xd, w1, b1, w1_16, w1_16t)), w2, b2, w2_16, w2_16t, rd)
+            y.backward(dout)
+            torch.cuda.synchronize()
+            out[name] = (y.detach(), xd.grad, rd.grad) + (tuple(p_.grad.clone() for p_ in params) if trainable else ())
+        for i, what in enumerate(('y', 'dx', 'dres')):
+            assert torch.equal(out['fused'][i], out['split'][i]), what
+        if trainable:
+            assert torch.equal(out['fused'][3], out['split'][3]), 'dW1'
+            assert torch.equal(out['fused'][5], out['split'][5]), 'dW2'
+            close(out['fused'][4], out['split'][4], 1e-5, 'db1 (fp32 atomics: order)')
+            close(out['fused'][6], out['split'][6], 1e-5, 'db2 (fp32 atomics: order)')
+    with torch.no_grad():
+        assert torch.equal(ops.feed_forward(x, w1, b1, w1_16, w1_16t, w2, b2, w2_16, w2_16t, res_in), out['split'][0])
+
+
 @pytest.mark.parametrize('M,F,K', [(32768, 1280, 320), (16384, 2560, 640), (4096, 5120, 1280), (33000, 1280, 320), (256, 1280, 320)])
 def test_linear_geglu_fused_equals_two_kernels(dev, M, F, K):
     """The transformer's FF-in projection with GEGLU in the GEMM's epilogue (sidlsg_gemm_geglu_bf16) against the two kernels it
