@@ -1836,7 +1836,8 @@ static int dispatch_gemm(const GemmParams& pin, hipStream_t s) {
         float* const g_ws = w.ptr;
         const long long g_ws_bytes = w.bytes;
         if (t < MIN_TILES && nk >= MIN_NK && (p.N & 3) == 0 && g_ws && (long long)p.M * p.N * 8 <= g_ws_bytes) {
-            int splits = (int)((512 + t - 1) / t);
+            static const int TARGET = getenv("SIDLSG_SPLITK_TARGET") ? atoi(getenv("SIDLSG_SPLITK_TARGET")) : 512;   // blocks a split launch aims at (2 per CU)
+            int splits = (int)((TARGET + t - 1) / t);
             const long long cap = g_ws_bytes / ((long long)p.M * p.N * 4);
             if (splits > cap) splits = (int)cap;
             if (splits > nk / MIN_KT) splits = nk / MIN_KT;
