@@ -681,6 +681,231 @@ __global__ __launch_bounds__(512) void gn_small_bwd_kernel(const bf16* __restric
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// ONE-PASS GroupNorm for the LARGE stages (64x64, 32x32; bf16): a block owns ONE (sample, group) -- cpg channels of every pixel,
+// i.e. D = cpg / 2 consecutive dwords per pixel at a pitch of C / 2 dwords (the group's offset is only 4-byte aligned: 10 channels
+// = 20 bytes at C = 320, which is why the 16-byte kernels above cannot take single groups) -- and keeps its slab (HW x cpg bf16:
+// 80 KB for a 64x64 x 320 layer) in REGISTERS: thread t holds dword t % D of the pixels t / D + i R, so its two channels are fixed
+// (scale / shift / gamma are four registers) and consecutive lanes read consecutive dwords of a pixel, then the next pixel (a wave
+// touches ~64 / D pixels per load instruction, each a 2 D-word run inside one or two cache lines).  Statistics: per-thread partials
+// -> xor butterfly inside the wave -> one LDS slot per wave -> every thread adds the slots in the same order (deterministic, all
+// threads hold bit-identical totals).  B x G blocks (512 at batch 16): x is read ONCE (the two-kernel path reads it twice -- three
+// times in the backward, with dy twice), there is one launch instead of two (three with the parameter gradients), no statistics
+// workspace.  The group ranges of one sample interleave inside every cache line, so the block order keeps a sample on one XCD.
+struct GnGrp {
+    int B, HW, C, G, cpg, D, R, NT;      // R pixel rows in flight, NT = D * R live threads (block size = NT rounded up to waves)
+};
+DEVFN void gn_grp_block(const GnGrp& g, int& b, int& gr) {
+    int bid = blockIdx.x;
+    const int nblk = g.B * g.G;
+    const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    b = bid / g.G; gr = bid - b * g.G;
+    // (scalar registers: the buffer descriptors built from them must not end up in VGPRs -- waterfall loops around every buffer operation)
+    b = __builtin_amdgcn_readfirstlane(b); gr = __builtin_amdgcn_readfirstlane(gr);
+}
+// deterministic block sum of two values; every thread returns the same bits.  red: >= 2 * waves floats of LDS
+DEVFN void gn_grp_sum2(float& a, float& b, float* red) {
+#pragma unroll
+    for (int o = 32; o; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
+    const int w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    if ((threadIdx.x & 63) == 0) { red[2 * w] = a; red[2 * w + 1] = b; }
+    __syncthreads();
+    float ta = 0.f, tb = 0.f;
+    for (int i = 0; i < nw; i++) { ta += red[2 * i]; tb += red[2 * i + 1]; }
+    a = ta; b = tb;
+}
+// buffer descriptor over one sample's bytes behind the group's first channel: rows past HW and dead threads (offset 2^31) read zeros /
+// store nothing; the per-thread VGPR offset is fixed, the pixel-row step travels in the wave-uniform soffset
+DEVFN __amdgpu_buffer_rsrc_t gn_grp_rsrc(const void* p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
+}
+DEVFN unsigned gn_ld(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) { return (unsigned)__builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0); }
+DEVFN void gn_st(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, unsigned v) { __builtin_amdgcn_raw_buffer_store_b32(v, r, voff, soff, 0); }
+DEVFN float bflo(unsigned v) { return __uint_as_float(v << 16); }
+DEVFN float bfhi(unsigned v) { return __uint_as_float(v & 0xffff0000u); }
+DEVFN unsigned bfpack(float lo, float hi) {
+    return (unsigned)__builtin_bit_cast(unsigned short, f2bf(lo)) | ((unsigned)__builtin_bit_cast(unsigned short, f2bf(hi)) << 16);
+}
+
+template <int P, bool ACT, int MAXT>       // (the activation is a template parameter: a run-time branch per row made the compiler spill the slab)
+__global__ __launch_bounds__(MAXT) void gn_group_fwd_kernel(const bf16* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            bf16* __restrict__ y, float* __restrict__ stats, GnGrp g, float eps,
+                                                            const float* __restrict__ gamma1, const float* __restrict__ beta1, int split) {
+    __shared__ float red[32];
+    int b, gr;
+    gn_grp_block(g, b, gr);
+    if (gamma1 && b >= split) { gamma = gamma1; beta = beta1; }
+    const int d = threadIdx.x % g.D, r = threadIdx.x / g.D;
+    const bool live = r < g.R;
+    const size_t base = (size_t)b * g.HW * g.C + (size_t)gr * g.cpg;                  // first element of the (sample, group)
+    const unsigned bytes = (unsigned)(((size_t)g.HW * g.C - (size_t)gr * g.cpg) * 2);   // to the end of the sample: rows >= HW are out of range
+    const unsigned voff = live ? ((unsigned)r * (unsigned)g.C + 2u * d) * 2u : 0x80000000u;
+    const unsigned step = (unsigned)g.R * (unsigned)g.C * 2u;                            // bytes between a thread's pixel rows
+    const __amdgpu_buffer_rsrc_t rx = gn_grp_rsrc(x + base, bytes);
+    unsigned v[P];
+#pragma unroll
+    for (int i = 0; i < P; i++) v[i] = gn_ld(rx, voff, i * step);
+    float s = 0.f, q = 0.f;
+#pragma unroll
+    for (int i = 0; i < P; i++) { const float f0 = bflo(v[i]), f1 = bfhi(v[i]); s += f0 + f1; q += f0 * f0 + f1 * f1; }
+    gn_grp_sum2(s, q, red);
+    const float n = (float)g.cpg * (float)g.HW;
+    const float mean = s / n;
+    const float rstd = rsqrtf(fmaxf(q / n - mean * mean, 0.f) + eps);
+    if (threadIdx.x == 0 && stats) { float* o = stats + ((size_t)b * g.G + gr) * 2; o[0] = mean; o[1] = rstd; }
+    if (!live) return;
+    const int c = gr * g.cpg + 2 * d;
+    const float sc0 = rstd * gamma[c], sc1 = rstd * gamma[c + 1];
+    const float sh0 = beta[c] - mean * sc0, sh1 = beta[c + 1] - mean * sc1;
+    const __amdgpu_buffer_rsrc_t ry = gn_grp_rsrc(y + base, bytes);
+    // (the slab stays PACKED between the passes: without this the compiler keeps the unpacked floats of the first pass alive
+    // -- two extra registers per dword -- instead of re-deriving them with one shift / and)
+#pragma unroll
+    for (int i = 0; i < P; i++) asm volatile("" : "+v"(v[i]));
+#pragma unroll
+    for (int i = 0; i < P; i++) {
+        float f0 = bflo(v[i]) * sc0 + sh0, f1 = bfhi(v[i]) * sc1 + sh1;
+        if (ACT) { f0 = silu_t<bf16>(f0); f1 = silu_t<bf16>(f1); }
+        gn_st(ry, voff, i * step, bfpack(f0, f1));          // rows >= HW: dropped by the range check
+    }
+}
+
+// backward of the same: x of the (sample, group) stays in registers, dy is streamed twice in 8-row pieces (its second read comes out
+// of the L2 / Infinity Cache: the block has just fetched those 80 KB; holding dy as well -- 2 x 32 dwords plus the eight rows of
+// unpacked operands the scheduler keeps in flight around the exponentials -- spilled at every block size).  dgamma / dbeta (trainable
+// networks): the per-channel totals are folded over the pixel rows in LDS (fixed order) and added with one fp32 atomic per channel
+// and block.
+template <int P, bool ACT, int MAXT>
+__global__ __launch_bounds__(MAXT) void gn_group_bwd_kernel(const bf16* __restrict__ x, const bf16* __restrict__ dy, const float* __restrict__ stats,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            const bf16* __restrict__ add, bf16* __restrict__ dx, float* __restrict__ dgamma,
+                                                            float* __restrict__ dbeta, GnGrp g,
+                                                            const float* __restrict__ gamma1, const float* __restrict__ beta1, int split) {
+    static_assert(P % 8 == 0, "8-row pieces");
+    __shared__ float red[32];
+    extern __shared__ float part[];          // [R][D][4] per-thread channel partials (only with parameter gradients)
+    int b, gr;
+    gn_grp_block(g, b, gr);
+    if (gamma1 && b >= split) { gamma = gamma1; beta = beta1; }
+    const int d = threadIdx.x % g.D, r = threadIdx.x / g.D;
+    const bool live = r < g.R;
+    const size_t base = (size_t)b * g.HW * g.C + (size_t)gr * g.cpg;
+    const unsigned bytes = (unsigned)(((size_t)g.HW * g.C - (size_t)gr * g.cpg) * 2);
+    const unsigned voff = live ? ((unsigned)r * (unsigned)g.C + 2u * d) * 2u : 0x80000000u;
+    const unsigned step = (unsigned)g.R * (unsigned)g.C * 2u;
+    const __amdgpu_buffer_rsrc_t rx = gn_grp_rsrc(x + base, bytes), rd = gn_grp_rsrc(dy + base, bytes);
+    const float mean = stats[((size_t)b * g.G + gr) * 2], rstd = stats[((size_t)b * g.G + gr) * 2 + 1];
+    const int c = gr * g.cpg + 2 * d;
+    const float ga0 = gamma[c], ga1 = gamma[c + 1], be0 = beta[c], be1 = beta[c + 1];
+    unsigned xv[P];
+#pragma unroll
+    for (int i = 0; i < P; i++) xv[i] = gn_ld(rx, voff, i * step);
+    float a0 = 0.f, a1 = 0.f, c0 = 0.f, c1 = 0.f;        // sum d * xhat, sum d per channel (d = dy * act'(.)); rows >= HW read dy = 0
+    unsigned dv[8], dn[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) dv[j] = gn_ld(rd, voff, j * step);
+#pragma unroll
+    for (int i0 = 0; i0 < P; i0 += 8) {
+        if (i0 + 8 < P) {            // the next piece is in flight while this one is worked on
+#pragma unroll
+            for (int j = 0; j < 8; j++) dn[j] = gn_ld(rd, voff, (i0 + 8 + j) * step);
+        }
+        // (pins the unpacking of these rows to this piece: pure arithmetic on the slab otherwise floats to the top of the kernel --
+        // the instruction selector is not bound by sched_barrier -- and the unpacked floats of ALL rows stay live)
+#pragma unroll
+        for (int j = 0; j < 8; j++) asm volatile("" : "+v"(xv[i0 + j]));
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const float h0 = (bflo(xv[i0 + j]) - mean) * rstd, h1 = (bfhi(xv[i0 + j]) - mean) * rstd;
+            float d0 = bflo(dv[j]), d1 = bfhi(dv[j]);
+            if (ACT) { d0 *= silu_grad_t<bf16>(h0 * ga0 + be0); d1 *= silu_grad_t<bf16>(h1 * ga1 + be1); }
+            a0 += d0 * h0; a1 += d1 * h1; c0 += d0; c1 += d1;
+        }
+        // (and the piece's arithmetic ends here: without the dependency the exponentials sink below the next pieces' loads and all of
+        // dy is live at once; "memory": the next piece's loads stay behind it)
+        asm volatile("" : "+v"(a0), "+v"(a1), "+v"(c0), "+v"(c1) : : "memory");
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 8; j++) dv[j] = dn[j];
+    }
+    if (dgamma && dbeta) {
+        if (live) { float* o = part + ((size_t)r * g.D + d) * 4; o[0] = a0; o[1] = c0; o[2] = a1; o[3] = c1; }
+        __syncthreads();
+        if ((int)threadIdx.x < g.D * 4) {        // (channel pair, stat) column summed over the rows by one thread, 4 independent chains
+            float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
+            const size_t st = (size_t)g.D * 4;
+            int rr = 0;
+            for (; rr + 3 < g.R; rr += 4) {
+                t0 += part[rr * st + threadIdx.x]; t1 += part[(rr + 1) * st + threadIdx.x];
+                t2 += part[(rr + 2) * st + threadIdx.x]; t3 += part[(rr + 3) * st + threadIdx.x];
+            }
+            for (; rr < g.R; rr++) t0 += part[rr * st + threadIdx.x];
+            const float tot = (t0 + t1) + (t2 + t3);
+            const int dd = threadIdx.x >> 2, k = threadIdx.x & 3;          // k: 0 a(ch 2dd), 1 c(ch 2dd), 2 a(ch 2dd+1), 3 c(ch 2dd+1)
+            const int ch = gr * g.cpg + 2 * dd + (k >> 1);
+            unsafeAtomicAdd(((k & 1) ? dbeta : dgamma) + ch, tot);
+        }
+    }
+    float s1 = ga0 * c0 + ga1 * c1, s2 = ga0 * a0 + ga1 * a1;
+    gn_grp_sum2(s1, s2, red);
+    if (!live) return;
+    const float n = (float)g.cpg * (float)g.HW;
+    const float m1 = s1 / n, m2 = s2 / n;
+    const __amdgpu_buffer_rsrc_t ra = gn_grp_rsrc(add ? add + base : x, add ? bytes : 0u), ro = gn_grp_rsrc(dx + base, bytes);
+    unsigned av[8], an[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) { dv[j] = gn_ld(rd, voff, j * step); av[j] = gn_ld(ra, voff, j * step); }   // no residual-branch gradient: zero-length buffer -> zeros
+#pragma unroll
+    for (int i0 = 0; i0 < P; i0 += 8) {
+        if (i0 + 8 < P) {
+#pragma unroll
+            for (int j = 0; j < 8; j++) { dn[j] = gn_ld(rd, voff, (i0 + 8 + j) * step); an[j] = gn_ld(ra, voff, (i0 + 8 + j) * step); }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; j++) asm volatile("" : "+v"(xv[i0 + j]));       // (as above; also keeps the slab packed between the passes)
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const float h0 = (bflo(xv[i0 + j]) - mean) * rstd, h1 = (bfhi(xv[i0 + j]) - mean) * rstd;
+            float d0 = bflo(dv[j]), d1 = bfhi(dv[j]);
+            if (ACT) { d0 *= silu_grad_t<bf16>(h0 * ga0 + be0); d1 *= silu_grad_t<bf16>(h1 * ga1 + be1); }
+            const float o0 = rstd * (d0 * ga0 - m1 - h0 * m2) + bflo(av[j]), o1 = rstd * (d1 * ga1 - m1 - h1 * m2) + bfhi(av[j]);
+            gn_st(ro, voff, (i0 + j) * step, bfpack(o0, o1));
+        }
+        asm volatile("" : : : "memory");
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 8; j++) { dv[j] = dn[j]; av[j] = an[j]; }
+    }
+}
+
+// Geometry of the per-group one-pass kernels, or false.  pmax640 / pmax1024: the largest per-thread dword count the caller has a kernel
+// for in a block of <= 640 / <= 1024 threads.  mask bit 0: forward, bit 1: backward (SIDLSG_GN_GROUP, A/B switch).
+static bool gn_grp_geom(GnGrp& g, int& threads, int& P, int B, int HW, int C, int G, int pmax640, int pmax1024, int dirbit) {
+    // Measured (MI355X, B = 16, tools/bench_kernels.py norm, SIDLSG_GN_GROUP=0/3, profiles/r04_gn_group_ab.txt): the BACKWARD wins where a
+    // group is at least 40 bytes of a pixel and its slab at most ~128 KB -- 32x32: 640 channels 36 -> 26 us, 1280 channels 63 -> 38 us,
+    // 1920 channels 70 -> 68 us -- and loses at 64x64 (320 channels: 51 -> 73 us, 640: 82 -> 107 us): with 20-byte runs every 128-byte
+    // line is pulled through the L2 by six different blocks, and a 160 KB slab leaves one block per CU.  The FORWARD ties or loses
+    // everywhere (29.5 -> 33 us at 64x64 x 320, 37-41 -> 36.5 us at 32x32 x 1920).  Inside the step the backward under those two limits
+    // is neutral (SIDLSG_GN_GROUP=2 vs 0, three alternations: 208.3 vs 208.1 ms): the kernels stay in the library, tested, and OFF by
+    // default (mask bit 2 lifts the limits for measurements and for the test).
+    static const int mask = getenv("SIDLSG_GN_GROUP") ? atoi(getenv("SIDLSG_GN_GROUP")) : 0;
+    static const int min_hw = getenv("SIDLSG_GN_GROUP_MIN_HW") ? atoi(getenv("SIDLSG_GN_GROUP_MIN_HW")) : 1024;
+    if (!((mask >> dirbit) & 1) || C % G || (C & 1) || B <= 0 || HW < min_hw) return false;
+    const int cpg = C / G;
+    if (cpg & 1) return false;
+    if (!(mask & 4) && (cpg < 20 || (size_t)HW * cpg * 2 > (128u << 10))) return false;
+    g.B = B; g.HW = HW; g.C = C; g.G = G; g.cpg = cpg; g.D = cpg / 2;
+    if (g.D > 64 || (size_t)HW * C * 2 >= 0x7fffffffull) return false;
+    for (int pass = 0; pass < 2; pass++) {
+        const int nt = pass ? 1024 : 640, pmax = pass ? pmax1024 : pmax640;
+        int R = nt / g.D; if (R > HW) R = HW; if (R < 1) continue;
+        const int p = (HW + R - 1) / R;
+        if (p <= pmax) { g.R = R; g.NT = g.D * R; threads = (g.NT + 63) / 64 * 64; P = p; return true; }
+    }
+    return false;
+}
+
 // Geometry of the one-pass kernels for a shape, or false: pmax = the largest per-thread chunk count the caller has a kernel for.
 static bool gn_small_geom(GnSmall& g, int& threads, int& P, int B, int HW, int C, int G, int pmax) {
     static const bool on = !(getenv("SIDLSG_GN_ONEPASS") && atoi(getenv("SIDLSG_GN_ONEPASS")) == 0);      // A/B switch
@@ -758,6 +983,19 @@ static int groupnorm_fwd_t(const void* x, const float* gamma, const float* beta,
             return sidlsg_last_error();
         }
     }
+    if constexpr (std::is_same<T, bf16>::value && !F8) {
+        GnGrp gg; int th, P;
+        if (gn_grp_geom(gg, th, P, B, HW, C, G, 64, 64, 0)) {
+#define GN_GF3(PP, AA, TT) SIDLSG_LAUNCH((gn_group_fwd_kernel<PP, AA, TT>), dim3(B * G), dim3(th), 0, s, (const bf16*)x, gamma, beta, (bf16*)y, stats, gg, eps, gamma1, beta1, B / 2)
+#define GN_GF2(PP, AA) do { if (th <= 640) GN_GF3(PP, AA, 640); else GN_GF3(PP, AA, 1024); } while (0)
+#define GN_GF(PP) do { if (silu) GN_GF2(PP, true); else GN_GF2(PP, false); } while (0)
+            if (P <= 16) GN_GF(16); else if (P <= 32) GN_GF(32); else GN_GF(64);
+#undef GN_GF3
+#undef GN_GF2
+#undef GN_GF
+            return sidlsg_last_error();
+        }
+    }
     const int threads = g.C8 * g.rows;
     SIDLSG_LAUNCH(gn_stats_kernel<T>, dim3(g.nch, B), dim3(threads), (size_t)g.rows * C * 2 * sizeof(float), s,
                        (const T*)x, ws, g);
@@ -785,6 +1023,20 @@ static int groupnorm_bwd_t(const void* x, const void* dy, const float* stats, co
 #define GN_SB(PP) SIDLSG_LAUNCH((gn_small_bwd_kernel<PP>), dim3(B * gs.ngr), dim3(th), lds, s, (const bf16*)x, (const bf16*)dy, stats, gamma, beta, (const bf16*)dres, (bf16*)dx, dgamma, dbeta, gs, silu, gamma1, beta1, B / 2)
             if (P <= 2) GN_SB(2); else if (P <= 4) GN_SB(4); else GN_SB(8);
 #undef GN_SB
+            return sidlsg_last_error();
+        }
+    }
+    if constexpr (std::is_same<T, bf16>::value) {
+        GnGrp gg; int th, P;
+        if (gn_grp_geom(gg, th, P, B, HW, C, G, 64, 32, 1)) {      // x in registers (<= 64 dwords per thread in <= 640 threads, 32 in <= 1024), dy streamed twice
+            const size_t lds = (dgamma && dbeta) ? (size_t)gg.R * gg.D * 4 * sizeof(float) : 0;
+#define GN_GB3(PP, AA, TT) SIDLSG_LAUNCH((gn_group_bwd_kernel<PP, AA, TT>), dim3(B * G), dim3(th), lds, s, (const bf16*)x, (const bf16*)dy, stats, gamma, beta, (const bf16*)dres, (bf16*)dx, dgamma, dbeta, gg, gamma1, beta1, B / 2)
+#define GN_GB2(PP, AA) do { if (th <= 640) GN_GB3(PP, AA, 640); else GN_GB3(PP, AA, 1024); } while (0)
+#define GN_GB(PP) do { if (silu) GN_GB2(PP, true); else GN_GB2(PP, false); } while (0)
+            if (P <= 16) GN_GB(16); else if (P <= 32) GN_GB(32); else GN_GB(64);
+#undef GN_GB3
+#undef GN_GB2
+#undef GN_GB
             return sidlsg_last_error();
         }
     }

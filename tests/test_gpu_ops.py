@@ -216,7 +216,13 @@ def test_linear_autograd(dev):
 @pytest.mark.parametrize('B,HW,C,G,silu', [(2, 64, 32, 8, 1), (3, 1024, 320, 32, 1), (2, 256, 1920, 32, 1), (2, 4096, 320, 32, 0),
                                            (1, 64, 2560, 32, 1), (2, 100, 80, 8, 0), (16, 64, 1280, 32, 1), (4, 256, 1280, 32, 0),
                                            (3, 1024, 640, 32, 1), (2, 1024, 1280, 32, 1), (2, 256, 640, 32, 1), (2, 256, 2560, 32, 1),
-                                           (2, 1024, 960, 32, 1), (1, 1, 64, 8, 1), (2, 7, 320, 32, 0), (5, 333, 640, 32, 1)])
+                                           (2, 1024, 960, 32, 1), (1, 1, 64, 8, 1), (2, 7, 320, 32, 0), (5, 333, 640, 32, 1),
+                                           # >= 32x32: shapes of the per-group one-pass kernels (gn_group_fwd / gn_group_bwd: one (sample, group) per
+                                           # block, x in registers) -- 5 / 10 / 15 / 20 / 30 dwords per pixel, 640 and 1024 threads, ragged pixel
+                                           # counts, 96x96.  Off by default (measured neutral in the step: csrc/norm.hip, gn_grp_geom);
+                                           # test_groupnorm_group_kernels_all_shapes runs this list in a process with SIDLSG_GN_GROUP=7 (every shape)
+                                           (2, 4096, 320, 32, 1), (2, 4096, 640, 32, 1), (1, 4096, 960, 32, 1), (2, 1024, 1920, 32, 1),
+                                           (1, 1100, 320, 32, 1), (3, 1024, 320, 32, 0), (1, 9216, 320, 32, 1), (17, 1024, 640, 32, 1)])
 def test_groupnorm(dev, B, HW, C, G, silu):
     from sid_lsg_amd import ops
     x = (rnd(B, HW, C, seed=1).float() * 1.5 + 0.3).to(BF16)
@@ -237,6 +243,19 @@ def test_groupnorm(dev, B, HW, C, G, silu):
     close(xd.grad, xr.grad, 1.5e-2, 'dx')
     close(gm.grad, gr.grad, 3e-3, 'dgamma')
     close(bm.grad, br.grad, 3e-3, 'dbeta')
+
+
+def test_groupnorm_group_kernels_all_shapes(dev):
+    """The per-group one-pass GroupNorm kernels on every shape they can take, forward and backward (the dispatch limits are read once
+    per process: a child process with SIDLSG_GN_GROUP=7 re-runs the large shapes of test_groupnorm)."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, SIDLSG_GN_GROUP='7')
+    r = subprocess.run([sys.executable, '-m', 'pytest', __file__, '-q', '-x', '-k', 'test_groupnorm and (4096 or 1024 or 1100 or 9216)'],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert ' passed' in r.stdout
 
 
 @pytest.mark.parametrize('rows,C', [(100, 320), (4096, 640), (257, 1280), (64, 32), (300, 80)])
