@@ -1009,6 +1009,9 @@ def geglu(h):
     return _GEGLU.apply(h)
 
 
+_GEGLU_FUSE_MIN_K = int(os.environ.get('SIDLSG_GEGLU_FUSE_MIN_K', '640'))     # A/B knob: smallest K at which the fused FF-in + GEGLU kernel is used when h is kept
+
+
 class _LinearGEGLU(torch.autograd.Function):
     """y = GEGLU(x W^T + b) with the projection and the gating in ONE kernel (sidlsg_gemm_geglu_bf16): the separate GEGLU pass over
     h = x W^T + b [M, 2F] -- at the 64x64 stage of SD1.5 a 335 MB read that took longer than the projection itself -- disappears.
@@ -1067,8 +1070,9 @@ def linear_geglu(x, weight, bias, w16, w16t, with_h=False):
         keep_h = torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad or (bias is not None and bias.requires_grad))
         # measured (tools/ab/geglu_fused.py, MI355X, batch 16): K = 640 / 1280 (32x32 / 16x16 stages) 177 -> 165 us / 134 -> 120 us with h
         # kept; K = 320 (64x64 stage) only pays when h is NOT kept (251 -> 190 us): with h the A-stationary GEMM + the stand-alone
-        # GEGLU kernel (164 + 87 us) beat the fused direct-to-LDS kernel (262 us)
-        if not keep_h or w16.shape[1] >= 640:
+        # GEGLU kernel (164 + 87 us) beat the fused direct-to-LDS kernel (262 us); inside the step the two are equal (SIDLSG_GEGLU_FUSE_MIN_K=320
+        # vs 640, eight alternations: 208.5 vs 208.7 ms, tools/_run50.sh)
+        if not keep_h or w16.shape[1] >= _GEGLU_FUSE_MIN_K:
             if with_h and keep_h:
                 return _LinearGEGLU.apply(x, weight, bias, w16, w16t, keep_h, True)
             y = _LinearGEGLU.apply(x, weight, bias, w16, w16t, keep_h)

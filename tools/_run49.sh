@@ -1,0 +1,5 @@
+set -x
+mkdir -p gpurun_out; rm -f gpurun_out/r49_ab.log
+run() { env $1 timeout 600 python bench.py --no-cpu-baseline --no-kernel-timing --steps 30 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$1', d['ms_per_step'], d['value'], d['loss_check'])" >> gpurun_out/r49_ab.log; }
+run SIDLSG_GEGLU_FUSE_MIN_K=640; run SIDLSG_GEGLU_FUSE_MIN_K=320; run SIDLSG_GEGLU_FUSE_MIN_K=640; run SIDLSG_GEGLU_FUSE_MIN_K=320; run SIDLSG_GEGLU_FUSE_MIN_K=640; run SIDLSG_GEGLU_FUSE_MIN_K=320
+cat gpurun_out/r49_ab.log
