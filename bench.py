@@ -43,41 +43,6 @@ def synth_prompts(n, seed):
     return out
 
 
-class KernelTimer:
-    """HIP-event timing of ONE entry point of the C ABI on the stream it is launched on (torch's current stream).
-    Every `stride`-th launch is bracketed by an event pair (stride 7 is coprime to the per-layer launch pattern, so
-    every shape is sampled); timing all ~1000 launches per step costs ~3 % of the step, every 7th < 0.5 %."""
-
-    def __init__(self, lib, name, flops_fn, stride=7):
-        self.lib, self.name, self.flops_fn, self.stride = lib, name, flops_fn, stride
-        self.events, self.flops, self.orig, self.calls = [], 0.0, None, 0
-
-    def __enter__(self):
-        self.orig = getattr(self.lib, self.name)
-        orig, self_ = self.orig, self
-
-        def timed(*a):
-            self_.calls += 1
-            if self_.calls % self_.stride:
-                return orig(*a)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            orig(*a)
-            e1.record()
-            self_.events.append((e0, e1))
-            self_.flops += self_.flops_fn(*a)
-        self.lib.__dict__[self.name] = timed
-        return self
-
-    def __exit__(self, *exc):
-        self.lib.__dict__[self.name] = self.orig
-
-    def result(self):
-        torch.cuda.synchronize()
-        ms = sum(a.elapsed_time(b) for a, b in self.events)
-        return dict(launches=len(self.events), calls=self.calls, ms=ms, flops=self.flops)
-
-
 class DispatchTrace:
     """Per-family kernel time of the step from per-DISPATCH timestamps (include/sidlsg_hip.h "in-library kernel timing"): every
     `stride`-th call of a family launches its kernels with start / stop events bound to the kernel's own dispatch packet, so the
@@ -107,43 +72,58 @@ class DispatchTrace:
         return out
 
 
-def conv_flops(*a):
-    # sidlsg_conv3x3_bf16(X, ldx, W, Y, ldc, bias, res, ldres, rowvec, ld_rowvec, B, H, Wd, Cin, Cout, stride, ups, alpha, flags, stream)
-    B, H, Wd, Cin, Cout, stride = a[10], a[11], a[12], a[13], a[14], a[15]
-    Ho, Wo = (H - 1) // stride + 1, (Wd - 1) // stride + 1
-    return 2.0 * B * Ho * Wo * Cout * 9 * Cin
+LINE_LIMIT = 4096          # bytes of the ONE stdout line (the driver keeps the last ~8 KB of stdout)
+FAMILY_KERNEL = {'gemm': 'gemm_v3_kernel<0> (+gemm_bf16/gemm_as/gemm_finish): dense GEMM fwd+dgrad', 'conv': 'gemm_v3_kernel<1>: implicit-GEMM conv3x3 fwd+dgrad',
+                 'attn': 'attn_q_kernel<*,*,0>: flash attention fwd', 'attn_bwd': 'attn_q_kernel<*,*,1> + attn_dkdv_kernel: flash attention bwd',
+                 'wgrad': 'wgrad_v2_kernel<0>/wgrad_v2s_kernel (+wgrad_reduce): dense dW', 'conv_wgrad': 'wgrad_v2f/v2wf/v2<1> (+wgrad_reduce): conv dW',
+                 'gn': 'gn_stats+gn_apply / gn_rows / gn_small: GroupNorm+SiLU fwd', 'gn_bwd': 'gn_bwd_stats+gn_bwd_apply / gn_small_bwd: GroupNorm+SiLU bwd',
+                 'ln': 'ln_fwd_kernel', 'ln_bwd': 'ln_bwd_kernel'}
 
 
-def gemm_flops(*a):
-    # sidlsg_gemm_bf16(A, lda, W, C, ldc, bias, res, ldres, rowvec, ld_rowvec, rows_per_batch, M, N, K, alpha, flags, stream)
-    return 2.0 * a[11] * a[12] * a[13]
+def _r(x, n=4):
+    return None if x is None else (round(x, n) if isinstance(x, float) else x)
 
 
-def wgrad_flops(*a):
-    # sidlsg_wgrad_bf16(dY, ldy, A, lda, dW, dBias, M, N, K, stream)
-    return 2.0 * a[6] * a[7] * a[8]
-
-
-def conv_wgrad_flops(*a):
-    # sidlsg_conv3x3_wgrad_bf16(dY, ldy, X, ldx, dW, dBias, B, H, Wd, Cin, Cout, stride, ups, stream)
-    B, H, Wd, Cin, Cout, stride = a[6], a[7], a[8], a[9], a[10], a[11]
-    Ho, Wo = (H - 1) // stride + 1, (Wd - 1) // stride + 1
-    return 2.0 * B * Ho * Wo * Cout * 9 * Cin
-
-
-def attn_bwd_flops(*a):
-    # sidlsg_attn_bwd(Q, K, V, O, dO, LSE, dQ, dK, dV, delta, B, H, Nq, Nk, D, ...): 5 contractions of the forward's 2
-    return 2.5 * 4.0 * a[10] * a[11] * a[12] * a[13] * a[14]
-
-
-def gn_bytes(*a):
-    # sidlsg_groupnorm_fwd(x, gamma, beta, y, stats, ws, B, HW, C, G, eps, silu, stream): algorithmic bytes = read x + write y (bf16)
-    return 2.0 * 2.0 * a[6] * a[7] * a[8]
-
-
-def attn_flops(*a):
-    # sidlsg_attn_fwd(Q, K, V, O, LSE, B, H, Nq, Nk, D, ...): QK^T + PV
-    return 4.0 * a[5] * a[6] * a[7] * a[8] * a[9]
+def compact_line(full):
+    """The ONE JSON line of stdout (< LINE_LIMIT bytes; tests/test_host_logic.py::test_bench_line_is_compact) from the full result
+    dict, which goes to bench_detail.json.  Keys: the driver's contract + `roofline` of the dominant kernel family (live,
+    per-dispatch timestamps over the timed region; `traffic` is null: HBM-side PMC bytes need their own serialising rocprofv3
+    passes and live under profiles/) + one fraction per other family + `cpu_baseline`."""
+    keep = ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype', 'data')
+    out = {k: _r(full[k]) for k in keep}
+    c = full['config']
+    out['config'] = {'workload': c['workload'][:200], 'global_batch': c['global_batch'], 'parallelism': c['parallelism'],
+                     'teacher_weights': c['teacher_weights']}
+    for k in ('step_tflops', 'step_mfma_frac', 'loss_check', 'grouped_frozen_pass', 'graph', 'peak_mem_gb', 'loss_fake', 'loss_G'):
+        if k in full:
+            out[k] = _r(full[k])
+    for k in ('teacher_pass', 'frozen_pair_pass'):
+        if full.get(k):
+            out[k] = {'ms': _r(full[k]['ms'], 3), 'mfma_frac': _r(full[k]['mfma_frac'])}
+    if full.get('comm'):
+        cm = full['comm']
+        out['comm'] = {'comm_exposed_ms': _r(cm['comm_exposed_ms'], 3), 'exposed_ms_per_step': {k: _r(v, 3) for k, v in cm['exposed_ms_per_step'].items()},
+                       'messages_per_step': _r(cm['messages_per_step'], 2), 'bytes_per_step': cm['bytes_per_step'],
+                       'allreduce_algbw_GBps': _r(cm['allreduce_algbw_GBps'], 2), 'allreduce_busbw_GBps': _r(cm['allreduce_busbw_GBps'], 2),
+                       'backend': cm['backend']}
+    r = full.get('roofline')
+    if r:
+        iso = r.get('isolated') or {}
+        out['roofline'] = {'family': r['family'], 'kernel': FAMILY_KERNEL.get(r['family'], r['family']), 'bound': r['bound'],
+                           'achieved': _r(r['achieved'], 2), 'peak': r['peak'], 'unit': r['unit'], 'frac': _r(r['frac']),
+                           'isolated_frac': _r(iso.get('frac')), 'frac_of_per_call_roofline': _r(r.get('frac_of_per_call_roofline')),
+                           'avg_launch_ms': _r(r['avg_launch_ms'], 5), 'launches_timed': r['launches'], 'est_ms_per_step': _r(r['est_ms_per_step'], 2),
+                           'traffic': None, 'timing': 'per-dispatch start/stop timestamps over the timed region (3 streams share the chip); '
+                                                      'isolated_frac: same kernels, streams folded into one'}
+        out['fracs'] = {k[len('roofline_'):]: [_r(v['frac']), _r((v.get('isolated') or {}).get('frac')), _r(v['est_ms_per_step'], 1)]
+                        for k, v in full.items() if k.startswith('roofline_')}
+        out['fracs_legend'] = '[frac of peak in the timed region, stand-alone, est ms/step]; gn/ln: of 8 TB/s, others of 2.5 PFLOP/s'
+    cb = full.get('cpu_baseline')
+    if cb:
+        out['cpu_baseline'] = {'value': _r(cb['value'], 5), 'unit': cb['unit'], 'cores': cb['cores'], 'kind': cb['kind'], 'sample': cb['sample'][:120]}
+    out['detail'] = 'bench_detail.json'
+    assert len(json.dumps(out)) < LINE_LIMIT, 'bench line outgrew the driver\'s tail'
+    return out
 
 
 def cpu_baseline(arch, threads, kappa=1.5):
@@ -183,9 +163,9 @@ def cpu_baseline(arch, threads, kappa=1.5):
     out = sid_ref.sid_iteration_ref(nets, st, DDPMSchedulerRef(), inputs, hp)
     dt = time.time() - t0
     return dict(value=b / dt, unit='images/s', cores=threads, kind='port',
-                sample=f'1 full SiD-LSG iteration (fake-score step + generator step + Adam + EMA) of the fp32 CPU restatement of the '
-                       f'reference loop (oracle/sid_ref.py on oracle/unet_ref.py), {arch} full size, batch 1, 64x64x4 latents, kappa={kappa}: '
-                       f'{dt:.1f} s on {threads} threads (setup {t_setup:.0f} s not timed); loss_fake {out["loss_fake"]:.1f}')
+                sample=f'1 full iteration of oracle/sid_ref.py (fp32 CPU restatement), {arch} full size, batch 1, 64x64x4, {dt:.1f} s',
+                detail=f'fake-score step + generator step + Adam + EMA, kappa={kappa}, {threads} threads (setup {t_setup:.0f} s not timed); '
+                       f'loss_fake {out["loss_fake"]:.1f}')
 
 
 LOSS_REFERENCE = os.path.join(ROOT, 'tests', 'golden', 'bench_loss_reference.json')
@@ -358,12 +338,6 @@ def main():
     ps = any(getattr(m, 'prescaled', False) for m in phi.modules())
     ATTN_FWD, ATTN_BWD = ('sidlsg_attn_fwd_ps', 'sidlsg_attn_bwd_ps') if ps else ('sidlsg_attn_fwd', 'sidlsg_attn_bwd')
 
-    def make_timers():
-        """One HIP-event timer per kernel family of the step (entry point of the C ABI, work per launch, sampling stride)."""
-        return dict(conv=KernelTimer(lib, 'sidlsg_conv3x3_bf16', conv_flops), gemm=KernelTimer(lib, 'sidlsg_gemm_bf16', gemm_flops, stride=11),
-                    attn=KernelTimer(lib, ATTN_FWD, attn_flops, stride=3), attn_bwd=KernelTimer(lib, ATTN_BWD, attn_bwd_flops, stride=3),
-                    wgrad=KernelTimer(lib, 'sidlsg_wgrad_bf16', wgrad_flops, stride=7), conv_wgrad=KernelTimer(lib, 'sidlsg_conv3x3_wgrad_bf16', conv_wgrad_flops, stride=5),
-                    gn=KernelTimer(lib, 'sidlsg_groupnorm_fwd', gn_bytes, stride=5))
     trace = DispatchTrace(lib)
     tracing = not args.no_kernel_timing and rank == 0 and not S.use_graph
     if tracing:      # rooflines of the step's kernel families, sampled live over the timed region
@@ -403,19 +377,6 @@ def main():
             torch.cuda.synchronize()
             if rank == 0:
                 timers = trace.stop()
-    # For comparison, the OLD way of timing (HIP events recorded around sampled launches; rounds 1-3): two extra iterations after
-    # the timed region, same stream concurrency -- `event_bracketed` in the roofline objects.
-    bracketed = {}
-    if not args.no_kernel_timing:          # rank-independent condition: the iterations exchange gradients
-        tms = make_timers() if rank == 0 else {}
-        for tm in tms.values():
-            tm.__enter__()
-        for it in range(args.warmup + args.steps + 10, args.warmup + args.steps + 12):
-            one_iteration(it)
-        torch.cuda.synchronize()
-        for k, tm in tms.items():
-            tm.__exit__()
-            bracketed[k] = tm.result()
     # The timed region runs the teacher (or the early generator forward) on a second HIP stream and the weight gradients on a
     # third (ops._OnWgradStream): kernels of the streams share the chip, so a kernel's duration over the timed region (what
     # rocprofv3 --kernel-trace reports for the same command) is longer than the kernel's own.  A few extra iterations AFTER the
@@ -477,8 +438,8 @@ def main():
     value = args.steps * batch_size / dt
     f_gmac = F_GMAC.get(args.arch, 0.0)
     if args.resolution != 512:          # analytic walk of the oracle for other latent sizes (attention is not linear in pixels)
-        from oracle.unet_ref import CONFIGS as _RC, unet_forward_macs
-        f_gmac = unet_forward_macs(_RC[args.arch], lat, lat) / 1e9
+        from sid_lsg_amd.unet import CONFIGS as _HC, unet_forward_macs
+        f_gmac = unet_forward_macs(_HC[args.arch], lat, lat) / 1e9
     f_tflop = 2 * f_gmac / 1000.0
     img_tflop = 18 * f_tflop if args.kappa != 1 else 11 * f_tflop
     out = {
@@ -556,44 +517,8 @@ def main():
                 a2 = q['flops'] / (q['ms'] * 1e-3) / div
                 o['isolated'] = {'achieved': a2, 'frac': a2 / peak, 'avg_launch_ms': q['ms'] / max(q['launches'], 1), 'launches': q['launches'],
                                  'what': '3 iterations after the timed region with the side-stream and weight-gradient-stream overlap off'}
-            q = bracketed.get(key)
-            if q is not None and q['ms'] > 0:
-                a3 = q['flops'] / (q['ms'] * 1e-3) / div
-                o['event_bracketed'] = {'achieved': a3, 'frac': a3 / peak, 'avg_launch_ms': q['ms'] / max(q['launches'], 1), 'launches': q['launches'],
-                                        'what': 'HIP events recorded AROUND sampled launches (the figure of rounds 1-3), 2 iterations after the timed '
-                                                'region with the same stream concurrency: includes the two barrier packets and the dispatch gap'}
             return o
         objs = {k: roof(k) for k in timers}
-        # HBM-side bytes per call: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, gfx950-corrected) of the SAME entry point
-        # on the SAME layer shapes, collected with the kernel micro-benchmark (tools/collect_traffic.sh -> tools/bench_kernels.py, batch
-        # 16: kernels alone) -- not inside this timed step (PMC passes serialise kernels); the committed summaries say so themselves
-        TRAFFIC = {'gemm': ('gemm', 'gemm'), 'conv': ('conv', 'conv'), 'wgrad': ('wgrad', 'wgrad'), 'conv_wgrad': ('wgrad', 'conv_wgrad'),
-                   'attn': ('attn', 'attn'), 'attn_bwd': ('attn', 'attn_bwd'), 'gn': ('norm', 'gn'), 'gn_bwd': ('norm', 'gn_bwd'),
-                   'ln': ('norm', 'ln'), 'ln_bwd': ('norm', 'ln_bwd')}
-        for key, (mode, fam) in TRAFFIC.items():
-            pmc = os.path.join(ROOT, 'profiles', f'r04_traffic_{mode}.json')
-            if key in objs and os.path.isfile(pmc):
-                ent = json.load(open(pmc)).get('families', {}).get(fam)
-                if ent and ent.get('calls'):
-                    objs[key]['traffic'] = ent['avg_hbm_side_bytes_per_call']
-                    objs[key]['traffic_over_algorithmic'] = ent.get('traffic_over_algorithmic')      # both of the micro-benchmark's calls
-                    objs[key]['traffic_source'] = (f'profiles/r04_traffic_{mode}.json: HBM-side bytes per call, micro-benchmark of the step\'s shapes at '
-                                                   'batch 16 (compare with the same benchmark\'s algorithmic bytes, not with this step\'s mix)')
-        # the same family under `rocprofv3 --kernel-trace --stats` (committed run of this command, profiles/): the profiler's interception slows
-        # the host, the streams overlap less and every kernel's begin -> end interval shrinks towards its stand-alone duration -- the figure the
-        # committed kernel_stats CSV reproduces, next to this run's in-region (`frac`) and stand-alone (`isolated.frac`) figures
-        ref = os.path.join(ROOT, 'profiles', 'r04_bench_under_rocprof.json')
-        if os.path.isfile(ref):
-            try:
-                refd = json.loads(open(ref).read().strip().splitlines()[-1])
-                for key in objs:
-                    e = refd.get('roofline_' + key)
-                    if e:
-                        objs[key]['under_rocprofv3'] = {'frac': e['frac'], 'avg_launch_ms': e['avg_launch_ms'], 'est_ms_per_step': e['est_ms_per_step'],
-                                                        'source': 'profiles/r04_bench_under_rocprof.json (this command under rocprofv3 --kernel-trace --stats; '
-                                                                  'kernel durations: profiles/r04_bench_step_kernel_stats.csv)'}
-            except (ValueError, KeyError):
-                pass
         # `roofline` = the family that takes the largest share of the step (dense GEMM since round 2's conv work; the MFMA
         # families are compared by est_ms_per_step); every family keeps its own object
         mfma = ['conv', 'gemm', 'attn_bwd', 'attn', 'wgrad', 'conv_wgrad']
@@ -605,7 +530,13 @@ def main():
         # torch's CPU backend degrades badly when oversubscribed on many-core hosts (256 threads: 160 s per forward);
         # 32 threads is the measured sweet spot class for one fp32 conv-heavy forward -> cores = threads actually used
         out['cpu_baseline'] = cpu_baseline(args.arch, min(os.cpu_count() or 1, 32), kappa=args.kappa)
-    print(json.dumps(out), flush=True)
+    detail = os.environ.get('SIDLSG_BENCH_DETAIL', os.path.join(ROOT, 'bench_detail.json'))
+    try:          # everything (every family's full roofline object, loss_check_detail, comm, ...) goes to a file ...
+        with open(detail, 'w') as f:
+            json.dump(out, f, indent=1)
+    except OSError as e:
+        print(f'bench.py: could not write {detail}: {e}', file=sys.stderr)
+    print(json.dumps(compact_line(out)), flush=True)          # ... and ONE line of < 4 KB to stdout (the driver keeps ~8 KB of tail)
     _shutdown(world)
 
 

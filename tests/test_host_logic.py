@@ -466,3 +466,52 @@ def replay_metrics_golden(golden_dir, device):
 
 def test_metrics_pipeline_matches_reference_golden_cpu(golden_dir):
     replay_metrics_golden(golden_dir, 'cpu')
+
+
+def test_bench_line_is_compact():
+    """The driver keeps the last ~8 KB of bench.py's stdout (round 4's 22 KB line lost its head: `parsed: null`).  The ONE stdout
+    line is built by bench.compact_line from the full result dict: < 4 KB even with every family present and paragraph-long
+    strings in the full objects, and it carries the contract's keys + `roofline` + `cpu_baseline`."""
+    import bench
+    fam = {'bound': 'mfma', 'kernel': 'k' * 300, 'achieved': 316.92153742307295, 'peak': 2500.0, 'unit': 'TFLOP/s', 'frac': 0.12676861496922917,
+           'timing': 't' * 400, 'frac_of_per_call_roofline': 0.1630670197494531, 'algorithmic_GBps': 1073.8, 'frac_hbm': 0.134, 'traffic': None,
+           'launches': 3935, 'launches_total': 27540, 'kernels_timed': 4276, 'avg_launch_ms': 0.07589743257946367, 'est_ms_per_step': 104.51076466192148,
+           'algorithmic_tflop_per_launch': 0.024, 'isolated': {'achieved': 585.5, 'frac': 0.2342061989362917, 'avg_launch_ms': 0.0409, 'launches': 591, 'what': 'w' * 200}}
+    full = {'metric': 'distillation images/sec (512^2, SD1.5, kappa=1.5)', 'value': 38.43796376494744, 'unit': 'images/s', 'n_gpus': 8, 'steps': 20, 'warmup': 5,
+            'ms_per_step': 208.12757015228271, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
+            'config': {'workload': 'w' * 400, 'global_batch': 64, 'parallelism': 'dp8', 'teacher_weights': 'bf16'}, 'step_tflops': 555.77, 'step_mfma_frac': 0.2223,
+            'graph': False, 'grouped_frozen_pass': False, 'host_enqueue_ms_per_step': None, 'loss_fake': 15833.16, 'loss_G': 3399.38, 'peak_mem_gb': 69.2,
+            'loss_check': 'ok', 'loss_check_detail': [{'x': 'y' * 500}] * 2,
+            'comm': {'exposed_ms_per_step': {'fake_score': 1.234567, 'G': 7.654321}, 'comm_exposed_ms': 8.9, 'messages_per_step': 8.0, 'bytes_per_step': 6.9e9,
+                     'allreduce_ms_per_step': 40.1, 'allreduce_algbw_GBps': 171.123456, 'allreduce_busbw_GBps': 299.4, 'backend': 'nccl', 'note': 'n' * 300},
+            'teacher_pass': {'what': 'x' * 100, 'ms': 18.3, 'tflops': 700.0, 'mfma_frac': 0.28},
+            'frozen_pair_pass': {'what': 'x' * 200, 'ms': 34.5, 'tflops': 740.0, 'mfma_frac': 0.296, 'vs_two_separate_passes': 1.06},
+            'roofline': dict(fam, family='gemm', why='y' * 100),
+            'cpu_baseline': {'value': 0.0256, 'unit': 'images/s', 'cores': 32, 'kind': 'port', 'sample': 's' * 400, 'detail': 'd' * 400}}
+    for k in ('gemm', 'conv', 'attn', 'attn_bwd', 'wgrad', 'conv_wgrad', 'gn', 'gn_bwd', 'ln', 'ln_bwd'):
+        full['roofline_' + k] = dict(fam)
+    line = bench.compact_line(full)
+    text = json.dumps(line)
+    assert len(text) < 4096, len(text)
+    for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype', 'data', 'config',
+              'roofline', 'cpu_baseline', 'loss_check', 'teacher_pass', 'step_mfma_frac'):
+        assert k in line, k
+    r = line['roofline']
+    assert r['bound'] == 'mfma' and r['peak'] == 2500.0 and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-3 and r['traffic'] is None
+    assert set(line['cpu_baseline']) == {'value', 'unit', 'cores', 'kind', 'sample'} and len(line['cpu_baseline']['sample']) <= 120
+    assert set(line['fracs']) == {'gemm', 'conv', 'attn', 'attn_bwd', 'wgrad', 'conv_wgrad', 'gn', 'gn_bwd', 'ln', 'ln_bwd'}
+    # a single-GPU line without kernel timing is still valid
+    bare = {k: v for k, v in full.items() if not k.startswith('roofline')}
+    bare['comm'] = None
+    assert 'roofline' not in bench.compact_line(bare)
+
+
+def test_forward_mac_count_matches_the_oracle_closed_form():
+    """bench.py prices `step_tflops` with sid_lsg_amd.unet.unet_forward_macs (a walk over the module tree); it equals the oracle's
+    closed form (401.6 GMAC per SD1.5 forward at 64x64 latents) for every architecture and latent size."""
+    from oracle.unet_ref import CONFIGS as RC, unet_forward_macs as ref
+    from sid_lsg_amd.unet import CONFIGS, unet_forward_macs
+    for arch in CONFIGS:
+        for h in (8, 64, 96):
+            assert unet_forward_macs(CONFIGS[arch], h, h) == ref(RC[arch], h, h), (arch, h)
+    assert unet_forward_macs(CONFIGS['sd15'], 64, 64) == 401636720640
