@@ -184,11 +184,18 @@ def load_loss_reference(args, world):
 
 
 def check_losses(ref, it, lf, lg):
+    """bf16 losses of iteration `it` against the stored fp32 references of this workload: the fp32 CPU ORACLE itself where it has
+    been run (iteration 0: `oracle_fp32`, oracle/make_bench_oracle_reference.py), the HIP fp32-accurate mode (pinned to the oracle
+    at iteration 0 by tests/test_gpu_bench_parity.py) for the later iterations."""
     if it >= len(ref['loss_fake']):
         return dict(iteration=it, ok=True, skipped=f'reference holds {len(ref["loss_fake"])} iterations')
-    rf, rg = ref['loss_fake'][it], ref['loss_G'][it]
+    orc = ref.get('oracle_fp32')
+    if orc is not None and it < len(orc['loss_fake']):
+        rf, rg, src = orc['loss_fake'][it], orc['loss_G'][it], 'oracle_fp32'
+    else:
+        rf, rg, src = ref['loss_fake'][it], ref['loss_G'][it], 'hip_fp32'
     ef, eg = abs(lf - rf) / abs(rf), abs(lg - rg) / abs(rg)
-    return dict(iteration=it, loss_fake=lf, loss_fake_ref=rf, rel_fake=ef, loss_G=lg, loss_G_ref=rg, rel_G=eg,
+    return dict(iteration=it, reference=src, loss_fake=lf, loss_fake_ref=rf, rel_fake=ef, loss_G=lg, loss_G_ref=rg, rel_G=eg,
                 bounds=list(LOSS_TOL), ok=bool(ef <= LOSS_TOL[0] and eg <= LOSS_TOL[1]))
 
 
@@ -452,9 +459,9 @@ def main():
         'step_tflops': value * img_tflop, 'step_mfma_frac': value * img_tflop / (PEAK_BF16_TFLOPS * world),
         'graph': bool(args.graph), 'grouped_frozen_pass': bool(step._use_grouped(b)), 'host_enqueue_ms_per_step': t_host, 'loss_fake': float(lf), 'loss_G': float(lg), 'peak_mem_gb': torch.cuda.max_memory_allocated(dev) / 2 ** 30,
     }
-    # parity at the BENCH workload: the losses of iteration 0 and of the first timed step against the stored fp32-mode values
-    # (tests/golden/bench_loss_reference.json, made by tools/make_bench_loss_reference.py with the HIP fp32-accurate mode, itself
-    # pinned to the CPU oracle at batch 1 and 2 by tests/test_gpu_unet.py); bounds = the bf16 bounds of the parity suite
+    # parity at the BENCH workload: the losses of iteration 0 against the fp32 CPU ORACLE run on this workload's own inputs and weights
+    # (tests/golden/bench_loss_reference.json `oracle_fp32`, oracle/make_bench_oracle_reference.py) and of the first timed step against
+    # the stored HIP fp32-mode values (tools/make_bench_loss_reference.py; equal to the oracle at iteration 0 to 4e-8); bf16 bounds
     if loss_ref is None:
         out['loss_check'] = 'no reference stored for this configuration'
     elif not checks:

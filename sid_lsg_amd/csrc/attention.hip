@@ -39,6 +39,8 @@ struct AttnParams {
     float scale2;                  // d^-0.5 * log2(e)
     float scale;                   // d^-0.5
     int xcd;                       // 1: blocks renumbered so that all blocks of one (batch, head) run on ONE XCD (attn_block_coords)
+    int rot;                       // 1: every block starts its walk over the streamed tiles (keys: forward / dQ; queries: dK/dV) at its own
+                                   //    offset and wraps around, so the co-resident blocks of a head do not read the same tile at the same time
 };
 
 // Hardware workgroup L (x fastest) runs on XCD L % 8, so the query / key blocks of one (batch, head) -- neighbours in x -- were spread
@@ -375,8 +377,14 @@ __global__ __launch_bounds__(256, (DP <= 48 && MODE == 0) ? 4 : ((DP <= 48 && MO
     Tile<DP, AT_KT, attn_q_dma<DP, MODE>()> tk, tv;
     tk.init(p.ldk, p.D, Ks[0], Ks[1], -1);
     tv.init(p.ldv, p.D, Vs[0], Vs[1], ones_col);
-    tk.load(rk, p.ldk, 0, Ks[0]);
-    tv.load(rv, p.ldv, 0, Vs[0]);
+    // Rotated walk (p.rot; whole tiles only): logical tile position k0 -> keys [wrap(k0 + kbase), +AT_KT).  Softmax statistics and the
+    // sums over keys do not depend on the order of the tiles; with the XCD-contiguous numbering the ~32 blocks of a head are resident
+    // together and would otherwise request the same K / V tile within the same microsecond, all the way through the kernel.
+    const bool rotate = p.rot && p.Nk % AT_KT == 0 && p.Nk >= 2 * AT_KT;
+    const int kbase = rotate ? (int)(((long long)bx_ * (p.Nk / AT_KT)) / gridDim.x) * AT_KT : 0;
+    auto wrap = [&](int k) { return k >= p.Nk && rotate ? k - p.Nk : k; };
+    tk.load(rk, p.ldk, kbase, Ks[0]);
+    tv.load(rv, p.ldv, kbase, Vs[0]);
     tk.commit(Ks[0], LD);
     tv.commit(Vs[0], LD, ones_col);
     __syncthreads();
@@ -391,7 +399,7 @@ __global__ __launch_bounds__(256, (DP <= 48 && MODE == 0) ? 4 : ((DP <= 48 && MO
         constexpr bool FIRST = decltype(first)::value;
         // next tile -> registers, or by DMA straight into the other buffer (last read before the previous barrier)
 #ifndef SIDLSG_EXP_ATTN_NOSTAGE
-        if (more) { tk.load(rk, p.ldk, k0 + AT_KT, Ks[buf ^ 1]); tv.load(rv, p.ldv, k0 + AT_KT, Vs[buf ^ 1]); }
+        if (more) { const int kn = wrap(k0 + AT_KT + kbase); tk.load(rk, p.ldk, kn, Ks[buf ^ 1]); tv.load(rv, p.ldv, kn, Vs[buf ^ 1]); }
 #endif
         const bf16* Kt = Ks[buf];
         const bf16* Vt = Vs[buf];
@@ -666,13 +674,16 @@ __global__ __launch_bounds__(256) void attn_dkdv_kernel(AttnParams p) {
             if (PS) { lse_r = -lse_r; dl_r = -dl_r; }
         }
     };
-    prefetch(0, 0);
+    // rotated walk over the query tiles (see attn_q_kernel): dK / dV are sums over queries
+    const bool rotate = p.rot && p.Nq % ST == 0 && p.Nq >= 2 * ST;
+    const int qbase = rotate ? (int)(((long long)bx_ * (p.Nq / ST)) / gridDim.x) * ST : 0;
+    prefetch(qbase, 0);
     tq.commit(Qs2[0], LD); tdo.commit(dOs2[0], LD);
     if (threadIdx.x < ST) { lse_s[0][threadIdx.x] = lse_r; dl_s[0][threadIdx.x] = dl_r; }
     __syncthreads();
     auto qtile = [&](const int q0, auto has_next) {       // (run-time `more`: the compile-time split measured slower here)
         const bool more = q0 + ST < p.Nq;
-        if (more) prefetch(q0 + ST, pb_ ^ 1);
+        if (more) { int qn = q0 + ST + qbase; if (qn >= p.Nq && rotate) qn -= p.Nq; prefetch(qn, pb_ ^ 1); }
 #pragma unroll
         for (int sub = 0; sub < SUB; sub++) {
         if (sub && q0 + sub * AK_QT >= p.Nq) break;
@@ -811,10 +822,17 @@ static int attn_xcd_on(int mode, const AttnParams& p) {
     if (!((mask >> mode) & 1)) return 0;
     return mode == 0 || (mask & 8) || (p.Nq <= 1024 && p.Nk <= 1024);
 }
+// SIDLSG_ATTN_ROT: bit mask of the passes whose blocks start their tile walk at per-block offsets (1 forward, 2 dQ, 4 dK/dV); only
+// together with the XCD-contiguous numbering (without it an XCD holds 4 blocks of each of 16 heads: nothing walks in lockstep)
+static int attn_rot_on(int mode, const AttnParams& p) {
+    static const int mask = getenv("SIDLSG_ATTN_ROT") ? atoi(getenv("SIDLSG_ATTN_ROT")) : 0;
+    return p.xcd && ((mask >> mode) & 1);
+}
 template <bool PS>
 static int dispatch_attn(const AttnParams& p_in, int mode, hipStream_t s) {
     AttnParams p = p_in;
     p.xcd = attn_xcd_on(mode, p);
+    p.rot = attn_rot_on(mode, p);
     if (p.D % 8 || p.D <= 0 || p.D > 160) return SIDLSG_EINVAL;
     const int dp = (p.D + 15) / 16 * 16;
     // 32 queries per wave (forward / dQ) and 16 keys per wave (dK/dV) keep 2-3 blocks per CU resident; 64 queries per

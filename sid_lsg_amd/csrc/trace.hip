@@ -11,14 +11,20 @@
 // sampled gets an event pair from the pool.  Sampling is per CALL (all kernels of a sampled call are timed, e.g. a split-K GEMM
 // and its finish kernel), every `stride`-th call of a family.  Disabled (the default): one thread-local pointer test per launch.
 #include "common.h"
+#include <atomic>
 #include <mutex>
 #include <vector>
 
 namespace {
-struct Rec { int family; double work, bytes; int first, count; };
+// A record keeps the pool indices of ITS event pairs: two host threads with sampled scopes open at once (the forward on the main
+// thread, autograd's worker, the input-prefetch thread) interleave their draws from the pool, so "first + 2 k" would hand one
+// call's kernels to another family.  8 kernels per call is the deepest entry point (split conv weight gradient + reductions).
+constexpr int REC_MAX = 8;
+struct Rec { int family; double work, bytes; int count; int ev[REC_MAX]; };
 struct State {
     std::mutex mu;
-    bool on = false;
+    std::atomic<bool> on{false};       // read outside the mutex on every launch
+    std::atomic<unsigned> gen{0};      // bumped by every (re)start: invalidates the thread-local record indices of the old run
     std::vector<hipEvent_t> pool;      // 2 events per kernel
     size_t used = 0;
     std::vector<Rec> recs;
@@ -27,18 +33,23 @@ struct State {
     State() { for (int& s : stride) s = 1; }
 };
 State& st() { static State s; return s; }
-thread_local int t_cur = -1;          // index of the open sampled record of this thread
+thread_local int t_cur = -1;          // index of the open sampled record of this thread ...
+thread_local unsigned t_gen = 0;      // ... valid for this generation of State::recs only
 }  // namespace
 
 bool sidlsg_trace_scope_begin(int family, double work, double bytes) {
     State& s = st();
-    if (!s.on || family < 0 || family >= SIDLSG_TRACE_FAMILIES || t_cur >= 0) return false;
+    if (!s.on.load(std::memory_order_relaxed) || family < 0 || family >= SIDLSG_TRACE_FAMILIES) return false;
     std::lock_guard<std::mutex> lk(s.mu);
+    if (t_cur >= 0 && t_gen == s.gen.load()) return false;      // nested scope of this thread: the outer one owns the kernels
+    t_cur = -1;
+    if (!s.on.load()) return false;
     const long long c = s.calls[family]++;
     if (c % s.stride[family]) return false;
     if (s.used + 16 > s.pool.size()) return false;      // pool exhausted: stop sampling, keep counting
-    s.recs.push_back({family, work, bytes, (int)s.used, 0});
+    s.recs.push_back({family, work, bytes, 0, {}});
     t_cur = (int)s.recs.size() - 1;
+    t_gen = s.gen.load();
     return true;
 }
 void sidlsg_trace_scope_end() { t_cur = -1; }
@@ -46,11 +57,13 @@ bool sidlsg_trace_events(hipEvent_t* e0, hipEvent_t* e1) {
     if (t_cur < 0) return false;
     State& s = st();
     std::lock_guard<std::mutex> lk(s.mu);
-    if (s.used + 2 > s.pool.size()) return false;
+    if (t_gen != s.gen.load() || (size_t)t_cur >= s.recs.size()) { t_cur = -1; return false; }      // tracing was restarted under this scope
+    Rec& r = s.recs[t_cur];
+    if (s.used + 2 > s.pool.size() || r.count >= REC_MAX) return false;
     *e0 = s.pool[s.used];
     *e1 = s.pool[s.used + 1];
+    r.ev[r.count++] = (int)s.used;
     s.used += 2;
-    s.recs[t_cur].count++;
     return true;
 }
 
@@ -61,6 +74,7 @@ int sidlsg_trace_enable(int max_kernels) {
     State& s = st();
     std::lock_guard<std::mutex> lk(s.mu);
     s.on = false;
+    s.gen++;
     s.used = 0;
     s.recs.clear();
     for (long long& c : s.calls) c = 0;
@@ -112,7 +126,7 @@ int sidlsg_trace_read(int family, double* out) {
         double t = 0;
         for (int k = 0; k < r.count; k++) {
             float f = 0.f;
-            if (hipEventElapsedTime(&f, s.pool[r.first + 2 * k], s.pool[r.first + 2 * k + 1]) != hipSuccess) { ok = false; break; }
+            if (hipEventElapsedTime(&f, s.pool[r.ev[k]], s.pool[r.ev[k] + 1]) != hipSuccess) { ok = false; break; }
             t += f;
         }
         if (!ok) continue;

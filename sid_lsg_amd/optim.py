@@ -85,12 +85,16 @@ class FusedAdamEMA:
             for lo, hi in sorted(ranges):
                 if lo > pos:
                     parts.append((pos, lo, None))
-                parts.append((lo, hi, [w for o, w in ws if lo <= o < hi]))
+                parts.append((lo, hi, [(o, w) for o, w in ws if lo <= o < hi]))
                 pos = hi
             if pos < self.flat.numel():
                 parts.append((pos, self.flat.numel(), None))
             self._parts = parts
         return self
+
+    def set_owner(self, net):
+        """The network whose flat buffers these are (load_state_dict / state_dict need its name -> offset table); attach() sets it too."""
+        self._owner = net
 
     _owner = None
     _covered = 0
@@ -138,20 +142,26 @@ class FusedAdamEMA:
         self._launch_parts(lo, hi, use_ema, zero_grad)
 
     def _launch_parts(self, lo, hi, use_ema, zero_grad):
-        if self._parts is None or not zero_grad:
+        if self._parts is None:
             return self._kernel(lo, hi, use_ema, zero_grad)
         for a, b, ws in self._parts:
             s, e = max(a, lo), min(b, hi)
             if e <= s:
                 continue
-            if ws is None or s != a or e != b:        # small parameters (or a weight range cut by the caller): zeroed as ever
-                self._kernel(s, e, use_ema, True)
+            if ws is None:                            # small parameters: zeroed as ever
+                self._kernel(s, e, use_ema, zero_grad)
                 continue
-            for w in ws:
-                if getattr(w, '_grad_assign', False) and w.grad is not None:
-                    w.grad.zero_()                    # no weight gradient since the last step took the mark: this step's gradient is zero
+            # A weight whose mark is still set got NO gradient since the last step took... nothing: its view still holds the
+            # gradient the previous step consumed (the range is never zeroed), so this step's gradient of it is zero -- whatever
+            # the caller does with the range (whole or cut, zeroing or not), the stale values must not be applied again.
+            for o, w in ws:
+                if o < e and o + w.numel() > s and getattr(w, '_grad_assign', False) and w.grad is not None:
+                    w.grad.zero_()
+            if not zero_grad or s != a or e != b:     # a range cut by the caller, or gradients the caller wants to keep: plain launch;
+                self._kernel(s, e, use_ema, zero_grad)    # marks stay as they are (set: the next gradient assigns; clear: it accumulates)
+                continue
             self._kernel(s, e, use_ema, False)
-            for w in ws:
+            for _, w in ws:
                 w._grad_assign = True
 
     def _kernel(self, lo, hi, use_ema, zero_grad):
@@ -177,20 +187,43 @@ class FusedAdamEMA:
             self.begin_step(ema_beta)
         self.launch(use_ema=ema_beta is not None and self.ema is not None, zero_grad=zero_grad)
 
+    def _layout_table(self):
+        """name -> (offset, numel) of the owner's flat buffers (None without an owner network)."""
+        fn = getattr(self._owner, 'flat_layout_table', None)
+        return fn() if fn is not None else None
+
     def state_dict(self):
         return dict(step=self.step_count, exp_avg_sq=self.exp_avg_sq, exp_avg=self.exp_avg, lr=self.lr, betas=self.betas,
-                    eps=self.eps, weight_decay=self.weight_decay, flat_layout=FLAT_LAYOUT)
+                    eps=self.eps, weight_decay=self.weight_decay, flat_layout=FLAT_LAYOUT, layout=self._layout_table())
 
     def load_state_dict(self, sd):
-        # the moments are stored in the order of the network's flat buffer: a file written under another parameter order would load
-        # without an error and pair every parameter with some other parameter's second moment
-        if sd.get('flat_layout', 1) != FLAT_LAYOUT:
-            raise ValueError(f"optimizer state of flat-buffer layout {sd.get('flat_layout', 1)}, this build uses layout {FLAT_LAYOUT} "
-                             '(weights first inside each gradient segment): restart the optimizer state or convert the file')
+        """The moments are stored in the order of the network's flat buffer.  Files carry the name -> (offset, numel) table of the
+        buffer they were written from (`layout`; files of rounds <= 4 only a version number, whose table the network can rebuild:
+        HipUNet2DCondition.flat_layout_table(version)), and a state written under another parameter order is PERMUTED by name --
+        never loaded positionally, which would pair every parameter with some other parameter's second moment."""
+        mine = self._layout_table()
+        theirs = sd.get('layout')
+        if theirs is None and mine is not None and sd.get('flat_layout', 1) != FLAT_LAYOUT:
+            theirs = self._owner.flat_layout_table(version=sd.get('flat_layout', 1))
+        if theirs is None or mine is None or theirs == mine:
+            if theirs is None and sd.get('flat_layout', 1) != FLAT_LAYOUT:
+                raise ValueError(f"optimizer state of flat-buffer layout {sd.get('flat_layout', 1)} without a name table, this build uses "
+                                 f'layout {FLAT_LAYOUT}, and the optimizer has no owner network to rebuild the table from: attach(owner=net) first')
+            if sd['exp_avg_sq'].numel() != self.exp_avg_sq.numel():
+                raise ValueError('optimizer state of another network (size of the flat buffer differs)')
+            self.exp_avg_sq.copy_(sd['exp_avg_sq'])
+            if self.exp_avg is not None and sd.get('exp_avg') is not None:
+                self.exp_avg.copy_(sd['exp_avg'])
+        else:
+            if set(theirs) != set(mine) or any(theirs[k][1] != mine[k][1] for k in mine):
+                raise ValueError('optimizer state of another architecture (parameter names / sizes differ)')
+            for dst, src in ((self.exp_avg_sq, sd['exp_avg_sq']), (self.exp_avg, sd.get('exp_avg'))):
+                if dst is None or src is None:
+                    continue
+                src = src.to(dst.device)
+                for k, (o, n) in mine.items():
+                    dst[o:o + n].copy_(src[theirs[k][0]:theirs[k][0] + n])
         self.step_count = int(sd['step'])
-        self.exp_avg_sq.copy_(sd['exp_avg_sq'])
-        if self.exp_avg is not None and sd.get('exp_avg') is not None:
-            self.exp_avg.copy_(sd['exp_avg'])
 
 
 class FusedAdamWEMA(FusedAdamEMA):

@@ -177,6 +177,9 @@ def training_loop(
         fake_score.load_state_dict(_sd(data['fake_score'])); G.load_state_dict(_sd(data['G']))
         if ema_halflife_kimg > 0:
             G_ema.load_state_dict(_sd(data['G_ema']))
+        for opt, net in ((opt_f, fake_score), (opt_g, G)):      # the owner's name -> offset table: states of another flat layout are permuted
+            if hasattr(opt, 'set_owner'):
+                opt.set_owner(net)
         opt_f.load_state_dict(data['fake_score_optimizer_state']); opt_g.load_state_dict(data['g_optimizer_state'])
         for net in (fake_score, G, G_ema):
             net.refresh_compute_weights()
@@ -355,6 +358,9 @@ def evaluate_network(run_dir, dataset_kwargs, network_kwargs, device, metrics, i
     if dataset_kwargs:
         msrc = dict(dataset_kwargs=dict(dataset_kwargs))
     else:
+        if not dataset_prompt_text_kwargs:
+            raise ValueError('evaluate_network: neither dataset_kwargs (--data: the evaluation caption set) nor dataset_prompt_text_kwargs '
+                             '(--data_prompt_text) was given -- there are no prompts to evaluate on')
         dist.print0('WARNING: no dataset_kwargs (--data): evaluating on the training prompts; not comparable with the reference\'s COCO numbers')
         msrc = dict(dataset_kwargs=dict(dataset_prompt_text_kwargs))
     out = {}

@@ -119,6 +119,12 @@ def build_config(o):
     if o.metrics is not None and o.data:
         # the evaluation caption set (reference: training.mscoco_dataset.ImageDataset on --data, sid_train.py:232-235)
         c.dataset_kwargs = EasyDict(class_name='sid_lsg_amd.data.CaptionDataset', path=o.data, resolution=o.resolution, random_flip=o.xflip)
+        # fail at start-up, not at the first metrics tick hours into the run: the set is only constructed there
+        try:
+            from sid_lsg_amd.data import CaptionDataset
+            CaptionDataset(o.data, resolution=o.resolution)
+        except OSError as e:
+            raise click.ClickException(f'--metrics with --data {o.data!r}: {e} (an image + .txt caption directory, or a text file with one caption per line)')
     c.data_loader_kwargs = EasyDict(pin_memory=True, num_workers=o.workers, prefetch_factor=2)
     c.dataset_prompt_text_kwargs = EasyDict(class_name='sid_lsg_amd.data.PromptDataset', path=o.data_prompt_text,
                                             resolution=o.resolution, random_flip=o.xflip, prompt_only=True)

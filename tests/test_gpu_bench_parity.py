@@ -1,10 +1,13 @@
 """Parity AT THE BENCH WORKLOAD (BASELINE.json configs[1]: full-size SD1.5, kappa = 1.5, batch_gpu 8, 64x64x4 latents).
 
-The full-size oracle tests of tests/test_gpu_unet.py run batch 1 / 2 (the fp32 CPU oracle needs ~40 s per sample); the shapes
-bench.py times -- 65 536-token GEMMs, the A-stationary FF-in kernel, the weight-gradient split model at M = 65 536, attention
-grids at B x H = 128 -- only occur at batch_gpu 8.  Chain of evidence: HIP fp32 mode == CPU oracle at batch 1 and 2
-(test_gpu_unet.py, ~1e-6), HIP bf16 == HIP fp32 at batch 8 (here, bf16 bounds), and bench.py itself checks its first timed step
-against the same stored values (`loss_check`)."""
+The shapes bench.py times -- 65 536-token GEMMs, the A-stationary FF-in kernel, the weight-gradient split model at M = 65 536,
+attention grids at B x H = 128 -- only occur at batch_gpu 8.  Round 5: the workload is pinned to the fp32 CPU ORACLE directly.
+bench.py's weights come from a CPU generator (sid_lsg_amd.unet.random_state_dict), its iteration-0 inputs are a committed fixture
+(tests/golden/bench_it0_inputs.npz, tools/dump_bench_it0_inputs.py) and oracle/make_bench_oracle_reference.py ran
+oracle/sid_ref.py on exactly those in the build container (8 accumulation rounds of one sample = the reference's own gradient
+accumulation): `oracle_fp32` in tests/golden/bench_loss_reference.json.  Here: the live inputs equal the fixture bit for bit, the
+HIP fp32 mode meets north_star's 1e-3 against the oracle at batch_gpu 8 (observed 4e-8 / 2e-8), bf16 stays inside its bounds against
+the oracle (iteration 0) and the fp32 mode (later iterations), and bench.py checks its own run against the same file (`loss_check`)."""
 import json
 import os
 import sys
@@ -52,17 +55,41 @@ def test_bench_workload_bf16_matches_stored_fp32_losses(dev):
     torch.cuda.empty_cache()
 
 
-def test_stored_reference_is_the_fp32_mode_of_this_tree(dev):
-    """The stored values are not stale: iteration 0 and 1 re-derived live in the HIP fp32-accurate mode (batch_gpu 8) agree
-    with the file to 1e-5 (fp32 atomics order)."""
+def test_fp32_mode_matches_the_cpu_oracle_at_the_bench_workload(dev):
+    """The bench workload against the fp32 CPU oracle DIRECTLY: (a) the inputs bench.py draws for iteration 0
+    are the committed fixture the oracle ran on, bit for bit, and the weights are the CPU-seeded ones (checksum); (b) the HIP fp32
+    mode at batch_gpu 8 is within north_star's 1e-3 of the oracle's losses (observed ~1e-7); (c) the stored fp32-mode values are
+    not stale (iterations 0 and 1 re-derived live, 1e-5: fp32 atomics order)."""
+    import numpy as np
     import bench
     ref = _reference()
+    fx = np.load(os.path.join(ROOT, 'tests', 'golden', 'bench_it0_inputs.npz'))
     S = bench.setup_step('sd15', 8, 512, 1.5, dev, compute_dtype=torch.float32)
+    p = S.phi.flat_params.double()
+    assert abs(float(p.sum()) - float(fx['weights_sum'])) < 1e-6 * float(fx['weights_abs_sum'])
+    assert abs(float(p.abs().sum()) - float(fx['weights_abs_sum'])) < 1e-9 * float(fx['weights_abs_sum'])
+    del p
+    S16 = bench.setup_step('sd15', 8, 512, 1.5, dev)          # the text states of the bench are bf16: compare in the bench's own mode
+    inputs, _ = S16.prepare(0)
+    torch.cuda.synchronize()
+    for ph in ('A', 'B'):
+        (r,) = inputs[ph]
+        assert np.array_equal(r['z'].cpu().numpy(), fx[f'{ph}_z']) and np.array_equal(r['noise'].cpu().numpy(), fx[f'{ph}_noise'])
+        assert np.array_equal(r['t'].cpu().numpy(), fx[f'{ph}_t'])
+        assert np.array_equal(r['cond'].contiguous().view(torch.int16).cpu().numpy(), fx[f'{ph}_cond_bf16'])
+        assert np.array_equal(r['uncond'][:1].contiguous().view(torch.int16).cpu().numpy(), fx[f'{ph}_uncond_bf16'])
+    del S16, inputs
+    torch.cuda.empty_cache()
+    orc = ref['oracle_fp32']
     for it in range(2):
         lf, lg = S.one_iteration(it)
         ef = abs(float(lf) - ref['loss_fake'][it]) / abs(ref['loss_fake'][it])
         eg = abs(float(lg) - ref['loss_G'][it]) / abs(ref['loss_G'][it])
         print(f'iteration {it} fp32 live: loss_fake {float(lf):.6f} loss_G {float(lg):.6f}  (stored: rel {ef:.1e} / {eg:.1e})')
         assert ef < 1e-5 and eg < 1e-4
+        if it < len(orc['loss_fake']):
+            of, og = abs(float(lf) - orc['loss_fake'][it]) / abs(orc['loss_fake'][it]), abs(float(lg) - orc['loss_G'][it]) / abs(orc['loss_G'][it])
+            print(f'iteration {it} fp32 live vs the CPU ORACLE: loss_fake rel {of:.1e}  loss_G rel {og:.1e}  (north_star: 1e-3)')
+            assert of < 1e-3 and og < 1e-3
     del S
     torch.cuda.empty_cache()

@@ -163,6 +163,18 @@ def test_sid_iteration_full_size_sd21_base(dev):
         torch.set_num_threads(min(8, os.cpu_count() or 8))
 
 
+def test_sid_iteration_full_size_config4_768px(dev):
+    """BASELINE.json configs[3] (`run_sid.sh:110`): SD2.1-base, kappa = 2, 768^2 images = 96x96x4 latents -- one COMPLETE iteration
+    (CFG batches, both losses, x0 prediction, both optimizer steps, EMA; self-attention over 9216 tokens in every pass, forward and
+    backward) against the fp32 CPU oracle in both compute modes; until round 5 this resolution was only checked for one network's
+    forward / backward (test_sd21_base_768px_forward_backward) and the step itself only ran inside bench.py."""
+    try:
+        _iteration_parity(dev, 'sd21-base', lat=96, b=1, rounds=1, lr=1e-6, kappa=2.0, alpha=1.0, iters=1,
+                          ema_names=('conv_in.weight', 'conv_out.bias'), modes=(BF16, F32))
+    finally:
+        torch.set_num_threads(min(8, os.cpu_count() or 8))
+
+
 def test_sd21_base_768px_forward_backward(dev):
     """configs[3] resolution: SD2.1-base at 96x96 latents (768^2 images): self-attention over N = 9216 / 2304 / 576 / 144
     tokens at d = 64.  Forward and input / parameter gradients of the full-size network against the fp32 CPU oracle, bf16
@@ -1118,3 +1130,77 @@ def test_graphed_iteration_equals_eager(dev):
     """SiDStep.iteration_graphed: one HIP graph per iteration (three streams, autograd backward, both fused optimizer
     kernels, EMA) against the eager iteration: same losses and weights over 4 iterations with changing inputs and EMA beta."""
     _assert_graph_equals_eager(*_graph_vs_eager(dev))
+
+
+def test_stale_unzeroed_gradients_are_never_applied_again(dev):
+    """ADVICE r04 (optim.py `_launch_parts`): after a step the weight ranges keep the gradients that step consumed (un-zeroed,
+    marked for overwriting).  A further step WITHOUT a backward in between must see zero gradients there however it is launched:
+    step(zero_grad=False), and a launch_range() that cuts a weight range in two."""
+    from sid_lsg_amd.optim import FusedAdamEMA
+    from sid_lsg_amd.unet import CONFIGS, HipUNet2DCondition
+    cfg = CONFIGS['tiny40']
+    net = HipUNet2DCondition(cfg).materialize(dev, seed=5)
+    net.requires_grad_(True)
+    opt = FusedAdamEMA(net.parameters(), lr=1e-3, betas=(0.0, 0.999), eps=1e-8)
+    opt.attach(w16=net.flat_w16, owner=net)
+    assert opt._parts is not None
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(2, 4, 16, 16, generator=g).to(dev)
+    ctx = torch.randn(2, cfg.text_len, cfg.cross_attention_dim, generator=g).to(dev).to(BF16)
+    y = net(x, torch.tensor([625, 37], device=dev), encoder_hidden_states=ctx).sample
+    y.float().square().sum().backward()
+    opt.step()                                            # consumes the gradients; weight ranges stay un-zeroed and marked
+    torch.cuda.synchronize()
+    ranges, ws = net.assign_plan()
+    assert all(getattr(w, '_grad_assign', False) for _, w in ws) and float(net.flat_grads.abs().max()) > 0.0
+    # (1) zero_grad=False, no backward since the last step: nothing may move
+    before = net.flat_params.clone()
+    opt.step(zero_grad=False)
+    torch.cuda.synchronize()
+    assert torch.equal(before, net.flat_params), 'step(zero_grad=False) applied the previous step\'s gradients again'
+    # (2) fresh gradients, consumed; then a range launch that cuts the first weight range: nothing may move either
+    y = net(x, torch.tensor([625, 37], device=dev), encoder_hidden_states=ctx).sample
+    y.float().square().sum().backward()
+    opt.step()
+    torch.cuda.synchronize()
+    before = net.flat_params.clone()
+    lo, hi = sorted(ranges)[0]
+    mid = (lo + (hi - lo) // 2) // 64 * 64
+    opt.begin_step()
+    opt.launch_range(lo, mid)
+    opt.launch_range(mid, hi)
+    torch.cuda.synchronize()
+    assert torch.equal(before[lo:hi], net.flat_params[lo:hi]), 'a cut weight range applied stale gradients'
+
+
+def test_optimizer_state_of_the_old_flat_layout_is_permuted_by_name(dev):
+    """ADVICE r04 (optim.py load_state_dict): a training-state file written under the parameter order of rounds <= 3 (flat_layout 1,
+    no name table) resumes: the second moments are permuted by parameter name into today's order; files of this build carry the
+    name table itself and load directly."""
+    from sid_lsg_amd.optim import FusedAdamEMA
+    from sid_lsg_amd.unet import CONFIGS, HipUNet2DCondition
+    net = HipUNet2DCondition(CONFIGS['tiny']).materialize(dev, seed=1)
+    net.requires_grad_(True)
+    opt = FusedAdamEMA(net.parameters(), lr=1e-3).attach(w16=net.flat_w16, owner=net)
+    new, old = net.flat_layout_table(), net.flat_layout_table(version=1)
+    assert set(new) == set(old) and new != old
+    # a recognisable second moment per parameter, laid out in the OLD order
+    size_old = max(o + n for o, n in old.values())
+    v_old = torch.zeros(size_old)
+    for i, (name, (o, n)) in enumerate(sorted(old.items())):
+        v_old[o:o + n] = float(i + 1) + torch.arange(n) * 1e-6
+    opt.load_state_dict(dict(step=7, exp_avg_sq=v_old, exp_avg=None, flat_layout=1))
+    assert opt.step_count == 7
+    for i, (name, (o, n)) in enumerate(sorted(new.items())):
+        got = opt.exp_avg_sq[o:o + n].cpu()
+        assert torch.equal(got, float(i + 1) + torch.arange(n) * 1e-6), name
+    # round trip of this build's own file
+    sd = opt.state_dict()
+    assert sd['layout'] == new
+    opt2 = FusedAdamEMA(net.parameters(), lr=1e-3).attach(w16=net.flat_w16, owner=net)
+    opt2.load_state_dict(sd)
+    assert torch.equal(opt2.exp_avg_sq, opt.exp_avg_sq)
+    # without an owner and without a table the old file is refused, not loaded positionally
+    opt3 = FusedAdamEMA(net.parameters(), lr=1e-3)
+    with pytest.raises(ValueError):
+        opt3.load_state_dict(dict(step=1, exp_avg_sq=v_old, exp_avg=None, flat_layout=1))

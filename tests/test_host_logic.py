@@ -269,6 +269,12 @@ def test_cli_dry_run_builds_reference_config(tmp_path):
     # errors the reference raises as ClickException
     bad = CliRunner().invoke(sid_train.main, ['--outdir', 'x', '--data_prompt_text', str(tmp_path), '--resume', 'nope.pt', '--seed', '0', '-n'])
     assert bad.exit_code != 0 and 'training-state' in bad.output
+    # --metrics with an empty --data directory is refused at start-up (the caption set is only constructed at the first metrics tick)
+    det, stat, empty = tmp_path / 'det.pt', tmp_path / 'stat.npz', tmp_path / 'no_captions'
+    det.write_bytes(b'x'); stat.write_bytes(b'x'); empty.mkdir()
+    bad = CliRunner().invoke(sid_train.main, ['--outdir', 'x', '--data_prompt_text', str(tmp_path), '--sd_model', 'random:tiny', '--metrics', 'fid30k_full',
+                                              '--metric_pt_path', str(det), '--data_stat', str(stat), '--data', str(empty), '-n'])
+    assert bad.exit_code != 0 and 'no captions' in bad.output, bad.output
 
 
 def test_generate_cli_helpers():

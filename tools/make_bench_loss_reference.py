@@ -44,9 +44,9 @@ def main():
     if os.path.isfile(args.out):
         with open(args.out) as f:
             data = json.load(f)
-    data[bench.loss_reference_key(args.arch, args.batch_gpu, args.resolution, args.kappa)] = dict(
-        made_by='tools/make_bench_loss_reference.py: bench.setup_step(compute_dtype=float32), HIP fp32-accurate mode on one MI355X',
-        loss_fake=lf, loss_G=lg)
+    ent = data.setdefault(bench.loss_reference_key(args.arch, args.batch_gpu, args.resolution, args.kappa), {})
+    ent.update(made_by='tools/make_bench_loss_reference.py: bench.setup_step(compute_dtype=float32), HIP fp32-accurate mode on one MI355X',
+               loss_fake=lf, loss_G=lg)          # (`oracle_fp32`, written by oracle/make_bench_oracle_reference.py, is kept)
     with open(args.out, 'w') as f:
         json.dump(data, f, indent=1)
     print('wrote', args.out)
