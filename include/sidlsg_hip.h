@@ -219,6 +219,9 @@ int sidlsg_add_bf16(const void* a, const void* b, void* o, long long n, void* st
 int sidlsg_colsum_nchunks(int B, int rows_per_batch); /* host: grid.x of the reduction */
 int sidlsg_colsum(const void* g, int ldg, float* per_batch, float* total, float* ws, int B, int rows_per_batch, int N,
                   void* stream); /* bias / time-embedding gradients: per_batch[B][N] += (zero it first), total[N] +=; ws unused */
+/* the same with a row stride for per_batch (elements, >= N): the 22 ResBlocks of a pass accumulate their time-embedding column
+ * gradients straight into their column slices of ONE [B][sum Cout] buffer (one fill per pass instead of 22, no concat kernel) */
+int sidlsg_colsum_strided(const void* g, int ldg, float* per_batch, int ld_pb, float* total, int B, int rows_per_batch, int N, void* stream);
 int sidlsg_cast_f32_bf16(const float* x, void* y, long long n, void* stream);
 int sidlsg_cast_bf16_f32(const void* x, float* y, long long n, void* stream);
 int sidlsg_transpose_w(const float* src, void* dst, int N, int K, int T, void* stream); /* [N][T][K] -> [K][T rev][N] bf16 */
@@ -325,6 +328,7 @@ int sidlsg_zero_insert2_f32(const void* g, void* out, int B, int Ho, int Wo, int
 int sidlsg_add_f32(const void* a, const void* b, void* o, long long n, void* stream);
 int sidlsg_colsum_f32(const void* g, int ldg, float* per_batch, float* total, float* ws, int B, int rows_per_batch, int N,
                       void* stream);
+int sidlsg_colsum_strided_f32(const void* g, int ldg, float* per_batch, int ld_pb, float* total, int B, int rows_per_batch, int N, void* stream);
 int sidlsg_transpose_w_f32(const float* src, void* dst, int N, int K, int T, void* stream);
 int sidlsg_transpose_w_batched_f32(const void* jobs, int njobs, int nblocks, void* stream);
 

@@ -223,7 +223,7 @@ __global__ void add_kernel(const T* __restrict__ a, const T* __restrict__ b, T* 
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ g, float* __restrict__ per_batch,
                                                      float* __restrict__ total, int rows_per_batch, int N, int ldg,
-                                                     int rows_per_chunk) {
+                                                     int rows_per_chunk, int ld_pb) {
     __shared__ float sm[256 * 8];
     const int N8 = N >> 3;
     const int cpp = N8 < 256 ? N8 : 256;
@@ -251,7 +251,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ g, fl
             if (col >= N) continue;
             float t = 0.f;
             for (int r = 0; r < rows; r++) t += sm[r * cpp * 8 + i];
-            if (per_batch) unsafeAtomicAdd(per_batch + (size_t)b * N + col, t);
+            if (per_batch) unsafeAtomicAdd(per_batch + (size_t)b * ld_pb + col, t);
             if (total) unsafeAtomicAdd(total + col, t);
         }
     }
@@ -532,12 +532,12 @@ static int colsum_nchunks(int B, int rows_per_batch) {
     int nch = want < maxch ? want : maxch; if (nch < 1) nch = 1; if (nch > 128) nch = 128; return nch;
 }
 template <typename T>
-static int colsum_t(const void* g, int ldg, float* per_batch, float* total, int B, int rows_per_batch, int N, void* stream) {
-    if (N % 8 || N <= 0) return SIDLSG_EINVAL;
+static int colsum_t(const void* g, int ldg, float* per_batch, float* total, int B, int rows_per_batch, int N, void* stream, int ld_pb = 0) {
+    if (N % 8 || N <= 0 || (ld_pb && ld_pb < N)) return SIDLSG_EINVAL;
     const int nch = colsum_nchunks(B, rows_per_batch);
     const int rpc = (rows_per_batch + nch - 1) / nch;
     hipLaunchKernelGGL(colsum_kernel<T>, dim3(nch, B), dim3(256), 0, (hipStream_t)stream, (const T*)g, per_batch, total,
-                       rows_per_batch, N, ldg, rpc);
+                       rows_per_batch, N, ldg, rpc, ld_pb ? ld_pb : N);
     return sidlsg_last_error();
 }
 template <typename D>
@@ -632,6 +632,12 @@ int sidlsg_colsum(const void* g, int ldg, float* per_batch, float* total, float*
 int sidlsg_colsum_f32(const void* g, int ldg, float* per_batch, float* total, float* ws, int B, int rows_per_batch, int N, void* stream) {
     (void)ws;
     return colsum_t<float>(g, ldg, per_batch, total, B, rows_per_batch, N, stream);
+}
+int sidlsg_colsum_strided(const void* g, int ldg, float* per_batch, int ld_pb, float* total, int B, int rows_per_batch, int N, void* stream) {
+    return colsum_t<bf16>(g, ldg, per_batch, total, B, rows_per_batch, N, stream, ld_pb);
+}
+int sidlsg_colsum_strided_f32(const void* g, int ldg, float* per_batch, int ld_pb, float* total, int B, int rows_per_batch, int N, void* stream) {
+    return colsum_t<float>(g, ldg, per_batch, total, B, rows_per_batch, N, stream, ld_pb);
 }
 int sidlsg_cast_f32_bf16(const float* x, void* y, long long n, void* stream) {
     hipLaunchKernelGGL(cast_f32_bf16_kernel, GRID1D((n + 7) / 8, 256), dim3(256), 0, (hipStream_t)stream, x, (bf16*)y, (size_t)n);

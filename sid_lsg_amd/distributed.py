@@ -144,6 +144,11 @@ class FlatGradReducer:
             for o in range(lo, hi, max_elems):
                 self._all_reduce(flat_grad[o:min(hi, o + max_elems)])
 
+    def start_segment(self, flat_grad, ranges):
+        """start_range for every (lo, hi) of one segment of HipUNet2DCondition.grad_segments()."""
+        for lo, hi in ranges:
+            self.start_range(flat_grad, lo, hi)
+
     def start(self, flat_grad):
         if get_world_size() < self.min_world:
             return

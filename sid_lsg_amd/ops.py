@@ -358,10 +358,19 @@ def conv3x3(x, w16, bias=None, res=None, rowvec=None, stride=1, ups=0, out_f32=F
     return out
 
 
-def colsum(g2d, rows_per_batch, per_batch=False, total=None):
-    """g2d: [B*rows_per_batch, N].  total (fp32 [N]) is accumulated in place; returns per-batch sums if asked."""
+def colsum(g2d, rows_per_batch, per_batch=False, total=None, slot=None):
+    """g2d: [B*rows_per_batch, N].  total (fp32 [N]) is accumulated in place; returns per-batch sums if asked.
+    slot: the (holder, column offset, width) of a split_columns() part -- the per-batch sums are then accumulated straight into the
+    part's columns of the holder's shared [B, sum C] gradient buffer (zeroed once per backward pass) and a view of it is returned."""
     R, N = g2d.shape
     B = R // rows_per_batch
+    if per_batch and slot is not None and slot[2] == N:
+        holder, off, _ = slot
+        buf = holder.buffer(B, g2d.device)
+        if buf is not None:
+            pb = buf[:, off:off + N]
+            _fn('colsum_strided', g2d.dtype)(_p(g2d), g2d.stride(0), pb.data_ptr(), buf.stride(0), _p(total), B, rows_per_batch, N, _s())
+            return pb
     pb = torch.zeros((B, N), device=g2d.device, dtype=F32) if per_batch else None
     _fn('colsum', g2d.dtype)(_p(g2d), g2d.stride(0), _p(pb), _p(total), None, B, rows_per_batch, N, _s())
     return pb
@@ -456,6 +465,7 @@ class _Conv3x3(torch.autograd.Function):
                     out_f32=out_f32)
         ctx.save_for_backward(x, weight, bias, w16t)
         ctx.cfg = (stride, ups, res is not None, rowvec is not None)
+        ctx.rv_slot = getattr(rowvec, '_col_slot', None)
         return y
 
     @staticmethod
@@ -503,7 +513,7 @@ class _Conv3x3(torch.autograd.Function):
         if need_b and not fused_b:
             btot = bias.grad if co_w == Cout else torch.zeros(Cout, device=dy.device, dtype=F32)
         if need_rv:
-            drv = colsum(dy2, Ho * Wo, per_batch=True, total=btot)
+            drv = colsum(dy2, Ho * Wo, per_batch=True, total=btot, slot=ctx.rv_slot)
         elif need_b and not fused_b:
             colsum(dy2, dy2.shape[0], total=btot)
         if need_b and not fused_b and co_w != Cout:
@@ -521,6 +531,7 @@ class _Conv3x3G2(torch.autograd.Function):
         y = conv3x3(x, w16, bias=bias, res=res, rowvec=rowvec, stride=stride, ups=ups, out_f32=out_f32)
         ctx.w16t = w16t
         ctx.cfg = (stride, ups, res is not None, rowvec is not None, x.shape)
+        ctx.rv_slot = getattr(rowvec, '_col_slot', None)
         return y
 
     @staticmethod
@@ -541,7 +552,7 @@ class _Conv3x3G2(torch.autograd.Function):
                 full = dx
                 dx = torch.empty(xs, device=dy.device, dtype=BF16)
                 lib.sidlsg_sumpool2x2(_p(full), _p(dx), B, xs[1], xs[2], xs[3], _s())
-        drv = colsum(dy.view(B * Ho * Wo, Cout), Ho * Wo, per_batch=True) if (has_rv and ctx.needs_input_grad[5]) else None
+        drv = colsum(dy.view(B * Ho * Wo, Cout), Ho * Wo, per_batch=True, slot=ctx.rv_slot) if (has_rv and ctx.needs_input_grad[5]) else None
         dres = dy if (has_res and ctx.needs_input_grad[4]) else None
         return dx, None, None, None, dres, drv, None, None, None
 
@@ -1332,23 +1343,58 @@ def transpose_w(src_f32, n, k, taps=1, dtype=BF16):
     return dst
 
 
+class _ColumnGrads:
+    """The gradient of a split_columns() source, built in place: one [n, sum C] fp32 buffer per backward pass (zeroed ONCE, on
+    first use) into whose column slices the consumers' backward kernels accumulate (ops.colsum(slot=...)); _SplitColumns.backward
+    hands it on as it is.  22 fills + a concat kernel per pass become one fill."""
+
+    def __init__(self, sizes):
+        self.total, self.buf = sum(sizes), None
+
+    def buffer(self, n, device):
+        if self.buf is None:
+            self.buf = torch.zeros((n, self.total), device=device, dtype=F32)
+        return self.buf if self.buf.shape[0] == n else None
+
+    def take(self):
+        b, self.buf = self.buf, None
+        return b
+
+
 class _SplitColumns(torch.autograd.Function):
-    """x [N, sum C] -> views x[:, off_i:off_i+C_i] (no copies); backward = one torch.cat of the column gradients."""
+    """x [N, sum C] -> views x[:, off_i:off_i+C_i] (no copies); backward = the shared column-gradient buffer when every part's
+    gradient is its slice of it (the normal case), else one torch.cat of the column gradients."""
 
     @staticmethod
-    def forward(ctx, x, sizes):
-        ctx.sizes, ctx.meta = sizes, (x.shape[0], x.dtype, x.device)
+    def forward(ctx, x, sizes, holder):
+        ctx.sizes, ctx.meta, ctx.holder = sizes, (x.shape[0], x.dtype, x.device), holder
         return tuple(x.split(sizes, dim=1))
 
     @staticmethod
     def backward(ctx, *grads):
         n, dtype, dev = ctx.meta
+        buf = ctx.holder.take()
+        if buf is not None and dtype == F32 and buf.shape[0] == n:
+            off, ok = 0, True
+            for g, c in zip(grads, ctx.sizes):
+                ok = ok and g is not None and g.dtype == F32 and g.data_ptr() == buf.data_ptr() + 4 * off and g.stride(0) == buf.stride(0) and g.shape == (n, c)
+                off += c
+            if ok:
+                return buf, None, None
         gs = [g if g is not None else torch.zeros((n, c), device=dev, dtype=dtype) for g, c in zip(grads, ctx.sizes)]
-        return torch.cat([g.to(dtype) for g in gs], dim=1), None
+        return torch.cat([g.to(dtype) for g in gs], dim=1), None, None
 
 
 def split_columns(x, sizes):
-    return _SplitColumns.apply(x, list(sizes))
+    """-> tuple of column views; part._col_slot = (holder, offset, width) lets a consumer's backward accumulate its gradient in place."""
+    sizes = list(sizes)
+    holder = _ColumnGrads(sizes)
+    parts = _SplitColumns.apply(x, sizes, holder)
+    off = 0
+    for p, c in zip(parts, sizes):
+        p._col_slot = (holder, off, c)
+        off += c
+    return parts
 
 
 class _GradReady(torch.autograd.Function):

@@ -24,7 +24,7 @@ from .sd_util import hip_denoise, hip_generate, hip_prepare_denoise
 
 class _SegmentedUpdate:
     """Optimizer step of one network, issued segment by segment from inside its backward (HipUNet2DCondition.grad_segments:
-    up blocks + head, mid block, the rest).  As soon as the backward has passed a segment, that segment's gradient exchange
+    up blocks + head, mid block, the deep down blocks, the rest).  As soon as the backward has passed a segment, that segment's gradient exchange
     (world > 1) and its slice of the fused nan_to_num + Adam (+ EMA) + bf16-copy kernel run on the optimizer stream beside the
     MFMA-bound backward of the earlier layers: the HBM-bound optimizer (25 GB of traffic per network, ~5.5 ms on an MI355X)
     leaves the critical path except for the last segment.  Elementwise kernel, disjoint ranges: bit-identical to one launch
@@ -44,23 +44,23 @@ class _SegmentedUpdate:
 
     def _ready(self, k):
         st, net = self.step, self.net
-        lo, hi = self.segs[k]
         cur = torch.cuda.current_stream()
         if st.exchange:
-            st.reducer.start_range(net.flat_grads, lo, hi)            # communication stream, after cur + weight-gradient streams
+            st.reducer.start_segment(net.flat_grads, self.segs[k])    # communication stream, after cur + weight-gradient streams
         st.opt_stream.wait_stream(cur)
         for s in ops.grad_streams(net.flat_grads.device):
             st.opt_stream.wait_stream(s)
         with torch.cuda.stream(st.opt_stream):
             if st.exchange:
                 st.reducer.wait()                                     # orders the optimizer stream after the collectives
-            self.opt.launch_range(lo, hi, use_ema=self.use_ema)
+            for lo, hi in self.segs[k]:
+                self.opt.launch_range(lo, hi, use_ema=self.use_ema)
 
     def start_last(self):
         """After the backward: the remaining segment (still on the optimizer stream: it runs beside whatever the caller
         enqueues next on the compute stream)."""
         self.net.set_grad_ready_callback(None)
-        self._ready(2)
+        self._ready(len(self.segs) - 1)
 
     def join(self):
         torch.cuda.current_stream().wait_stream(self.step.opt_stream)
@@ -163,7 +163,7 @@ class SiDStep:
         self.G.requires_grad_(True)                                                 # :468
         if overlap:     # the markers of the segment-wise exchange are placed by the forward
             segs = self.G.grad_segments()
-            self.G.set_grad_ready_callback(lambda k: self.reducer.start_range(self.G.flat_grads, *segs[k]))
+            self.G.set_grad_ready_callback(lambda k: self.reducer.start_segment(self.G.flat_grads, segs[k]))
         cur = torch.cuda.current_stream()
         self.side.wait_stream(cur)
         for t in (r['z'], r['cond']):
@@ -189,11 +189,11 @@ class SiDStep:
             if overlap and i == len(rounds) - 1:
                 # last accumulation round: a segment of psi's flat gradient is exchanged as soon as the backward has passed it
                 # (the same scheme as for the generator in generator_update)
-                self.psi.set_grad_ready_callback(lambda k: self.reducer.start_range(self.psi.flat_grads, *segs[k]))
+                self.psi.set_grad_ready_callback(lambda k: self.reducer.start_segment(self.psi.flat_grads, segs[k]))
             loss = self.fake_round(r)
         if overlap:
             self.psi.set_grad_ready_callback(None)
-            self.reducer.start_range(self.psi.flat_grads, *segs[2])
+            self.reducer.start_segment(self.psi.flat_grads, segs[-1])
         self.psi.requires_grad_(False)                                              # :455
         return loss
 
@@ -275,12 +275,12 @@ class SiDStep:
             if overlap and i == len(rounds) - 1 and pre is None:
                 # last accumulation round (what DDP does outside no_sync): a segment of the flat gradient is exchanged as
                 # soon as the backward has passed it, while the earlier layers' backward is still running
-                self.G.set_grad_ready_callback(lambda k: self.reducer.start_range(self.G.flat_grads, *segs[k]))
+                self.G.set_grad_ready_callback(lambda k: self.reducer.start_segment(self.G.flat_grads, segs[k]))
             loss = self.generator_round(r, before_fake_eval if i == 0 else None, pre if i == 0 else None)
         self.G.requires_grad_(False)                                                # :538
         if overlap:
             self.G.set_grad_ready_callback(None)
-            self.reducer.start_range(self.G.flat_grads, *segs[2])
+            self.reducer.start_segment(self.G.flat_grads, segs[-1])
         self._optimizer_step(self.G, self.opt_G, ema_beta=ema_beta, started=overlap)   # :541-565
         return loss
 

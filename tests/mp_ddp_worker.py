@@ -128,11 +128,11 @@ def run_nccl(out):
 
         def cb(k):
             fired.append(k)
-            red.start_range(net.flat_grads, *segs[k])
+            red.start_segment(net.flat_grads, segs[k])
         net.set_grad_ready_callback(cb)
         net.forward_nhwc(x, t, ctx).backward(dy)
         net.set_grad_ready_callback(None)
-        red.start_range(net.flat_grads, *segs[2])
+        red.start_segment(net.flat_grads, segs[-1])
         red.wait()
         torch.cuda.synchronize()
         res[f'{name}_segments'] = float((net.flat_grads - want).abs().max()) / scale

@@ -490,17 +490,19 @@ def test_grad_segments_complete_when_marker_fires(dev):
         net = HipUNet2DCondition(CONFIGS[cfg_name]).materialize(dev, seed=3)
         net.requires_grad_(True)
         segs = net.grad_segments()
-        assert segs[0][1] == net.flat_grads.numel() and segs[2][0] == 0 and segs[0][0] == segs[1][1] and segs[1][0] == segs[2][1]
+        nseg = len(segs)
+        assert nseg == 3 + len(net.down_blocks) - 1
+        cover = sorted(r for sg in segs for r in sg)          # the segments partition the buffer
+        assert cover[0][0] == 0 and cover[-1][1] == net.flat_grads.numel() and all(a[1] == b[0] for a, b in zip(cover, cover[1:]))
         snaps, order = {}, []
 
         def cb(k):
             order.append(k)
-            lo, hi = segs[k]
             # the consumer's contract (FlatGradReducer.start_range): order after the current stream AND after the
             # weight-gradient stream, then the segment is final
             for side in ops.grad_streams(dev):
                 torch.cuda.current_stream().wait_stream(side)
-            snaps[k] = net.flat_grads[lo:hi].clone()
+            snaps[k] = [net.flat_grads[lo:hi].clone() for lo, hi in segs[k]]
         net.set_grad_ready_callback(cb)
         g = torch.Generator().manual_seed(1)
         x = torch.randn(2, 4, lat, lat, generator=g).to(dev).requires_grad_()
@@ -508,11 +510,15 @@ def test_grad_segments_complete_when_marker_fires(dev):
         y = net(x, torch.tensor([625, 37], device=dev), encoder_hidden_states=ctx).sample
         y.backward(torch.randn(y.shape, generator=g).to(dev))
         net.set_grad_ready_callback(None)
-        assert order == [0, 1], order
-        for k in (0, 1):
-            lo, hi = segs[k]
-            assert snaps[k].abs().sum() > 0
-            assert torch.equal(snaps[k], net.flat_grads[lo:hi]), f'{cfg_name}: segment {k} changed after its marker fired'
+        assert order == list(range(nseg - 1)), order
+        for k in range(nseg - 1):
+            assert sum(float(t.abs().sum()) for t in snaps[k]) > 0
+            for t, (lo, hi) in zip(snaps[k], segs[k]):
+                assert torch.equal(t, net.flat_grads[lo:hi]), f'{cfg_name}: segment {k} changed after its marker fired'
+        # what is left for after the backward is small: down_blocks[0], conv_in, the time embedding (+ its fused projections)
+        left = sum(hi - lo for lo, hi in segs[-1]) / net.flat_grads.numel()
+        print(f'{cfg_name}: {nseg} segments, {100 * left:.1f} % of the buffer exchanged after the backward')
+        assert left < 0.12
 
 
 def _loop_kwargs_from_golden(g, run_dir, pdir, dev):

@@ -15,6 +15,7 @@ from sid_lsg_amd._lib import lib  # noqa: E402
 lib.load()
 dev = torch.device('cuda:0')
 B = 16
+PS = os.environ.get('ATTN_PS', '1') == '1'      # the `_ps` entry points the networks use (pre-scaled queries)
 ref_path = sys.argv[1] if len(sys.argv) > 1 else None
 out = {}
 for N, heads, D in ((4096, 8, 40), (4096, 5, 64), (1024, 8, 80)):
@@ -23,12 +24,12 @@ for N, heads, D in ((4096, 8, 40), (4096, 5, 64), (1024, 8, 80)):
     qkv = (torch.randn(B, N, 3 * C, device=dev, generator=g)).to(torch.bfloat16).requires_grad_()
     do = torch.randn(B, N, C, device=dev, generator=g).to(torch.bfloat16)
     for _ in range(6):
-        y = ops.self_attention(qkv, heads)
+        y = ops.self_attention(qkv, heads, PS)
         qkv.grad = None
         y.backward(do)
     torch.cuda.synchronize()
-    out[f'y_{N}_{D}'] = y.detach().float().cpu()
-    out[f'g_{N}_{D}'] = qkv.grad.detach().float().cpu()
+    out[f'y_{N}_{D}'] = y.detach()[::5, ::97].float().cpu()          # (a sample: the file stays small)
+    out[f'g_{N}_{D}'] = qkv.grad.detach()[::5, ::97].float().cpu()
 if ref_path:
     if os.path.isfile(ref_path):
         ref = torch.load(ref_path)
