@@ -108,6 +108,13 @@ int sidlsg_groupnorm_bwd(const void* x, const void* dy, const float* stats, cons
 int sidlsg_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* stats, int rows, int C,
                          float eps, void* stream);
 int sidlsg_layernorm_bwd_nblocks(int rows); /* host: ws = nblocks*C*2 floats */
+/* Deferred dgamma / dbeta reductions (csrc/norm.hip "deferred parameter-gradient reductions"): with deferral on for a stream the norm
+ * backward entry points queue their final reduction; sidlsg_flush_reductions launches everything queued for the stream as ONE kernel.
+ * The caller keeps every `ws` passed to a deferred call allocated and untouched until the flush.  Return: reductions flushed, < 0 error;
+ * sidlsg_pending_reductions: queued reductions, -1 when deferral is off for the stream. */
+int sidlsg_defer_reductions(void* stream, int on); /* 1: queue from now on; 2: stop queuing, keep the queue; 0: flush + forget */
+int sidlsg_flush_reductions(void* stream);
+int sidlsg_pending_reductions(void* stream);
 int sidlsg_layernorm_bwd(const void* x, const void* dy, const float* stats, const float* gamma, const void* dres, void* dx,
                          float* dgamma, float* dbeta, float* ws, int rows, int C, void* stream);
 

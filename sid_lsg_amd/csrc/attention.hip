@@ -811,21 +811,26 @@ template <int DP, int QT, int KT, bool PS>
 static int launch_attn(const AttnParams& p, int mode, hipStream_t s) {
     return mode == 2 ? launch_attn_dkdv<DP, KT, PS>(p, s) : launch_attn_q<DP, QT, PS>(p, mode, s);
 }
-// Which passes renumber (measured, MI355X, B = 16, rocprofv3 per-kernel averages with / without): forward 314 -> 312 us (N 4096, d 40), 46.2 -> 44.0
+// Which passes renumber.  Round 4 (rocprofv3 per-kernel averages with / without, MI355X, B = 16): forward 314 -> 312 us (N 4096, d 40), 46.2 -> 44.0
 // (N 1024, d 80), 19.0 -> 17.0 (N 256, d 160); dQ pass 816 -> 827 / 91.4 -> 86.7 / 26.6 -> 25.0; dK/dV pass 1110 -> 1174 / 119 -> 115 / 36.9 -> 30.5:
-// the backward passes of the 4096-token layers lose (all resident blocks of an XCD then walk the same Q / dO rows in lockstep and meet in
-// the same L2 channels), everything else gains -> forward always, backward passes up to 1024 tokens.  HBM-side bytes per call of the
-// micro-benchmark with everything renumbered: forward 364 -> 107 MB (3.66x -> 1.08x the algorithmic bytes), backward 1134 -> 436 MB (4.9x -> 1.9x).
-// SIDLSG_ATTN_XCD: bit mask of the passes that may renumber (1 forward, 2 dQ, 4 dK/dV; 8: also the long backward passes); default 7.
+// the backward passes of the 4096-token layers LOST -- all resident blocks of an XCD then walk the same Q / dO rows in lockstep -- so they
+// kept the round-robin order and with it 4.1x the algorithmic HBM-side bytes (every XCD fetches every head).  Round 5: the ROTATED walk
+// (AttnParams::rot: block i of a head starts at tile i * ntiles / nblocks and wraps) takes the lockstep away: N 4096 d 40 dK/dV pass
+// 1042 (round robin) / 1123 (contiguous) / 1039 (contiguous + rotated) us, dQ 784 / 782 / 785, forward 523 / 511 / 507; d 64: 757 / 756 / 757,
+// 535 / 540 / 515-521, 421 / 415 / 424 (tools/ab/attn_rot.py under rocprofv3, gpurun_out r5c3) -- kernel time and step time (211-214 ms either
+// way) are unchanged, the long backward passes now fetch a head's Q / dO once per XCD instead of once per XCD AND per 4-block group.
+// HBM-side bytes per call of the micro-benchmark with everything renumbered: forward 364 -> 107 MB (3.66x -> 1.08x the algorithmic bytes),
+// backward 1134 -> 436 MB (4.9x -> 1.9x).
+// SIDLSG_ATTN_XCD: bit mask of the passes that may renumber (1 forward, 2 dQ, 4 dK/dV; 8: also the long backward passes); default 15.
 static int attn_xcd_on(int mode, const AttnParams& p) {
-    static const int mask = getenv("SIDLSG_ATTN_XCD") ? atoi(getenv("SIDLSG_ATTN_XCD")) : 7;
+    static const int mask = getenv("SIDLSG_ATTN_XCD") ? atoi(getenv("SIDLSG_ATTN_XCD")) : 15;
     if (!((mask >> mode) & 1)) return 0;
     return mode == 0 || (mask & 8) || (p.Nq <= 1024 && p.Nk <= 1024);
 }
-// SIDLSG_ATTN_ROT: bit mask of the passes whose blocks start their tile walk at per-block offsets (1 forward, 2 dQ, 4 dK/dV); only
-// together with the XCD-contiguous numbering (without it an XCD holds 4 blocks of each of 16 heads: nothing walks in lockstep)
+// SIDLSG_ATTN_ROT: bit mask of the passes whose blocks start their tile walk at per-block offsets (1 forward, 2 dQ, 4 dK/dV; default 7);
+// only together with the XCD-contiguous numbering (without it an XCD holds 4 blocks of each of 16 heads: nothing walks in lockstep)
 static int attn_rot_on(int mode, const AttnParams& p) {
-    static const int mask = getenv("SIDLSG_ATTN_ROT") ? atoi(getenv("SIDLSG_ATTN_ROT")) : 0;
+    static const int mask = getenv("SIDLSG_ATTN_ROT") ? atoi(getenv("SIDLSG_ATTN_ROT")) : 7;
     return p.xcd && ((mask >> mode) & 1);
 }
 template <bool PS>

@@ -205,6 +205,61 @@ class _OnWgradStream:
         return False
 
 
+# ---- deferred parameter-gradient reductions of the norm backward kernels ---------------------------------------------------
+# (csrc/norm.hip "deferred parameter-gradient reductions"): the dgamma / dbeta reductions of a backward pass -- ~80 per trainable
+# network and pass, each a tiny launch on the critical stream -- are queued by the library and run as ONE launch per stream when the
+# backward pass ends (autograd engine callback), when a gradient-exchange marker fires (_GradReady) or when somebody is about to
+# read gradients (flush_deferred(): the fused optimizer and the reducer call it).  The partial-sum workspaces are kept alive here
+# until then.  SIDLSG_DEFER_REDUCE=0: one reduction launch per layer as before (A/B, tests).
+_DEFER = os.environ.get('SIDLSG_DEFER_REDUCE', '1') != '0'
+_defer_streams = {}          # stream handle -> [torch stream, [workspaces]]
+_defer_armed = set()
+
+
+def _defer_begin(device):
+    """Before a norm-backward launch that reduces parameter gradients: deferral on for the current stream."""
+    if not _DEFER:
+        return None
+    st = torch.cuda.current_stream(device)
+    h = st.cuda_stream
+    if h not in _defer_streams:
+        _defer_streams[h] = [st, []]
+    lib.sidlsg_defer_reductions.raw(h, 1)
+    return h
+
+
+def _defer_end(h, ws):
+    """After the launch: keep its partial sums alive; flush at the end of this backward pass (right away outside one)."""
+    if h is None:
+        return
+    lib.sidlsg_defer_reductions.raw(h, 2)        # only the call in between was deferred (direct users of the C ABI never are)
+    _defer_streams[h][1].append(ws)
+    tid = torch._C._current_graph_task_id()
+    if tid < 0:
+        flush_deferred()
+    elif tid not in _defer_armed:
+        _defer_armed.clear()             # ids never repeat: anything left is from a pass that did not finish
+        _defer_armed.add(tid)
+
+        def done():
+            _defer_armed.discard(tid)
+            flush_deferred()
+        torch.autograd.Variable._execution_engine.queue_callback(done)
+
+
+def flush_deferred():
+    """Launch every queued reduction (one kernel per stream that has any) and order the current stream after them."""
+    for h, (st, keep) in _defer_streams.items():
+        if not keep:
+            continue
+        if lib.sidlsg_flush_reductions.raw(h) < 0:
+            raise RuntimeError('sidlsg_flush_reductions failed')
+        keep.clear()
+        cur = torch.cuda.current_stream(st.device)
+        if cur.cuda_stream != h:
+            cur.wait_stream(st)
+
+
 def ensure_stream_workspace(stream, nbytes=256 << 20):
     """Private split-K scratch for a side stream that runs contractions concurrently with the main one."""
     key = stream.cuda_stream
@@ -607,8 +662,10 @@ class _GroupNorm(torch.autograd.Function):
         ws = torch.empty(n, device=x.device, dtype=F32)
         dx = torch.empty_like(x)
         pg = _wants_grad(gamma) and _wants_grad(beta)
+        h = _defer_begin(x.device) if pg else None
         _fn('groupnorm_bwd', x.dtype)(_p(x), _p(dy), _p(stats), _p(gamma), _p(beta), _p(dkeep) if dkeep is not None else None, _p(dx),
                                       _p(gamma.grad) if pg else None, _p(beta.grad) if pg else None, _p(ws), B, HW, C, groups, silu, _s())
+        _defer_end(h, ws)
         return dx, None, None, None, None, None, None
 
 
@@ -697,8 +754,10 @@ class _LayerNorm(torch.autograd.Function):
         dx = torch.empty_like(x)
         pg = _wants_grad(gamma) and _wants_grad(beta)
         ws = torch.empty(lib.sidlsg_layernorm_bwd_nblocks.raw(rows) * C * 2, device=x.device, dtype=F32) if pg else None
+        h = _defer_begin(x.device) if pg else None
         _fn('layernorm_bwd', x.dtype)(_p(x), _p(dy), _p(stats), _p(gamma), _p(dkeep) if dkeep is not None else None, _p(dx),
                                       _p(gamma.grad) if pg else None, _p(beta.grad) if pg else None, _p(ws), rows, C, _s())
+        _defer_end(h, ws)
         return dx, None, None, None, None
 
 
@@ -1409,6 +1468,7 @@ class _GradReady(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
+        flush_deferred()        # queued dgamma / dbeta reductions belong to the segment that is about to be declared final
         ctx.cb()
         return g, None
 

@@ -128,6 +128,7 @@ class FusedAdamEMA:
         self._hyper_evt[k] = evt
 
     def launch(self, use_ema=True, zero_grad=True):
+        ops.flush_deferred()          # (no-op unless a backward pass left reductions queued outside the autograd engine's callback)
         self._covered = 0
         self._launch_parts(0, self.flat.numel(), use_ema, zero_grad)
 
@@ -137,6 +138,7 @@ class FusedAdamEMA:
         finished with it, on its own stream beside the rest of the backward."""
         if hi <= lo:
             return
+        ops.flush_deferred()
         if lo % 4:
             raise ValueError('range start must be a multiple of 4 elements (16-byte vector accesses)')
         self._launch_parts(lo, hi, use_ema, zero_grad)

@@ -279,6 +279,89 @@ def test_layernorm(dev, rows, C):
     close(bm.grad, br.grad, 3e-3, 'dbeta')
 
 
+def test_deferred_parameter_gradient_reductions(dev):
+    """Round 5: the dgamma / dbeta reductions of a backward pass are queued by the library and run as one launch per stream at the end
+    of the pass (csrc/norm.hip "deferred parameter-gradient reductions", ops.flush_deferred).  (a) C ABI: two LayerNorm and one
+    two-kernel GroupNorm backward with deferral on leave the gradients untouched until the flush and then equal the undeferred
+    results; a call made after `defer(stream, 2)` is not deferred.  (b) autograd: a chain of 100 LayerNorms (more than one job table)
+    in one backward pass gives every layer's dgamma / dbeta, nothing stays queued, and a marker (ops.grad_ready_marker) in the middle
+    sees the gradients of the layers behind it final."""
+    from sid_lsg_amd import ops
+    from sid_lsg_amd._lib import lib
+    st = ops._s()
+    rows, C = 4096, 320
+    x, dy = rnd(rows, C, seed=1).to(dev), rnd(rows, C, seed=2).to(dev)
+    gam = (torch.randn(C, generator=torch.Generator().manual_seed(3)) * 0.5 + 1).to(dev)
+    stats = torch.empty(rows, 2, device=dev)
+    y = torch.empty_like(x)
+    lib.sidlsg_layernorm_fwd(x.data_ptr(), gam.data_ptr(), gam.data_ptr(), y.data_ptr(), stats.data_ptr(), rows, C, 1e-5, st)
+
+    def ln_bwd(dg, db, ws):
+        dx = torch.empty_like(x)
+        lib.sidlsg_layernorm_bwd(x.data_ptr(), dy.data_ptr(), stats.data_ptr(), gam.data_ptr(), None, dx.data_ptr(), dg.data_ptr(), db.data_ptr(),
+                                 ws.data_ptr(), rows, C, st)
+    nws = lib.sidlsg_layernorm_bwd_nblocks.raw(rows) * C * 2
+    ref_g, ref_b = torch.zeros(C, device=dev), torch.zeros(C, device=dev)
+    ln_bwd(ref_g, ref_b, torch.empty(nws, device=dev))
+    torch.cuda.synchronize()
+    assert float(ref_g.abs().sum()) > 0
+    g1, b1, g2, b2 = (torch.zeros(C, device=dev) for _ in range(4))
+    w1, w2 = torch.empty(nws, device=dev), torch.empty(nws, device=dev)
+    assert lib.sidlsg_pending_reductions.raw(st) in (-1, 0)
+    lib.sidlsg_defer_reductions.raw(st, 1)
+    ln_bwd(g1, b1, w1)
+    ln_bwd(g2, b2, w2)
+    torch.cuda.synchronize()
+    assert lib.sidlsg_pending_reductions.raw(st) == 2 and float(g1.abs().sum()) == 0.0 and float(b2.abs().sum()) == 0.0
+    lib.sidlsg_defer_reductions.raw(st, 2)
+    g3, b3 = torch.zeros(C, device=dev), torch.zeros(C, device=dev)
+    ln_bwd(g3, b3, torch.empty(nws, device=dev))             # not deferred any more: immediate
+    torch.cuda.synchronize()
+    assert float(g3.abs().sum()) > 0 and lib.sidlsg_pending_reductions.raw(st) == 2
+    assert lib.sidlsg_flush_reductions.raw(st) == 2
+    torch.cuda.synchronize()
+    for g, b in ((g1, b1), (g2, b2), (g3, b3)):
+        close(g, ref_g, 1e-5, 'deferred dgamma')
+        close(b, ref_b, 1e-5, 'deferred dbeta')
+    assert lib.sidlsg_pending_reductions.raw(st) == 0
+    # (b) through autograd
+    n_layers = 100
+    gms = [torch.nn.Parameter((torch.randn(C, generator=torch.Generator().manual_seed(10 + i)) * 0.2 + 1).to(dev)) for i in range(n_layers)]
+    bms = [torch.nn.Parameter(torch.zeros(C, device=dev)) for _ in range(n_layers)]
+    for p in gms + bms:
+        p.grad = torch.zeros_like(p)
+    seen = {}
+
+    def at_marker():
+        # the layers behind the marker (50 ...) have run their backward: their gradients must be final NOW (the marker flushed)
+        torch.cuda.synchronize()
+        seen['late'] = [float(gms[i].grad.abs().sum()) for i in (50, 75, 99)]
+        seen['early'] = [float(gms[i].grad.abs().sum()) for i in (0, 25, 49)]
+    for mode in ('deferred', 'ref'):
+        h = x.clone().requires_grad_()
+        a = h
+        for p in gms + bms:
+            p.grad.zero_()
+        old = ops._DEFER
+        ops._DEFER = mode == 'deferred'
+        try:
+            for i in range(n_layers):
+                if i == 50 and mode == 'deferred':
+                    a = ops.grad_ready_marker(a, at_marker)
+                a = ops.layer_norm(a, gms[i], bms[i], 1e-5)
+            a.backward(dy)
+            torch.cuda.synchronize()
+        finally:
+            ops._DEFER = old
+        if mode == 'deferred':
+            assert lib.sidlsg_pending_reductions.raw(st) == 0
+            got = [(g.grad.clone(), b.grad.clone()) for g, b in zip(gms, bms)]
+            assert min(seen['late']) > 0 and max(seen['early']) == 0.0, seen
+    for i, (g, b) in enumerate(got):
+        close(g, gms[i].grad, 1e-4, f'layer {i} dgamma')
+        close(b, bms[i].grad, 1e-4, f'layer {i} dbeta')
+
+
 @pytest.mark.parametrize('kind', ['gn', 'ln'])
 def test_norm_fork_fuses_residual_gradient(dev, kind):
     """fork=True: (y, x_keep); the gradient arriving through x_keep is summed inside the norm-backward kernel.
