@@ -54,6 +54,13 @@ def _grad_side_streams(t):
     return ops.grad_streams(t.device)
 
 
+def _flush_deferred(t):
+    """Gradients are about to be read: run the norm kernels' queued dgamma / dbeta reductions first (ops.flush_deferred)."""
+    if t.is_cuda:
+        from . import ops
+        ops.flush_deferred()
+
+
 class FlatGradReducer:
     """Data-parallel gradient exchange on a network's flat fp32 gradient buffer.
 
@@ -133,6 +140,7 @@ class FlatGradReducer:
         ordered after everything already enqueued on the current stream.  Several ranges may be in flight; wait() joins all."""
         if get_world_size() < self.min_world or hi <= lo:
             return
+        _flush_deferred(flat_grad)
         if self.stream is not None:
             self.stream.wait_stream(torch.cuda.current_stream())
             for side in _grad_side_streams(flat_grad):      # weight gradients are produced on their own stream (ops.py)
@@ -152,6 +160,7 @@ class FlatGradReducer:
     def start(self, flat_grad):
         if get_world_size() < self.min_world:
             return
+        _flush_deferred(flat_grad)
         n = flat_grad.numel()
         step = (n + self.nbuckets - 1) // self.nbuckets
         step = (step + 1023) // 1024 * 1024

@@ -41,6 +41,7 @@ def _ddp_exchange(net, out):
         # engine callbacks run in FIFO order and this one was queued by the FIRST node of the backward, i.e. before the
         # weight-gradient stream's own join callback (armed at the first wgrad launch): wait for that stream here
         g = inner.flat_grads
+        ops.flush_deferred()          # queued dgamma / dbeta reductions first (their own end-of-backward callback may run after this one)
         if g.is_cuda:
             cur = torch.cuda.current_stream(g.device)
             for s in ops.grad_streams(g.device):
