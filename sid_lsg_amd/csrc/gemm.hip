@@ -1779,121 +1779,12 @@ static int launch_gemm_as(const GemmParams& p, hipStream_t s) {
     return sidlsg_last_error();
 }
 
-// ---------------------------------------------------------------------------------------------------------------------
-// "s64": dense GEMM for the SMALL launches (the 64 x 64-tile fallback of the dispatcher: M <= ~2048 rows -- the 77-token K / V
-// projections of the 16 cross-attention layers, the 8 x 8 stage's Linears, the time-embedding MLP; ~250 launches per iteration).
-// These are latency-bound, not throughput-bound: a 64 x 64 x 64 K-tile is 0.5 MFLOP per block (~0.1 us of MFMA), while the
-// register-staged double buffer of gemm_bf16_kernel<64, 64> keeps ONE K-tile in flight, so every K-tile costs a full L2 -> LDS round
-// trip (~0.8 - 1 us under load; 12 - 20 K-tiles -> 17 - 20 us per launch in the step's profile for 1 - 3 GFLOP).  Here the tiles are
-// staged by buffer_load ... lds into a 4-slot ring with THREE K-tiles in flight and counted waits (the scheme of gemm_as_kernel: every
-// vector-memory operation of the loop is an always-issued buffer operation, dead tiles fetch zeros through out-of-range offsets, so
-// s_waitcnt vmcnt(8) means "everything but the two youngest tiles has landed"); one barrier per K-tile; 16 KiB per slot -> 64 KiB per
-// block, 2 blocks per CU.  Fragment layout, swizzles (A: (row >> 1) & 7, W: wsw) and the W-row permutation are those of gemm_v3_kernel,
-// so the shared epilogue (bias / residual / row vector / SiLU / fp32 / accumulate / ragged N, grouped launches) is reused unchanged.
-constexpr int S64_R = 4;
-__global__ __launch_bounds__(NTHREADS, 2) void gemm_s64_kernel(GemmParams p) {
-    constexpr int BM = 64, BN = 64, MT = 2, NT = 2, R = S64_R;
-    constexpr int AST = BM * BK, STG = (BM + BN) * BK;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    bf16* ring = reinterpret_cast<bf16*>(smem);
-    const int tiles_m = m_tiles_rt(p, BM);
-    const int tiles_n = (p.N + BN - 1) / BN;
-    int bid = blockIdx.x;
-    {
-        const int nblk = tiles_m * tiles_n;
-        const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
-    const int nt = bid / tiles_m, mt = bid - nt * tiles_m;          // m fastest: neighbours share the 64 x K weight panel
-    const int m0 = group_select<BM>(p, mt);
-    const int n0 = nt * BN;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm0 = (wave >> 1) * 32, wn0 = (wave & 1) * 32;
-    const int li = lane & 15, lg = lane >> 4;
-    const int lrow = lane >> 3, lslot = lane & 7;
-    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(p.A), 0, (int)p.a_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(p.W), 0, (int)p.w_bytes, 0x00020000);
-    unsigned aoff[2], boff[2];
-    int akc[2], bkc[2];
-#pragma unroll
-    for (int j = 0; j < 2; j++) {
-        const int r = wave * 16 + j * 8 + lrow;
-        akc[j] = lslot ^ ((r >> 1) & 7);
-        bkc[j] = lslot ^ wsw(r);
-        const int m = m0 + r, n = n0 + r;
-        aoff[j] = m < p.M ? ((unsigned)m * (unsigned)p.lda + akc[j] * 8) * 2u : OOB;
-        boff[j] = n < p.N ? ((unsigned)n * (unsigned)p.K + bkc[j] * 8) * 2u : OOB;
-    }
-    const int nk = (p.K + BK - 1) / BK;
-    // always 4 DMAs per wave; tiles past the end (and the chunks of a ragged last K-tile past K) fetch zeros
-    auto issue = [&](int t) __attribute__((always_inline)) {
-        bf16* sa = ring + (t % R) * STG;
-        bf16* sb = sa + AST;
-        const int k0 = t * BK;
-        const bool live = t < nk;
-#pragma unroll
-        for (int j = 0; j < 2; j++) {
-            const bool oka = live && k0 + akc[j] * 8 < p.K, okb = live && k0 + bkc[j] * 8 < p.K;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lptr_t)(sa + (wave * 16 + j * 8) * BK), 16, oka ? aoff[j] : OOB, live ? k0 * 2 : 0, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lptr_t)(sb + (wave * 16 + j * 8) * BK), 16, okb ? boff[j] : OOB, live ? k0 * 2 : 0, 0, 0);
-        }
-    };
-    EpiPre<NT> pre;
-    epilogue_prefetch<NT>(p, pre, n0 + wn0, lg);        // plain loads, older than every DMA: landed at the first counted wait
-    issue(0); issue(1); issue(2);
-    f32x4 acc[NT][MT];
-#pragma unroll
-    for (int i = 0; i < NT; i++)
-#pragma unroll
-        for (int j = 0; j < MT; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    int wrow[NT];
-#pragma unroll
-    for (int ni = 0; ni < NT; ni++) wrow[ni] = wn0 + (li >> 2) * 8 + (ni & 1) * 4 + (li & 3);
-    for (int kt = 0; kt < nk; kt++) {
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");      // tile kt has landed (tiles kt+1, kt+2 = 8 DMAs may still fly)
-        __builtin_amdgcn_s_barrier();                          // ... for every wave; and everybody is done reading tile kt-1
-        asm volatile("" ::: "memory");
-        issue(kt + 3);                                         // into the slot of tile kt-1
-        const bf16* a = ring + (kt % R) * STG;
-        const bf16* b = a + AST;
-#pragma unroll
-        for (int kk = 0; kk < 2; kk++) {
-            const int ch = kk * 4 + lg;
-            bf16x8 fa[MT], fw[NT];
-#pragma unroll
-            for (int mi = 0; mi < MT; mi++) {
-                const int r = wm0 + mi * 16 + li;
-                fa[mi] = *reinterpret_cast<const bf16x8*>(a + r * BK + ((ch ^ ((r >> 1) & 7)) << 3));
-            }
-#pragma unroll
-            for (int ni = 0; ni < NT; ni++) {
-                const int r = wrow[ni];
-                fw[ni] = *reinterpret_cast<const bf16x8*>(b + r * BK + ((ch ^ wsw(r)) << 3));
-            }
-#pragma unroll
-            for (int ni = 0; ni < NT; ni++)
-#pragma unroll
-                for (int mi = 0; mi < MT; mi++)
-                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[ni], fa[mi], acc[ni][mi], 0, 0, 0);
-        }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the dead tiles' DMAs must not outlive the block's LDS allocation
-    gemm_epilogue<MT, NT>(p, acc, m0 + wm0, n0 + wn0, li, lg, pre);
-}
-
-static int launch_gemm_s64(const GemmParams& p, hipStream_t s) {
-    constexpr size_t lds = (size_t)S64_R * (64 + 64) * BK * sizeof(bf16);
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_s64_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_done = true;
-    }
-    const int tiles = m_tiles_rt(p, 64) * ((p.N + 63) / 64);
-    SIDLSG_LAUNCH(gemm_s64_kernel, dim3(tiles), dim3(NTHREADS), lds, s, p);
-    return sidlsg_last_error();
-}
-
+// (A multi-stage variant of the 64 x 64 fallback below -- "s64": buffer_load ... lds into a 4-slot ring, three K-tiles in flight, counted
+// vmcnt waits, the v3 fragment layout -- was built in round 5 on the theory that the ~250 small launches per iteration (text K / V
+// projections, 8 x 8 stage Linears: 17 - 20 us each in the step's profile) are bound by one L2 -> LDS round trip per K-tile.  Measured
+// alone (tools/ab/small_gemm.py under rocprofv3) they are not: 1232 x 640 x 768 7.4 us with either kernel, 1024 x 1280 x 1280 12.9 ->
+// 11.2, 2048 x 1280 x 1280 17.2 -> 18.7, step 209.98 vs 209.87 ms -- their time in the step is chip sharing, not their own latency.
+// Correct (the shapes are in tests/test_gpu_ops.py::test_gemm), neutral, not in the build: commit "gemm_s64_kernel" of round 5.)
 template <int BM, int BN, int MODE>
 static int launch_gemm(const GemmParams& p, hipStream_t s) {
     const int tiles = m_tiles_rt(p, BM) * ((p.N + BN - 1) / BN);
@@ -1971,10 +1862,6 @@ static int dispatch_gemm(const GemmParams& pin, hipStream_t s) {
         return n160 ? launch_gemm<128, 160, MODE>(p, s) : launch_gemm<128, 128, MODE>(p, s);
     }
     if (tiles(64, n160 ? 160 : 128) >= 384) return n160 ? launch_gemm<64, 160, MODE>(p, s) : launch_gemm<64, 128, MODE>(p, s);
-    if constexpr (MODE == 0) {
-        static const bool s64_on = !(getenv("SIDLSG_GEMM_S64") && atoi(getenv("SIDLSG_GEMM_S64")) == 0);   // A/B switch
-        if (s64_on && !p.kt_per_split && !(((uintptr_t)p.A | (uintptr_t)p.W) & 15)) return launch_gemm_s64(p, s);
-    }
     return launch_gemm<64, 64, MODE>(p, s);
 }
 

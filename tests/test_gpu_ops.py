@@ -46,8 +46,8 @@ def close(got, ref, tol, name=''):
 @pytest.mark.parametrize('M,N,K', [(256, 320, 320), (1000, 136, 72), (4096, 960, 320), (77 * 2, 640, 768), (130, 8, 2880), (64, 2560, 320),
                                    (1000, 1280, 2560), (300, 136, 4096),     # split-K path (few tiles, long K)
                                    (49152, 320, 320), (49160, 320, 328),                      # direct-to-LDS kernel (+ ragged M, K tail)
-                                   # the multi-stage 64 x 64 kernel of the small launches (gemm_s64_kernel: 3 K-tiles in flight, counted waits):
-                                   # K / V projections of the text states, 8 x 8 stage Linears; ragged M / N / K, K shorter than the ring
+                                   # the 64 x 64-tile fallback of the small launches: K / V projections of the text states, 8 x 8 stage Linears;
+                                   # ragged M / N / K, very short K
                                    (1232, 640, 768), (616, 2560, 768), (1024, 1280, 1280), (2048, 1280, 1280), (300, 200, 200), (65, 72, 8),
                                    (129, 136, 136), (1000, 320, 5120)])
 def test_gemm(dev, M, N, K):
