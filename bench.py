@@ -291,6 +291,10 @@ def main():
     ap.add_argument('--graph', action='store_true',
                     help='run the timed region through SiDStep.iteration_graphed (one HIP graph per iteration); per-kernel event '
                          'timing then happens on eager iterations after the timed region')
+    ap.add_argument('--force-exchange', action='store_true',
+                    help='single rank only: run the data-parallel gradient exchange anyway (RCCL all-reduces over a world of 1, '
+                         'FlatGradReducer(min_world=1)) -- the schedule, stream waits and launch path of a multi-GPU run on one GPU; '
+                         '`comm` then reports how long the compute stream stood still for it (no xGMI traffic: a lower bound)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true')
     args = ap.parse_args()
@@ -310,6 +314,13 @@ def main():
     if world > 1:
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         torch.distributed.init_process_group('gloo' if share else 'nccl', init_method='env://')
+    elif args.force_exchange:
+        import socket
+        with socket.socket() as sk:
+            sk.bind(('127.0.0.1', 0))
+            port = sk.getsockname()[1]
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        torch.distributed.init_process_group('nccl', init_method=f'tcp://127.0.0.1:{port}', world_size=1, rank=0)
     assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
 
     from sid_lsg_amd._lib import lib
@@ -318,7 +329,7 @@ def main():
 
     b = args.batch_gpu
     lat = args.resolution // 8
-    reducer = FlatGradReducer() if world > 1 else None
+    reducer = FlatGradReducer() if world > 1 else (FlatGradReducer(min_world=1) if args.force_exchange else None)
     if reducer is not None and not args.graph:
         reducer.enable_timing()          # exposed-communication figures of the multi-GPU run (`comm` in the JSON line)
     S = setup_step(args.arch, b, args.resolution, args.kappa, dev, rank=rank, world=world, teacher_weights=args.teacher_weights,
@@ -455,7 +466,8 @@ def main():
         'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
         'config': {'workload': f'{args.arch} SiD-LSG inner step, kappa={args.kappa} on all branches, {args.resolution}x{args.resolution} ({lat}x{lat}x4 latents), '
                                f'batch_gpu={b}, fp32 masters + bf16 MFMA compute, Adam(beta1=0)+EMA, random-init weights',
-                   'global_batch': batch_size, 'parallelism': f'dp{world}', 'teacher_weights': args.teacher_weights},
+                   'global_batch': batch_size, 'parallelism': f'dp{world}' + ('+forced-exchange(world-1 RCCL)' if args.force_exchange and world == 1 else ''),
+                   'teacher_weights': args.teacher_weights},
         'step_tflops': value * img_tflop, 'step_mfma_frac': value * img_tflop / (PEAK_BF16_TFLOPS * world),
         'graph': bool(args.graph), 'grouped_frozen_pass': bool(step._use_grouped(b)), 'host_enqueue_ms_per_step': t_host, 'loss_fake': float(lf), 'loss_G': float(lg), 'peak_mem_gb': torch.cuda.max_memory_allocated(dev) / 2 ** 30,
     }
@@ -551,6 +563,7 @@ def _shutdown(world):
     """All ranks leave together: the others wait here while rank 0 finishes its rank-local measurements (teacher pass)."""
     if world > 1:
         torch.distributed.barrier()
+    if torch.distributed.is_available() and torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
 
 

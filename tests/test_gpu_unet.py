@@ -767,13 +767,17 @@ def test_reference_loop_shape_with_foreign_optimizer(dev):
         assert agree / max(total, 1) > 0.93, f'update-sign agreement {agree / max(total, 1):.4f}'
 
 
-@pytest.mark.parametrize('precision', ['fp32', 'bf16'])
+@pytest.mark.parametrize('precision', ['fp32', 'bf16', 'fp32+bf16-exchange'])
 def test_two_rank_loop_matches_reference_ddp_golden(dev, golden_dir, tmp_path, precision):
     """the data-parallel path against a 2-RANK run of the UNMODIFIED reference loop
     (DistributedDataParallel + misc.ddp_sync on gloo, oracle/make_goldens.py::gen_loop_2rank -> loop2_k15_a1.npz): each
     rank's own loss curve and the (rank-identical) final weights.  Two processes share this GPU and exchange over gloo
     (tests/mp_loop_worker.py); the exchange logic (FlatGradReducer, overlapped psi / segment-wise G exchange, mean in the
-    optimizer kernel) is the production one.  fp32 mode: 1e-3 (north_star); bf16: the bounds of the 1-rank golden test."""
+    optimizer kernel) is the production one.  fp32 mode: 1e-3 (north_star); bf16: the bounds of the 1-rank golden test.
+    'fp32+bf16-exchange' (round 5): fp32 compute with the OPT-IN bf16 gradient exchange (SIDLSG_GRAD_EXCHANGE=bf16: every rank's
+    contribution rounded to 8 mantissa bits, bf16 accumulation in the collective, half the xGMI bytes) -- what that switch costs on
+    the loss curve is a known number BEFORE the first 8-GPU run asks for it: observed fake <= ~1e-3, G <= ~3e-3 of the loss scale
+    over the golden's ticks (bounds 3e-3 / 1e-2); the ranks still end with identical weights."""
     import socket
     import subprocess
     import sys
@@ -783,6 +787,10 @@ def test_two_rank_loop_matches_reference_ddp_golden(dev, golden_dir, tmp_path, p
     golden = os.path.join(golden_dir, 'loop2_k15_a1.npz')
     out = str(tmp_path / 'loop2')
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    bf16x = precision.endswith('+bf16-exchange')
+    if bf16x:
+        env['SIDLSG_GRAD_EXCHANGE'] = 'bf16'
+        precision = precision.split('+')[0]
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
            '--master-port', str(port), os.path.join(os.path.dirname(os.path.abspath(__file__)), 'mp_loop_worker.py'), golden, out, precision]
     res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
@@ -797,8 +805,11 @@ def test_two_rank_loop_matches_reference_ddp_golden(dev, golden_dir, tmp_path, p
         rel_f = np.abs(got[0::2] - ref[0::2]) / np.abs(ref[0::2])
         rel_g = np.abs(got[1::2] - ref[1::2]) / np.abs(ref[1::2])
         abs_g = np.abs(got[1::2] - ref[1::2]) / np.abs(ref[0::2])
-        print(f'rank {rank} [{precision}]: product {got} reference {ref} fake rel {rel_f} G rel {rel_g}')
-        if precision == 'fp32':
+        print(f'rank {rank} [{precision}{" + bf16 exchange" if bf16x else ""}]: product {got} reference {ref} fake rel {rel_f} G rel {rel_g}')
+        if bf16x:
+            print(f'bf16 exchange: worst fake rel {rel_f.max():.2e}, worst G error / loss scale {abs_g.max():.2e}')
+            assert rel_f.max() < 3e-3 and abs_g.max() < 1e-2
+        elif precision == 'fp32':
             assert rel_f.max() < 1e-3 and rel_g.max() < 1e-3
         else:
             # bf16: per-tick generator losses of this tiny 2-rank run carry 0.3 ... 6 % rounding noise of THEMSELVES in either
@@ -808,7 +819,7 @@ def test_two_rank_loop_matches_reference_ddp_golden(dev, golden_dir, tmp_path, p
         finals.append(r)
     for key in ('G_conv_in_w', 'fake_conv_in_w', 'G_last_b'):
         assert np.array_equal(finals[0][key], finals[1][key]), f'{key}: ranks diverged'
-        if precision == 'fp32':
+        if precision == 'fp32' and not bf16x:
             d = np.abs(finals[0][key] - g[key])
             assert (d < 0.05 * lr).mean() > 0.98, f'{key}: {(d < 0.05 * lr).mean():.4f} of the weights match the reference DDP run'
 
