@@ -313,15 +313,22 @@ def main():
     dev = torch.device('cuda', local_rank)
     if world > 1:
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        torch.distributed.init_process_group('gloo' if share else 'nccl', init_method='env://')
+        torch.distributed.init_process_group('gloo' if share else 'nccl', init_method='env://', **({} if share else dict(device_id=dev)))
     elif args.force_exchange:
         import socket
         with socket.socket() as sk:
             sk.bind(('127.0.0.1', 0))
             port = sk.getsockname()[1]
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        torch.distributed.init_process_group('nccl', init_method=f'tcp://127.0.0.1:{port}', world_size=1, rank=0)
+        torch.distributed.init_process_group('nccl', init_method=f'tcp://127.0.0.1:{port}', world_size=1, rank=0, device_id=dev)
     assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
+    if torch.distributed.is_initialized():
+        # RCCL creates its communicator at the first collective: do that HERE (main thread, default stream) -- the step's first
+        # collective is issued from inside the backward pass (autograd's device thread, communication stream)
+        warm = torch.ones(1 << 16, device=dev)
+        torch.distributed.all_reduce(warm)
+        torch.cuda.synchronize()
+        del warm
 
     from sid_lsg_amd._lib import lib
     from sid_lsg_amd.distributed import FlatGradReducer

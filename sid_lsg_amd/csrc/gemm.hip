@@ -47,7 +47,6 @@ struct GemmParams {
     int kt_per_split;            // split-K: K-tiles per split (0 = no split)
     int group_m;                 // v3: m-tiles per group of the logical tile order (see gemm_v3_kernel)
     float* ws;                   // split-K: fp32 [splits][M][N] partial-sum slabs
-    unsigned* tickets;           // split-K, in-launch combine (2 splits): one arrival counter per output tile (zero between launches), else null
     const float* wscale;         // fp8-weight path: per-output-channel dequantisation scale [N] (else null)
     // grouped launch (sidlsg_*_g2: two networks of identical shape evaluated on one stacked activation matrix): rows [0, Mg) are
     // contracted with (W, bias), rows [Mg, M) with (W1, bias1).  Mg = 0: ordinary launch.  Mtot: row count of a split-K slab
@@ -737,23 +736,11 @@ static float* g_ws_default = nullptr;
 static long long g_ws_default_bytes = 0;
 static WsSlot g_ws_slots[8] = {};
 static int g_ws_nslots = 0;
-// The last TICKET_BYTES of every workspace are the arrival counters of the in-launch split-K combine (gemm_v3_body): zeroed when the
-// workspace is registered, and every launch that uses them leaves them zero (the last arriver of a tile resets its counter).
-constexpr long long TICKET_BYTES = 64 << 10;       // 16384 output tiles
-struct Ws { float* ptr; long long bytes; unsigned* tickets; };
-static Ws ws_of(float* ptr, long long bytes) {
-    if (!ptr || bytes <= 2 * TICKET_BYTES) return {ptr, bytes, nullptr};
-    return {ptr, bytes - TICKET_BYTES, reinterpret_cast<unsigned*>(reinterpret_cast<char*>(ptr) + bytes - TICKET_BYTES)};
-}
+struct Ws { float* ptr; long long bytes; };
 static Ws ws_for(hipStream_t s) {
     for (int i = 0; i < g_ws_nslots; i++)
-        if (g_ws_slots[i].stream == s) return ws_of(g_ws_slots[i].ptr, g_ws_slots[i].bytes);
-    return ws_of(g_ws_default, g_ws_default_bytes);
-}
-static int ws_clear_tickets(float* ptr, long long bytes) {
-    const Ws w = ws_of(ptr, bytes);
-    if (w.tickets && hipMemset(w.tickets, 0, TICKET_BYTES) != hipSuccess) return SIDLSG_EINVAL;
-    return SIDLSG_OK;
+        if (g_ws_slots[i].stream == s) return {g_ws_slots[i].ptr, g_ws_slots[i].bytes};
+    return {g_ws_default, g_ws_default_bytes};
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1111,50 +1098,7 @@ DEVFN void gemm_v3_body(GemmParams& p) {
                         if (nb + r < p.N) dst[r] = acc[ni][mi][r];
             }
         }
-        if (!p.tickets) return;           // the slabs are combined by gemm_finish_kernel
-        // ---- in-launch combine (round 5; launches of TWO K-splits: the 16 x 16 stage's convs and FF-out at CFG batch 16 -- 158 of the
-        // ~400 split launches of an iteration): the tile's LAST-arriving block sums the slabs and runs the ordinary epilogue, so the
-        // launch needs no gemm_finish_kernel (14 us + a dependent-launch boundary behind 42 MB of freshly written partials).  Hand-off =
-        // the counter form of the guide's release / acquire recipe (cdna_hip_programming.md, split-K in-launch reduction): plain slab stores,
-        // every wave drains its stores, barrier, ONE agent-scope release + restated vmcnt(0) + relaxed ticket by lane 0; the block that draws
-        // nsplit - 1 does ONE agent-scope acquire, barrier, then plain loads.  Placement-independent; the counter is left at zero.
-        // Only for 2 splits: the reducer reads the other blocks' 80 KB slabs at ~100 GB/s (5 us for one, 35 us for seven: there the
-        // chip-wide finish kernel wins).  The slabs are summed in slab order, own slab re-read: bit-identical to gemm_finish_kernel's sum.
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        unsigned* flag = reinterpret_cast<unsigned*>(ring);          // (the one LDS array of this kernel; the K loop is over)
-        const int tile = bid - split * ntile;
-        if (tid == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            const unsigned old = __hip_atomic_fetch_add(p.tickets + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const bool last = old == (unsigned)nsplit - 1u;
-            if (last) {
-                __hip_atomic_store(p.tickets + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            }
-            flag[0] = last ? 1u : 0u;
-        }
-        __syncthreads();
-        if (!flag[0]) return;
-        __syncthreads();                  // everybody has read the flag before the epilogue reuses the ring
-#pragma unroll
-        for (int mi = 0; mi < MT; mi++) {
-            const int m = m0 + wm0 + mi * 16 + li;
-#pragma unroll
-            for (int ni = 0; ni < NT; ni++) {
-                const bool paired = (ni | 1) < NT;
-                const int nb = n0 + wn0 + (paired ? 32 * (ni >> 1) + lg * 8 + (ni & 1) * 4 : 16 * ni + lg * 4);
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (m < p.M && nb + 4 <= p.N) {
-                    const float* src = p.ws + (size_t)m * p.N + nb;
-                    v = *reinterpret_cast<const f32x4*>(src);
-                    for (int sp = 1; sp < nsplit; sp++) v += *reinterpret_cast<const f32x4*>(src + (size_t)sp * p.Mtot * p.N);
-                }
-                acc[ni][mi] = v;
-            }
-        }
-        epilogue_prefetch<NT>(p, pre, wcol0, lg);
+        return;
     }
 #ifndef SIDLSG_EXP_DIRECT_STORE
     if (!(p.flags & (F_OUT_F32 | F_ACCUM)) && (p.N & 7) == 0) {
@@ -1269,7 +1213,7 @@ static int launch_gemm_v3(const GemmParams& p, hipStream_t s) {
     static const int group_env = getenv("SIDLSG_GEMM_GROUP_M") ? atoi(getenv("SIDLSG_GEMM_GROUP_M")) : 4;   // A/B switch (measured: 4 and 8 equivalent, 1 = row-major strips)
     q.group_m = group_env < 1 ? 1 : group_env;
     SIDLSG_LAUNCH((gemm_v3_kernel<MODE>), dim3(tiles * splits), dim3(NTHREADS), lds, s, q);
-    if (p.kt_per_split && !p.tickets) {
+    if (p.kt_per_split) {
         const size_t n4 = ((size_t)p.M * p.N + 3) / 4;
         SIDLSG_LAUNCH(gemm_finish_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, p, splits);
     }
@@ -1908,11 +1852,6 @@ static int dispatch_gemm(const GemmParams& pin, hipStream_t s) {
                 GemmParams q = p;
                 q.kt_per_split = (nk + splits - 1) / splits;
                 q.ws = g_ws;
-                // in-launch combine instead of gemm_finish_kernel (see gemm_v3_body): 2 splits, N % 160 == 0 (whole f32x4 groups), bf16 or fp32
-                // plain outputs alike (the ordinary epilogue runs); $SIDLSG_SPLITK_TICKET = largest split count that takes it (0: never)
-                static const int TICKET_MAX = getenv("SIDLSG_SPLITK_TICKET") ? atoi(getenv("SIDLSG_SPLITK_TICKET")) : 2;
-                const int real_splits = (nk + q.kt_per_split - 1) / q.kt_per_split;
-                if (v3 && w.tickets && real_splits >= 2 && real_splits <= TICKET_MAX && t * 4 <= TICKET_BYTES && !p.Mg) q.tickets = w.tickets;
                 if (v3) return launch_gemm_v3<MODE == 2 ? 0 : MODE>(q, s);
                 return n160 ? launch_gemm<128, 160, MODE>(q, s) : launch_gemm<128, 128, MODE>(q, s);
             }
@@ -2597,7 +2536,7 @@ int sidlsg_debug_wgrad_blocks_per_cu(int which) {
 // Pass NULL/0 to disable split-K.
 int sidlsg_set_workspace(void* ptr, long long bytes) {
     g_ws_default = (float*)ptr; g_ws_default_bytes = ptr ? bytes : 0;
-    return ws_clear_tickets(g_ws_default, g_ws_default_bytes);       // (a blocking memset: set-up time, never inside a capture)
+    return SIDLSG_OK;
 }
 
 // Private scratch for one stream (see WsSlot).  ptr = NULL removes the entry.  At most 4 streams.
@@ -2605,14 +2544,14 @@ int sidlsg_set_stream_workspace(void* stream, void* ptr, long long bytes) {
     hipStream_t s = (hipStream_t)stream;
     for (int i = 0; i < g_ws_nslots; i++)
         if (g_ws_slots[i].stream == s) {
-            if (ptr) { g_ws_slots[i].ptr = (float*)ptr; g_ws_slots[i].bytes = bytes; return ws_clear_tickets((float*)ptr, bytes); }
+            if (ptr) { g_ws_slots[i].ptr = (float*)ptr; g_ws_slots[i].bytes = bytes; }
             else { g_ws_slots[i] = g_ws_slots[--g_ws_nslots]; }
             return SIDLSG_OK;
         }
     if (!ptr) return SIDLSG_OK;
     if (g_ws_nslots >= 8) return SIDLSG_EINVAL;
     g_ws_slots[g_ws_nslots++] = {s, (float*)ptr, bytes};
-    return ws_clear_tickets((float*)ptr, bytes);
+    return SIDLSG_OK;
 }
 
 // Dense GEMM: C[M,N] = act(alpha * A[M,K] W[N,K]^T + bias[N] + rowvec[m/rpb,N] + res[M,N])

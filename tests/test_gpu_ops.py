@@ -65,56 +65,6 @@ def test_gemm(dev, M, N, K):
     close(got, full, 2e-3, 'epilogue')
 
 
-def test_split_k_in_launch_combine(dev, tmp_path):
-    """Round 5: split-K launches of TWO splits combine their slabs inside the launch (gemm_v3_body: arrival ticket per output tile, the
-    last-arriving block sums the slabs and runs the ordinary epilogue) instead of through gemm_finish_kernel.  (a) dense 4096 x 1280 x
-    2560 and a 16 x 16 conv 1280 -> 1280 at batch 16 (256 tiles -> 2 splits) against fp32 references, every epilogue feature; (b) the
-    hand-off under load: 30 repetitions while a second stream keeps the chip busy with other GEMMs must all give the SAME bits (a stale
-    slab read would show up as a differing repetition); (c) bit-equality with the finish-kernel path (child process with
-    SIDLSG_SPLITK_TICKET=0) -- the slabs are summed in the same order."""
-    import subprocess
-    import sys
-    from sid_lsg_amd import ops
-    ops.ensure_workspace(dev)
-    M, N, K = 4096, 1280, 2560
-    a, w = rnd(M, K, seed=1).to(dev), rnd(N, K, seed=2, scale=K ** -0.5).to(dev)
-    bias = torch.randn(N, generator=torch.Generator().manual_seed(3)).to(dev)
-    res = rnd(M, N, seed=4).to(dev)
-    ref = a.float() @ w.float().t()
-    close(ops.gemm(a, w), ref, 1.2e-2, 'plain')
-    close(ops.gemm(a, w, bias=bias, res=res, out_f32=True), ref + bias + res.float(), 2e-3, 'bias + residual, fp32 out')
-    first = ops.gemm(a, w, bias=bias, res=res)
-    side = torch.cuda.Stream()
-    ops.ensure_stream_workspace(side)
-    x2, w2 = rnd(8192, 640, seed=5).to(dev), rnd(640, 640, seed=6, scale=0.04).to(dev)
-    for rep in range(30):
-        with torch.cuda.stream(side):
-            for _ in range(4):
-                ops.gemm(x2, w2)
-        got = ops.gemm(a, w, bias=bias, res=res)
-        assert torch.equal(got, first), f'repetition {rep} differs: a slab was read before it had arrived'
-    torch.cuda.synchronize()
-    # conv of the 16 x 16 stage at CFG batch 16
-    B, H, C = 16, 16, 1280
-    x, wc = rnd(B, H, H, C, seed=7).to(dev), rnd(C, 9 * C, seed=8, scale=(9 * C) ** -0.5).to(dev)
-    bc = torch.randn(C, generator=torch.Generator().manual_seed(9)).to(dev)
-    yc = ops.conv3x3(x, wc, bias=bc)
-    yr = F.conv2d(x.float().permute(0, 3, 1, 2), wc.float().view(C, 3, 3, C).permute(0, 3, 1, 2), bc, padding=1).permute(0, 2, 3, 1)
-    close(yc, yr, 1.2e-2, 'conv 16x16 1280->1280, 2 splits')
-    # (c) the finish-kernel path gives the same bits
-    out = tmp_path / 'ref.pt'
-    code = (f"import sys, torch; sys.path.insert(0, {repr(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))});"
-            "sys.path.insert(0, 'tests'); from test_gpu_ops import rnd; from sid_lsg_amd import ops; from sid_lsg_amd._lib import lib; lib.load();"
-            "dev = torch.device('cuda:0'); ops.ensure_workspace(dev);"
-            f"a, w = rnd({M}, {K}, seed=1).to(dev), rnd({N}, {K}, seed=2, scale={K} ** -0.5).to(dev);"
-            f"bias = torch.randn({N}, generator=torch.Generator().manual_seed(3)).to(dev); res = rnd({M}, {N}, seed=4).to(dev);"
-            f"torch.save(ops.gemm(a, w, bias=bias, res=res).cpu(), {repr(str(out))})")
-    r = subprocess.run([sys.executable, '-c', code], env=dict(os.environ, SIDLSG_SPLITK_TICKET='0'), capture_output=True, text=True, timeout=600,
-                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    assert torch.equal(torch.load(out), first.cpu()), 'in-launch combine and gemm_finish_kernel disagree'
-
-
 def test_gemm_short_k_a_stationary(dev):
     """K = 320 with N % 160 == 0 and M >= 8192 can take the A-stationary kernel (gemm_as_kernel: A panel resident in LDS, W tiles
     streamed as one continuous chunk sequence, counted vmcnt waits).  Production dispatches it from N = 2560 (the measured
