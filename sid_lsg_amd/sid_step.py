@@ -91,13 +91,14 @@ class SiDStep:
         # [psi's CFG batch ; phi's CFG batch] -- every contraction / normalisation launch carries both parameter sets and picks
         # one per block, so the grids of the 16x16 / 8x8 stages, the time-embedding MLP and the 77-token K/V projections are
         # twice as large and the frozen passes issue half the launches (forward AND data-gradient backward).
-        # Measured on one MI355X (profiles/r04_grouped_ab.md): the grouped pass alone is 1.10x faster than the two networks one after
-        # the other (34.5 vs 2 x 19.0 ms at batch_gpu 8), and inside the step it wins where the grids are small -- batch_gpu 1: 134 ->
-        # 113 ms per iteration, batch_gpu 2: 131 -> 113 -- but at batch_gpu 4 / 8 the two-STREAM path is 1 % / 2 % faster: there both
-        # networks' grids fill the chip on their own, and two concurrent streams also hide each other's kernel tails, which one
-        # stream of twice-as-large kernels cannot.  $SIDLSG_GROUPED_FROZEN: 1 = always, 0 = never (two-stream path), auto (default)
-        # = for rounds of at most 2 samples per rank, and never while gradients are exchanged between ranks (there psi's exchange +
-        # optimizer step hide under the teacher's forward, which a joint pass -- psi must be up to date when it starts -- gives up).
+        # Measured on one MI355X.  Round 4 (profiles/r04_grouped_ab.md): the grouped pass alone 1.10x faster than the two networks one
+        # after the other; inside the step a clear win for small rounds (batch_gpu 1: 134 -> 113 ms, 2: 131 -> 113) and a 1-2 % loss at
+        # batch_gpu 4 / 8 against the two-STREAM path.  Round 5, after the attention renumbering / rotated walk and the deferred
+        # reductions (profiles/r05_grouped_ab.txt, five in-session alternations at batch_gpu 8): 209.4 -> 203.5 ms (-2.8 %), and with the
+        # gradient exchange forced (RCCL world 1, `bench.py --force-exchange`) 221.8 -> 210.4 -- the joint pass halves the launches of
+        # 4 F per image, and what it gives up (psi's optimizer step hidden under the teacher's forward) is 4-5 ms.  $SIDLSG_GROUPED_FROZEN:
+        # 1 / auto (default) = grouped wherever both networks allow it (_can_group: same architecture, bf16, no e4m3 copies), 0 = never
+        # (two-stream path).
         self.grouped_mode = os.environ.get('SIDLSG_GROUPED_FROZEN', 'auto').lower()
         self.grouped = self.grouped_mode == '1' and self._can_group()
         # opt-in: optimizer steps issued segment-wise from inside the backward, on their own stream (_SegmentedUpdate).  Same
@@ -120,8 +121,6 @@ class SiDStep:
 
     def _use_grouped(self, batch):
         if self.grouped_mode == '0':
-            return False
-        if self.grouped_mode == 'auto' and (batch > 2 or self.exchange):
             return False
         return self._can_group()
 
