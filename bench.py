@@ -314,7 +314,7 @@ def main():
     if world > 1:
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         torch.distributed.init_process_group('gloo' if share else 'nccl', init_method='env://', **({} if share else dict(device_id=dev)))
-    elif args.force_exchange:
+    elif args.force_exchange and os.environ.get('SIDLSG_BENCH_NO_PG', '0') != '1':      # (NO_PG: diagnosis, with SIDLSG_EXCHANGE_DRYRUN=1)
         import socket
         with socket.socket() as sk:
             sk.bind(('127.0.0.1', 0))
@@ -337,7 +337,9 @@ def main():
     b = args.batch_gpu
     lat = args.resolution // 8
     reducer = FlatGradReducer() if world > 1 else (FlatGradReducer(min_world=1) if args.force_exchange else None)
-    if reducer is not None and not args.graph:
+    if os.environ.get('SIDLSG_BENCH_PG_ONLY', '0') == '1':      # diagnosis: process group alive, no exchange
+        reducer = None
+    if reducer is not None and not args.graph and os.environ.get('SIDLSG_BENCH_COMM_TIMING', '1') != '0':
         reducer.enable_timing()          # exposed-communication figures of the multi-GPU run (`comm` in the JSON line)
     S = setup_step(args.arch, b, args.resolution, args.kappa, dev, rank=rank, world=world, teacher_weights=args.teacher_weights,
                    reducer=reducer)
@@ -372,7 +374,8 @@ def main():
     for it in range(args.warmup, args.warmup + args.steps):
         lf, lg = one_iteration(it)
         if first is None:
-            first = (lf, lg)            # device scalars of the first timed step: read after the timed region
+            first = (lf.clone(), lg.clone())      # device scalars of the first timed step, read after the timed region (copies: the graphed
+                                                  # iteration returns STATIC scalars that the next replay overwrites)
     sync()
     dt = time.time() - t0
     if rank == 0 and loss_ref is not None and first is not None and (world == 1 or args.warmup == 0):

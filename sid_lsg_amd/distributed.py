@@ -54,6 +54,9 @@ def _grad_side_streams(t):
     return ops.grad_streams(t.device)
 
 
+_DRYRUN = os.environ.get('SIDLSG_EXCHANGE_DRYRUN', '0') == '1'      # A/B: FlatGradReducer issues no collective (WRONG for world > 1)
+
+
 def _flush_deferred(t):
     """Gradients are about to be read: run the norm kernels' queued dgamma / dbeta reductions first (ops.flush_deferred)."""
     if t.is_cuda:
@@ -119,6 +122,12 @@ class FlatGradReducer:
         if self.timing and view.is_cuda:
             e0 = torch.cuda.Event(enable_timing=True)
             e0.record()
+        if _DRYRUN:          # measurement only: the whole stream choreography of the exchange without the collective itself
+            if e0 is not None:
+                e1 = torch.cuda.Event(enable_timing=True)
+                e1.record()
+                self._t_msgs.append((view.numel() * view.element_size(), e0, e1))
+            return
         if self.exchange_dtype == torch.bfloat16:
             stage = view.to(torch.bfloat16)
             h = torch.distributed.all_reduce(stage, group=self.group, async_op=True)
