@@ -827,10 +827,12 @@ static int attn_xcd_on(int mode, const AttnParams& p) {
     if (!((mask >> mode) & 1)) return 0;
     return mode == 0 || (mask & 8) || (p.Nq <= 1024 && p.Nk <= 1024);
 }
-// SIDLSG_ATTN_ROT: bit mask of the passes whose blocks start their tile walk at per-block offsets (1 forward, 2 dQ, 4 dK/dV; default 7);
+// SIDLSG_ATTN_ROT: bit mask of the passes whose blocks start their tile walk at per-block offsets (1 forward, 2 dQ, 4 dK/dV; default 6: the
+// backward passes.  The forward never had the lockstep penalty; rotated it is 1-3 % faster alone but fetches 1.57x instead of 1.08x its
+// algorithmic bytes -- profiles/r05_traffic_attn*.json -- and bytes are what the step is short of);
 // only together with the XCD-contiguous numbering (without it an XCD holds 4 blocks of each of 16 heads: nothing walks in lockstep)
 static int attn_rot_on(int mode, const AttnParams& p) {
-    static const int mask = getenv("SIDLSG_ATTN_ROT") ? atoi(getenv("SIDLSG_ATTN_ROT")) : 7;
+    static const int mask = getenv("SIDLSG_ATTN_ROT") ? atoi(getenv("SIDLSG_ATTN_ROT")) : 6;
     return p.xcd && ((mask >> mode) & 1);
 }
 template <bool PS>

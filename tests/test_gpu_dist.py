@@ -140,7 +140,7 @@ def test_bench_under_torchrun_two_ranks(dev):
                      env_extra=dict(SIDLSG_BENCH_SHARE_GPU='1'))
     print({k: out[k] for k in ('value', 'n_gpus', 'ms_per_step', 'config')})
     assert out['n_gpus'] == 2 and out['steps'] == 2 and out['config']['global_batch'] == 4 and out['config']['parallelism'] == 'dp2'
-    assert abs(out['value'] - 2 * 4 / (2 * out['ms_per_step'] / 1e3)) < 1e-6 * out['value']
+    assert abs(out['value'] - 2 * 4 / (2 * out['ms_per_step'] / 1e3)) < 1e-4 * out['value']      # (the line carries 4 decimals)
     assert 'cpu_baseline' not in out                    # rank 0 at N = 1 only
     assert out['roofline']['launches_timed'] > 0 and out['roofline']['isolated_frac'] > 0 and out['teacher_pass']['ms'] > 0
     assert len(json.dumps(out)) < 4096, 'the driver keeps ~8 KB of stdout: the bench line must stay small'
