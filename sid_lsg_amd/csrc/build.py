@@ -6,7 +6,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.dirname(HERE)
-SOURCES = ['gemm.hip', 'norm.hip', 'attention.hip', 'elementwise.hip', 'optim.hip', 'fp32.hip', 'trace.hip', 'defer.hip']
+SOURCES = ['gemm.hip', 'norm.hip', 'attention.hip', 'elementwise.hip', 'optim.hip', 'fp32.hip', 'trace.hip']
 LIB = os.path.join(PKG, 'libsidlsg_hip.so')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-munsafe-fp-atomics', '-Wno-unused-result']
 # Per-file extras.  attention.hip: the softmax works on MFMA results with VALU ops; with the default heuristics the

@@ -131,12 +131,6 @@ template <typename T> DEVFN void zerov8(T* p) {
     stv8<T>(p, z);
 }
 
-// ---- deferred reductions (defer.hip): queue instead of launch; see the file header
-bool sidlsg_defer_pairs(hipStream_t s, const float* part, float* out0, float* out1, int P, size_t pstride, int n, unsigned gx, unsigned gy);
-float* sidlsg_defer_slab_alloc(hipStream_t s, float* base, long long total, long long bytes);
-bool sidlsg_defer_slabs(hipStream_t s, const float* ws, float* dW, size_t n, int splits, int assign);
-void sidlsg_defer_release_workspace(hipStream_t s);
-
 // ---- in-library kernel timing (trace.hip): families of the step's kernels, and the launch macro every family kernel goes through
 enum { SIDLSG_FAM_GEMM = 0, SIDLSG_FAM_CONV, SIDLSG_FAM_ATTN_FWD, SIDLSG_FAM_ATTN_BWD, SIDLSG_FAM_WGRAD, SIDLSG_FAM_CONV_WGRAD,
        SIDLSG_FAM_GN_FWD, SIDLSG_FAM_GN_BWD, SIDLSG_FAM_LN_FWD, SIDLSG_FAM_LN_BWD, SIDLSG_TRACE_FAMILIES };

@@ -1503,7 +1503,6 @@ static int launch_gemm_mx8(const GemmParams& p, hipStream_t s) {
         if (splits < 2) splits = 1;
     }
     if (splits > 1) {
-        sidlsg_defer_release_workspace(s);
         q.kt_per_split = (nk + splits - 1) / splits;
         q.ws = w.ptr;
         splits = (nk + q.kt_per_split - 1) / q.kt_per_split;
@@ -1850,7 +1849,6 @@ static int dispatch_gemm(const GemmParams& pin, hipStream_t s) {
             if (splits > nk / MIN_KT) splits = nk / MIN_KT;
             if (splits > 16) splits = 16;
             if (splits >= 2) {
-                sidlsg_defer_release_workspace(s);      // (pending weight-gradient slabs of this stream are reduced before their space is reused)
                 GemmParams q = p;
                 q.kt_per_split = (nk + splits - 1) / splits;
                 q.ws = g_ws;
@@ -2483,13 +2481,6 @@ static int launch_wgrad(WgradParams p, hipStream_t s) {
             p.ws = g_ws;
         }
     }
-    // deferred reduction (defer.hip): the slabs come from the workspace used as a bump arena and stay there until the batched reduce
-    bool deferred = false;
-    if (splits > 1 && p.ws) {
-        float* piece = sidlsg_defer_slab_alloc(s, g_ws, g_ws_bytes, (long long)splits * nk * 4);
-        if (piece) { p.ws = piece; deferred = true; }
-        else sidlsg_defer_release_workspace(s);          // this launch writes the workspace from its start
-    }
     p.m_per_split = mps;
     p.nsplits = splits;
     if (p.assign && splits > 1 && !p.ws) {          // fp32-atomic fallback (no slab space): the atomics need a zeroed target
@@ -2520,10 +2511,8 @@ static int launch_wgrad(WgradParams p, hipStream_t s) {
         else SIDLSG_LAUNCH((wgrad_v2_kernel<MODE>), dim3(tiles * splits), dim3(NTHREADS), lds, s, p);
     } else
     SIDLSG_LAUNCH((wgrad_bf16_kernel<MODE>), dim3(tiles, splits), dim3(NTHREADS), 0, s, p);
-    if (splits > 1 && p.ws) {
-        if (!(deferred && sidlsg_defer_slabs(s, p.ws, p.dW, (size_t)nk, splits, p.assign)))
-            SIDLSG_LAUNCH(wgrad_reduce_kernel, dim3((unsigned)((nk / 4 + 256) / 256)), dim3(256), 0, s, p.ws, p.dW, (size_t)nk, splits, p.assign);
-    }
+    if (splits > 1 && p.ws)
+        SIDLSG_LAUNCH(wgrad_reduce_kernel, dim3((unsigned)((nk / 4 + 256) / 256)), dim3(256), 0, s, p.ws, p.dW, (size_t)nk, splits, p.assign);
     return sidlsg_last_error();
 }
 

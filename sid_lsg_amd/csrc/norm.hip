@@ -16,7 +16,10 @@
 //   colsum_reduce: dgamma/dbeta (+=) from the per-channel partials
 #include "common.h"
 #include <stdlib.h>
+#include <map>
+#include <mutex>
 #include <type_traits>
+#include <vector>
 
 constexpr int GN_MAX_C = 2560;
 #ifndef SIDLSG_GN_U
@@ -306,12 +309,79 @@ static dim3 reduce_grid(int n, int P) {
     return dim3((n + 255) / 256, split);
 }
 
-// ---- deferred parameter-gradient reductions (round 5): csrc/defer.hip.  With deferral on for the stream the reduction is queued
-// (sidlsg_defer_pairs) and runs later as part of ONE batched launch; else it is launched here.
+// ---- deferred parameter-gradient reductions (round 5) --------------------------------------------------------------------------
+// A trainable backward pass holds 48 LayerNorm + ~32 two-kernel GroupNorm layers, each ending in a colsum_reduce2 launch of 1-10
+// blocks' worth of work: ~160 launches and 2.2 ms of kernel time per iteration on the critical stream, for sums nobody reads before
+// the end of the backward (or the next gradient-exchange marker).  With deferral switched on for a stream (sidlsg_defer_reductions),
+// the norm backward entry points QUEUE the reduction (pointers + sizes, host side) instead of launching it, and
+// sidlsg_flush_reductions(stream) runs everything queued for that stream as ONE launch: the job table travels as a by-value kernel
+// argument (no device table, no copies: graph-capturable like every other launch of this library).  Same block decomposition and
+// the same arithmetic per job as colsum_reduce2_kernel.  The caller keeps the partial-sum workspaces alive until the flush.
+struct PairJob { const float* part; float* out0; float* out1; unsigned n, P, pstride, blk0, gx, gy; };      // 48 bytes
+constexpr int PAIR_JOBS = 72;                                                                              // 72 x 48 = 3456 bytes of kernarg
+struct PairBatch { int njobs, pad; PairJob j[PAIR_JOBS]; };
+
+__global__ __launch_bounds__(256) void colsum_reduce2_batched_kernel(PairBatch b) {
+    int lo = 0, hi = b.njobs - 1;                       // last job whose first block is <= blockIdx.x
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (b.j[mid].blk0 <= blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const PairJob& q = b.j[lo];
+    const unsigned local = blockIdx.x - q.blk0;
+    const unsigned bx = local % q.gx, by = local / q.gx;
+    const unsigned i = bx * 256 + threadIdx.x;
+    if (i >= q.n) return;
+    const unsigned per = (q.P + q.gy - 1) / q.gy;
+    const unsigned p0 = by * per, p1 = min(q.P, p0 + per);
+    float t0 = 0.f, t1 = 0.f;
+    for (unsigned p = p0; p < p1; p++) {
+        const float2 v = *reinterpret_cast<const float2*>(q.part + (size_t)p * q.pstride + (size_t)i * 2);
+        t0 += v.x; t1 += v.y;
+    }
+    if (p1 > p0) { unsafeAtomicAdd(q.out0 + i, t0); unsafeAtomicAdd(q.out1 + i, t1); }
+}
+
+namespace {
+struct DeferState {
+    std::mutex mu;
+    struct Q { bool accepting = false; std::vector<PairJob> jobs; };
+    std::map<hipStream_t, Q> q;      // streams that have used deferral -> whether calls queue right now, and their queued jobs
+};
+DeferState& dst() { static DeferState s; return s; }
+}  // namespace
+
+static int flush_pairs_locked(hipStream_t s, std::vector<PairJob>& v) {
+    int done = 0;
+    for (size_t o = 0; o < v.size(); o += PAIR_JOBS) {
+        PairBatch b{};
+        b.njobs = (int)std::min<size_t>(PAIR_JOBS, v.size() - o);
+        unsigned blocks = 0;
+        for (int k = 0; k < b.njobs; k++) {
+            b.j[k] = v[o + k];
+            b.j[k].blk0 = blocks;
+            blocks += b.j[k].gx * b.j[k].gy;
+        }
+        hipLaunchKernelGGL(colsum_reduce2_batched_kernel, dim3(blocks), dim3(256), 0, s, b);
+        done += b.njobs;
+    }
+    v.clear();
+    return done;
+}
+
+// true: queued (the caller must not launch the reduction itself)
+static bool defer_pairs(hipStream_t s, const float* part, float* out0, float* out1, int P, size_t pstride, int n) {
+    DeferState& d = dst();
+    std::lock_guard<std::mutex> lk(d.mu);
+    auto it = d.q.find(s);
+    if (it == d.q.end() || !it->second.accepting) return false;
+    const dim3 g = reduce_grid(n, P);
+    it->second.jobs.push_back(PairJob{part, out0, out1, (unsigned)n, (unsigned)P, (unsigned)pstride, 0u, g.x, g.y});
+    return true;
+}
 #define SIDLSG_REDUCE_PAIRS(s, ws, o0, o1, P, C)                                                                                   \
     do {                                                                                                                            \
-        const dim3 rg_ = reduce_grid(C, P);                                                                                         \
-        if (!sidlsg_defer_pairs(s, ws, o0, o1, P, (size_t)(C) * 2, C, rg_.x, rg_.y))                                                \
+        if (!defer_pairs(s, ws, o0, o1, P, (size_t)(C) * 2, C))                                                                     \
             SIDLSG_LAUNCH(colsum_reduce2_kernel, reduce_grid(C, P), dim3(256), 0, s, ws, o0, o1, P, (size_t)(C) * 2, C);            \
     } while (0)
 
@@ -1118,6 +1188,43 @@ static int layernorm_bwd_t(const void* x, const void* dy, const float* stats, co
     }
     return sidlsg_last_error();
 }
+
+extern "C" {
+
+// Deferred parameter-gradient reductions of the normalisation backward kernels (see colsum_reduce2_batched_kernel).
+// on = 1: from now on sidlsg_layernorm_bwd* / sidlsg_groupnorm_bwd* called with `stream` queue their dgamma / dbeta reduction instead
+// of launching it; the partial sums stay in the caller's `ws` (which must stay allocated and untouched) until
+// sidlsg_flush_reductions(stream) launches all queued reductions as one kernel on that stream.  on = 2: later calls launch their own
+// reduction again, what is queued stays queued (the host wrapper brackets exactly ITS calls with 1 / 2, so direct users of the C ABI
+// on the same stream are never deferred behind their back).  on = 0: flush and forget the stream.  Returns the number of reductions flushed (>= 0) or a negative error.
+int sidlsg_defer_reductions(void* stream, int on) {
+    DeferState& d = dst();
+    std::lock_guard<std::mutex> lk(d.mu);
+    hipStream_t s = (hipStream_t)stream;
+    if (on == 1) { d.q[s].accepting = true; return 0; }
+    auto it = d.q.find(s);
+    if (it == d.q.end()) return 0;
+    if (on == 2) { it->second.accepting = false; return 0; }          // stop queuing, keep what is queued
+    const int n = flush_pairs_locked(s, it->second.jobs);
+    d.q.erase(it);
+    return sidlsg_last_error() == SIDLSG_OK ? n : -1;
+}
+int sidlsg_flush_reductions(void* stream) {
+    DeferState& d = dst();
+    std::lock_guard<std::mutex> lk(d.mu);
+    auto it = d.q.find((hipStream_t)stream);
+    if (it == d.q.end() || it->second.jobs.empty()) return 0;
+    const int n = flush_pairs_locked((hipStream_t)stream, it->second.jobs);
+    return sidlsg_last_error() == SIDLSG_OK ? n : -1;
+}
+int sidlsg_pending_reductions(void* stream) {
+    DeferState& d = dst();
+    std::lock_guard<std::mutex> lk(d.mu);
+    auto it = d.q.find((hipStream_t)stream);
+    return it == d.q.end() ? -1 : (int)it->second.jobs.size();
+}
+
+}  // extern "C"
 
 extern "C" {
 

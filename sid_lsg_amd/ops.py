@@ -142,8 +142,7 @@ def _wgrad_stream_list(device):
     if key not in _wgrad_streams:
         lst = [torch.cuda.Stream(device=device) for _ in range(_WGRAD_NSTREAMS)]
         for st in lst:
-            # (with deferred reductions the workspace is the slab ARENA of a whole backward segment: 2 GiB = ~40-50 weight gradients per flush)
-            ensure_stream_workspace(st, nbytes=(256 << 20) // _WGRAD_NSTREAMS if _WGRAD_NSTREAMS > 1 else ((2 << 30) if _DEFER else (256 << 20)))
+            ensure_stream_workspace(st, nbytes=(256 << 20) // _WGRAD_NSTREAMS if _WGRAD_NSTREAMS > 1 else 256 << 20)
         _wgrad_streams[key] = lst
     return _wgrad_streams[key]
 
@@ -171,18 +170,15 @@ class _OnWgradStream:
 
     def __enter__(self):
         if not self.on:
-            self.dh = _defer_begin(self.tensors[0].device) if self.tensors[0].dtype == BF16 else None
             return self
         dev = self.tensors[0].device
         self.side = wgrad_stream(dev)
         self.side.wait_stream(torch.cuda.current_stream(dev))
         self.cm = torch.cuda.stream(self.side)
         self.cm.__enter__()
-        self.dh = _defer_begin(dev)              # the slab reductions of the launches inside are queued (csrc/defer.hip)
         return self
 
     def __exit__(self, *exc):
-        _defer_end(self.dh)
         if not self.on:
             return False
         self.cm.__exit__(*exc)
@@ -209,21 +205,19 @@ class _OnWgradStream:
         return False
 
 
-# ---- deferred reductions (csrc/defer.hip) -------------------------------------------------------------------------------------
-# The "fold the partial sums" launches that end a LayerNorm / GroupNorm backward (dgamma / dbeta) and a pixel-split weight gradient
-# (dW from per-split slabs) -- ~80 and ~170 per trainable backward pass, each a tiny launch with a dependent-launch boundary -- are
-# queued by the library and run as ONE launch per stream and kind when the backward pass ends (autograd engine callback), when a
-# gradient-exchange marker fires (_GradReady) or when somebody is about to read gradients (flush_deferred(): the fused optimizer and
-# the reducer call it).  The norm kernels' partial-sum workspaces are kept alive here until then; the weight-gradient slabs live in
-# the stream's split workspace, used as a bump arena (2 GiB on the weight-gradient stream).  SIDLSG_DEFER_REDUCE=0: one reduction
-# launch per layer as before (A/B, tests).
+# ---- deferred parameter-gradient reductions of the norm backward kernels ---------------------------------------------------
+# (csrc/norm.hip "deferred parameter-gradient reductions"): the dgamma / dbeta reductions of a backward pass -- ~80 per trainable
+# network and pass, each a tiny launch on the critical stream -- are queued by the library and run as ONE launch per stream when the
+# backward pass ends (autograd engine callback), when a gradient-exchange marker fires (_GradReady) or when somebody is about to
+# read gradients (flush_deferred(): the fused optimizer and the reducer call it).  The partial-sum workspaces are kept alive here
+# until then.  SIDLSG_DEFER_REDUCE=0: one reduction launch per layer as before (A/B, tests).
 _DEFER = os.environ.get('SIDLSG_DEFER_REDUCE', '1') != '0'
-_defer_streams = {}          # stream handle -> [torch stream, [workspaces kept alive]]
+_defer_streams = {}          # stream handle -> [torch stream, [workspaces]]
 _defer_armed = set()
 
 
 def _defer_begin(device):
-    """Before a launch whose final reduction may be deferred: deferral accepting on the current stream."""
+    """Before a norm-backward launch that reduces parameter gradients: deferral on for the current stream."""
     if not _DEFER:
         return None
     st = torch.cuda.current_stream(device)
@@ -234,13 +228,12 @@ def _defer_begin(device):
     return h
 
 
-def _defer_end(h, ws=None):
+def _defer_end(h, ws):
     """After the launch: keep its partial sums alive; flush at the end of this backward pass (right away outside one)."""
     if h is None:
         return
     lib.sidlsg_defer_reductions.raw(h, 2)        # only the call in between was deferred (direct users of the C ABI never are)
-    if ws is not None:
-        _defer_streams[h][1].append(ws)
+    _defer_streams[h][1].append(ws)
     tid = torch._C._current_graph_task_id()
     if tid < 0:
         flush_deferred()
@@ -254,19 +247,17 @@ def _defer_end(h, ws=None):
         torch.autograd.Variable._execution_engine.queue_callback(done)
 
 
-def flush_deferred(join=True):
-    """Launch every queued reduction (one kernel per stream and kind that has any).  join: order the CURRENT stream after them (what a
-    reader of gradients on the current stream needs); a gradient-exchange marker passes False -- FlatGradReducer.start_range orders the
-    communication stream after the compute and weight-gradient streams itself, the compute stream must not wait for the latter."""
+def flush_deferred():
+    """Launch every queued reduction (one kernel per stream that has any) and order the current stream after them."""
     for h, (st, keep) in _defer_streams.items():
-        n = lib.sidlsg_flush_reductions.raw(h)
-        if n < 0:
+        if not keep:
+            continue
+        if lib.sidlsg_flush_reductions.raw(h) < 0:
             raise RuntimeError('sidlsg_flush_reductions failed')
         keep.clear()
-        if n and join:
-            cur = torch.cuda.current_stream(st.device)
-            if cur.cuda_stream != h:
-                cur.wait_stream(st)
+        cur = torch.cuda.current_stream(st.device)
+        if cur.cuda_stream != h:
+            cur.wait_stream(st)
 
 
 def ensure_stream_workspace(stream, nbytes=256 << 20):
@@ -1477,7 +1468,7 @@ class _GradReady(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        flush_deferred(join=False)        # queued reductions belong to the segment that is about to be declared final
+        flush_deferred()        # queued dgamma / dbeta reductions belong to the segment that is about to be declared final
         ctx.cb()
         return g, None
 
