@@ -20,7 +20,9 @@ import os
 import sys
 import time
 
-import torch
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # dmabuf IPC for RCCL on this platform: must be set before the HIP runtime starts
+
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)

@@ -20,12 +20,14 @@ import json
 import os
 import re
 
-import click
-import torch
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # dmabuf IPC for RCCL on this platform: before the HIP runtime starts
 
-from sid_lsg_amd import distributed as dist
-from sid_lsg_amd.dnnlib_util import EasyDict, construct_class_by_name
-from sid_lsg_amd.training_loop import training_loop
+import click  # noqa: E402
+import torch  # noqa: E402
+
+from sid_lsg_amd import distributed as dist  # noqa: E402
+from sid_lsg_amd.dnnlib_util import EasyDict, construct_class_by_name  # noqa: E402
+from sid_lsg_amd.training_loop import training_loop  # noqa: E402
 
 
 def _csv(_ctx, _param, value):
