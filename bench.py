@@ -51,15 +51,19 @@ class DispatchTrace:
     durations are the begin -> end intervals `rocprofv3 --kernel-trace` reports for the same command -- not event records around a
     launch, which add barrier packets and over-state ~50 us kernels under three concurrent streams by ~1.5x (round 3)."""
     FAM = dict(gemm=0, conv=1, attn=2, attn_bwd=3, wgrad=4, conv_wgrad=5, gn=6, gn_bwd=7, ln=8, ln_bwd=9)
-    STRIDE = dict(gemm=7, conv=5, attn=3, attn_bwd=3, wgrad=5, conv_wgrad=3, gn=5, gn_bwd=5, ln=7, ln_bwd=7)
+    # every STRIDE-th call of a family is timed (primes: coprime to the per-layer launch pattern, every shape gets sampled).  Round 5: x4 --
+    # sampling every 3rd-7th call cost the timed region 2.7 ms per iteration (1.3 %; hipExtLaunchKernelGGL + two events per kernel), every
+    # 11th-29th 0.9 ms, with 460 dense-GEMM launches still timed in 12 iterations (tools/experiments/r5_call19.sh)
+    STRIDE = dict(gemm=29, conv=19, attn=11, attn_bwd=11, wgrad=19, conv_wgrad=11, gn=19, gn_bwd=19, ln=29, ln_bwd=29)
 
     def __init__(self, lib):
         self.lib = lib
 
     def start(self):
         self.lib.sidlsg_trace_enable(1 << 17)
+        mul = int(os.environ.get('SIDLSG_BENCH_TRACE_STRIDE_MUL', '1'))      # (A/B: cost of the sampling itself)
         for k, f in self.FAM.items():
-            self.lib.sidlsg_trace_set_stride(f, self.STRIDE[k])
+            self.lib.sidlsg_trace_set_stride(f, self.STRIDE[k] * mul)
 
     def stop(self):
         torch.cuda.synchronize()
