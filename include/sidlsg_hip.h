@@ -87,6 +87,11 @@ int sidlsg_wgrad_bf16(const void* dY, int ldy, const void* A, int lda, float* dW
  * summation order as the accumulating entry points on a zeroed dW: bit-identical results. */
 int sidlsg_wgrad_assign_bf16(const void* dY, int ldy, const void* A, int lda, float* dW, float* dBias, int M, int N, int K,
                              void* stream);
+/* Several dense weight gradients as ONE launch + one slab-reduction launch (round 5: the C x C projections of a transformer block each
+ * need ~56 pixel splits to fill the chip alone; grouped, the group fills it with ~6 each).  jobs: HOST array of njobs <= 8 records of
+ * 64 bytes  { const void* dY; const void* A; float* dW; float* dBias; int ldy, lda, M, N, K, assign; int pad[2]; }  with the meaning
+ * of sidlsg_wgrad_bf16 (assign = 0) / sidlsg_wgrad_assign_bf16 (assign = 1) per record; N, K, ldy, lda % 8 == 0, 16-byte aligned operands. */
+int sidlsg_wgrad_group_bf16(const void* jobs, int njobs, void* stream);
 int sidlsg_conv3x3_wgrad_assign_bf16(const void* dY, int ldy, const void* X, int ldx, float* dW, float* dBias, int B, int H, int Wd,
                                      int Cin, int Cout, int stride, int ups, void* stream);
 int sidlsg_debug_wgrad_blocks_per_cu(int which); /* host diagnostic: resident blocks per CU of the weight-gradient kernels (0: 128x128, 1: 160x128, 2: 160x160 tiles) */

@@ -1900,6 +1900,7 @@ struct WgradParams {
     float* dB;        // optional: dB[n] += sum_m dY[m][n] (bias gradient), produced by the k-tile-0 blocks
     int slow_gather;  // conv: 1 = per-stage recomputation of the gather offsets also where the constant-advance path applies (A/B switch)
     int assign;       // dW = instead of dW +=: the caller knows dW holds nothing to keep (sidlsg_*wgrad_assign_bf16) -- no read of dW
+    int bid0;         // grouped launch (wgrad_v2g_kernel): index of this job's first block (a multiple of 8); 0 otherwise
 };
 
 DEVFN int wg_swz(int row) { return (row & 3) | (((row >> 3) & 1) << 2); }
@@ -2087,7 +2088,9 @@ template <int TN> DEVFN int wg_yswz(int row) { return TN == 128 ? wg_swz(row) : 
 // TK = k (X column) extent of the tile: 128, or (dense only, round 4) 160 -- with N and K multiples of 160 a 160 x 160 tile wastes no
 // MFMA work on padding (320 = 2 x 160 instead of 3 x 128) and the operands are re-read 2 + 2 instead of 3 + 3 times per split
 // (L2 -> LDS bytes -44 % at 320 x 320); the X tile is then staged exactly like the dY tile (same chunk grid, same swizzle).
-template <int MODE, int TN, int TK, bool CF = false>      // CF: conv with constant-advance gather offsets (see fastc below; the host checks the conditions)
+// (TAG: hipcc 7.2's host pass rejects the SECOND kernel that instantiates one specialisation of this template -- "no matching function,
+// substitution failure", as it did for attn_q_kernel -- so the grouped kernel asks for its own, TAG = 1)
+template <int MODE, int TN, int TK, bool CF = false, int TAG = 0>      // CF: conv with constant-advance gather offsets (see fastc below; the host checks the conditions)
 DEVFN void wgrad_v2_body(const WgradParams& p) {
     static_assert(TK == WG_T || (TK == 160 && MODE == 0), "160-wide k tiles: dense operands only");
     constexpr int KI = TK / 32;             // 16-column X fragments per wave (wave = TN/2 x TK/2 of the tile)
@@ -2101,6 +2104,7 @@ DEVFN void wgrad_v2_body(const WgradParams& p) {
     const int tiles_k = (p.K + TK - 1) / TK;
     const int tiles = ((p.N + TN - 1) / TN) * tiles_k;
     int bid = blockIdx.x;
+    bid -= p.bid0;                           // (bid0: first block of this job in a grouped launch, else 0)
     {
         const int nblk = tiles * p.nsplits;
         const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
@@ -2395,6 +2399,52 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad_v2s_kernel(WgradParams p) {
 __global__ __launch_bounds__(NTHREADS, 2) void wgrad_v2f_kernel(WgradParams p) { wgrad_v2_body<1, 128, WG_T, true>(p); }     // conv, constant-advance gather
 __global__ __launch_bounds__(NTHREADS, 2) void wgrad_v2wf_kernel(WgradParams p) { wgrad_v2_body<1, 160, WG_T, true>(p); }    // the same with 160-wide n tiles
 
+// ---- grouped dense weight gradients (round 5) --------------------------------------------------------------------------------------
+// The square projections of a transformer block (to_out of both attentions, the cross-attention's to_q, proj_in / proj_out: C x C, plus the
+// 77-token k|v projection) each need ~56 pixel splits to fill the chip on their own (9 tiles of 128 x 128 at C = 320): per layer 31 MB of
+// slabs, a reduce launch, and 49 + 16 us for 13 GFLOP.  wgrad_v2g_kernel runs up to WG_GROUP such layers in ONE grid -- every job keeps its
+// own operands, shapes and split count (WgradParams by value in the kernel argument), a block finds its job from its index -- so that the
+// group as a whole fills the chip with ~1/5 of the splits per layer, and wgrad_reduce_g_kernel folds all its slabs in one launch.
+constexpr int WG_GROUP = 8;
+struct WgradGroup { int njobs; int blk0[WG_GROUP + 1]; WgradParams j[WG_GROUP]; };      // blk0: first block of each job (multiples of 8)
+__global__ __launch_bounds__(NTHREADS, 2) void wgrad_v2g_kernel(WgradGroup g) {
+    const int bx = blockIdx.x;
+    int j = 0;
+#pragma unroll
+    for (int i = 1; i < WG_GROUP; i++)
+        if (i < g.njobs && bx >= g.blk0[i]) j = i;
+    const WgradParams& p = g.j[j];          // (p.bid0 == g.blk0[j], set by the host)
+    const int local = bx - g.blk0[j];
+    const int nblk = (((p.N + 127) / 128) * ((p.K + WG_T - 1) / WG_T)) * p.nsplits;
+    if (local >= nblk) return;              // (the job's range is padded to a multiple of 8 blocks: XCD = block index mod 8 inside a job too)
+    wgrad_v2_body<0, 128, WG_T, false, 1>(p);
+}
+struct WgradReduceGroup { int njobs; unsigned blk0[WG_GROUP + 1]; const float* ws[WG_GROUP]; float* dW[WG_GROUP]; unsigned n4[WG_GROUP]; int splits[WG_GROUP], assign[WG_GROUP]; };
+__global__ __launch_bounds__(256) void wgrad_reduce_g_kernel(WgradReduceGroup g) {
+    int j = 0;
+#pragma unroll
+    for (int i = 1; i < WG_GROUP; i++)
+        if (i < g.njobs && blockIdx.x >= g.blk0[i]) j = i;
+    const unsigned i4 = (blockIdx.x - g.blk0[j]) * 256 + threadIdx.x;
+    if (i4 >= g.n4[j]) return;
+    const size_t i = (size_t)i4 * 4, n = (size_t)g.n4[j] * 4;
+    const float* ws = g.ws[j];
+    float* dW = g.dW[j];
+    const int splits = g.splits[j];
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (!g.assign[j]) v = *reinterpret_cast<const f32x4*>(dW + i);
+    int sidx = 0;
+    for (; sidx + 3 < splits; sidx += 4) {          // wgrad_reduce_kernel's order: bit-identical sums
+        const f32x4 a = *reinterpret_cast<const f32x4*>(ws + (size_t)sidx * n + i);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(ws + (size_t)(sidx + 1) * n + i);
+        const f32x4 c = *reinterpret_cast<const f32x4*>(ws + (size_t)(sidx + 2) * n + i);
+        const f32x4 d = *reinterpret_cast<const f32x4*>(ws + (size_t)(sidx + 3) * n + i);
+        v += a; v += b; v += c; v += d;
+    }
+    for (; sidx < splits; sidx++) v += *reinterpret_cast<const f32x4*>(ws + (size_t)sidx * n + i);
+    *reinterpret_cast<f32x4*>(dW + i) = v;
+}
+
 // dW[i] += sum_s slab[s][i]  (assign: dW[i] = sum_s slab[s][i], summed in the same order from 0 -- bit-identical to the sum onto a zeroed dW)
 __global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dW, size_t n, int splits, int assign) {
     const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
@@ -2517,6 +2567,67 @@ static int launch_wgrad(WgradParams p, hipStream_t s) {
 }
 
 static bool fits31(unsigned long long bytes) { return bytes < 0x7FFFFFFFull; }
+
+// Host side of the grouped dense weight gradient.  Every job must be one the 128 x 128 direct-to-LDS kernel takes (aligned operands);
+// the split count is chosen for the GROUP: all jobs together should put ~512 blocks on the chip (whole rounds, like launch_wgrad's
+// model), each job splitting its pixel range in proportion to its own row count.
+static int launch_wgrad_group(WgradParams* jobs, int njobs, hipStream_t s) {
+    if (njobs < 1 || njobs > WG_GROUP) return SIDLSG_EINVAL;
+    long long tiles[WG_GROUP], total_tiles = 0;
+    for (int i = 0; i < njobs; i++) {
+        const WgradParams& p = jobs[i];
+        const bool aligned = !(p.N & 7) && !(p.K & 7) && !(p.ldy & 7) && !(p.lda & 7) && !(((uintptr_t)p.dY | (uintptr_t)p.A) & 15);
+        if (!aligned) return SIDLSG_EINVAL;
+        tiles[i] = (long long)((p.N + 127) / 128) * ((p.K + WG_T - 1) / WG_T);
+        total_tiles += tiles[i];
+    }
+    const Ws wsl = ws_for(s);
+    static const int slots = getenv("SIDLSG_WGRAD_SLOTS") ? atoi(getenv("SIDLSG_WGRAD_SLOTS")) : 512;
+    int want = (int)std::max<long long>(1, slots / std::max<long long>(1, total_tiles));        // splits per job when all rows counts are equal
+    WgradGroup g{};
+    WgradReduceGroup rg{};
+    g.njobs = njobs;
+    int blocks = 0, rjobs = 0;
+    unsigned rblocks = 0;
+    long long ws_used = 0;
+    for (int i = 0; i < njobs; i++) {
+        WgradParams p = jobs[i];
+        const int max_splits = (p.M + 4 * WG_MB - 1) / (4 * WG_MB);
+        int splits = std::min(std::min(want, 64), std::max(1, max_splits));
+        int mps = (p.M + splits - 1) / splits;
+        mps = (mps + WG_MB - 1) / WG_MB * WG_MB;
+        splits = (p.M + mps - 1) / mps;
+        const long long nk = (long long)p.N * p.K;
+        p.ws = nullptr;
+        if (splits > 1) {
+            if (!wsl.ptr || ws_used + (long long)splits * nk * 4 > wsl.bytes || (nk & 3)) { splits = 1; mps = (p.M + WG_MB - 1) / WG_MB * WG_MB; }
+            else { p.ws = reinterpret_cast<float*>(reinterpret_cast<char*>(wsl.ptr) + ws_used); ws_used += ((long long)splits * nk * 4 + 255) / 256 * 256; }
+        }
+        p.m_per_split = mps;
+        p.nsplits = splits;
+        g.blk0[i] = blocks;
+        p.bid0 = blocks;
+        g.j[i] = p;
+        blocks += (int)((tiles[i] * splits + 7) / 8 * 8);
+        if (splits > 1) {
+            rg.blk0[rjobs] = rblocks; rg.ws[rjobs] = p.ws; rg.dW[rjobs] = p.dW; rg.n4[rjobs] = (unsigned)(nk / 4);
+            rg.splits[rjobs] = splits; rg.assign[rjobs] = p.assign;
+            rblocks += (unsigned)((nk / 4 + 255) / 256);
+            rjobs++;
+        }
+    }
+    g.blk0[njobs] = blocks;
+    rg.njobs = rjobs; rg.blk0[rjobs] = rblocks;
+    const size_t lds = (size_t)2 * WG_MB * (128 + WG_T) * sizeof(bf16);
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_v2g_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * WG_MB * (128 + WG_T) * 2);
+        attr_done = true;
+    }
+    SIDLSG_LAUNCH(wgrad_v2g_kernel, dim3(blocks), dim3(NTHREADS), lds, s, g);
+    if (rjobs) SIDLSG_LAUNCH(wgrad_reduce_g_kernel, dim3(rblocks), dim3(256), 0, s, rg);
+    return sidlsg_last_error();
+}
 
 extern "C" {
 
@@ -2706,6 +2817,34 @@ int sidlsg_wgrad_bf16(const void* dY, int ldy, const void* A, int lda, float* dW
 // Same summation order as the accumulating entry point on a zeroed dW: bit-identical results.
 int sidlsg_wgrad_assign_bf16(const void* dY, int ldy, const void* A, int lda, float* dW, float* dBias, int M, int N, int K, void* stream) {
     return wgrad_dense_impl(dY, ldy, A, lda, dW, dBias, M, N, K, 1, stream);
+}
+
+// Several dense weight gradients as ONE launch (+ one slab-reduction launch): jobs = host array of njobs <= 8 records
+//   { const void* dY; const void* A; float* dW; float* dBias; int ldy, lda, M, N, K, assign; int pad[2]; }      (64 bytes each)
+// with the meaning of sidlsg_wgrad_bf16 / _assign_bf16 per record.  Every job must satisfy the alignment of the direct-to-LDS kernel
+// (N, K, ldy, lda multiples of 8, 16-byte aligned operands), else EINVAL and nothing is launched.  Bit-identical per job to the single
+// entry points wherever both choose the same split count; otherwise the fp32 summation order over pixels differs.
+struct sidlsg_wgrad_job { const void* dY; const void* A; float* dW; float* dBias; int ldy, lda, M, N, K, assign; int pad[2]; };
+int sidlsg_wgrad_group_bf16(const void* jobs, int njobs, void* stream) {
+    if (!jobs || njobs < 1 || njobs > WG_GROUP) return SIDLSG_EINVAL;
+    const sidlsg_wgrad_job* in = (const sidlsg_wgrad_job*)jobs;
+    WgradParams ps[WG_GROUP];
+    double flop = 0, bytes = 0;
+    for (int i = 0; i < njobs; i++) {
+        const sidlsg_wgrad_job& q = in[i];
+        if (q.M <= 0 || q.N <= 0 || q.K <= 0 || !q.dY || !q.A || !q.dW) return SIDLSG_EINVAL;
+        WgradParams p{};
+        p.dY = (const bf16*)q.dY; p.A = (const bf16*)q.A; p.dW = q.dW; p.dB = q.dBias; p.M = q.M; p.N = q.N; p.K = q.K; p.ldy = q.ldy; p.lda = q.lda;
+        p.assign = q.assign;
+        const unsigned long long ab = ((unsigned long long)(q.M - 1) * q.lda + q.K) * 2ull, yb = ((unsigned long long)(q.M - 1) * q.ldy + q.N) * 2ull;
+        if (!fits31(ab) || !fits31(yb)) return SIDLSG_EINVAL;
+        p.a_bytes = (unsigned)ab; p.y_bytes = (unsigned)yb;
+        ps[i] = p;
+        flop += 2.0 * q.M * (double)q.N * q.K;
+        bytes += 2.0 * ((double)q.M * q.N + (double)q.M * q.K) + (q.assign ? 4.0 : 8.0) * q.N * q.K;
+    }
+    SidlsgTraceScope ts(SIDLSG_FAM_WGRAD, flop, bytes);
+    return launch_wgrad_group(ps, njobs, (hipStream_t)stream);
 }
 
 // dW[Cout][3][3][Cin] += conv3x3 weight gradient (same geometry arguments as sidlsg_conv3x3_bf16)

@@ -12,6 +12,7 @@ contiguous; parameters are fp32
 weight/bias gradients are ACCUMULATED IN PLACE by the kernels (atomics / +=) and the autograd
 functions return None for them, so no per-parameter gradient tensors are ever materialised.
 """
+import ctypes
 import os
 
 import torch
@@ -234,21 +235,15 @@ def _defer_end(h, ws):
         return
     lib.sidlsg_defer_reductions.raw(h, 2)        # only the call in between was deferred (direct users of the C ABI never are)
     _defer_streams[h][1].append(ws)
-    tid = torch._C._current_graph_task_id()
-    if tid < 0:
+    if torch._C._current_graph_task_id() < 0:
         flush_deferred()
-    elif tid not in _defer_armed:
-        _defer_armed.clear()             # ids never repeat: anything left is from a pass that did not finish
-        _defer_armed.add(tid)
-
-        def done():
-            _defer_armed.discard(tid)
-            flush_deferred()
-        torch.autograd.Variable._execution_engine.queue_callback(done)
+    else:
+        _arm_end_of_backward_flush()
 
 
 def flush_deferred():
     """Launch every queued reduction (one kernel per stream that has any) and order the current stream after them."""
+    flush_wgrad_queues()
     for h, (st, keep) in _defer_streams.items():
         if not keep:
             continue
@@ -258,6 +253,75 @@ def flush_deferred():
         cur = torch.cuda.current_stream(st.device)
         if cur.cuda_stream != h:
             cur.wait_stream(st)
+
+
+# ---- grouped dense weight gradients (csrc/gemm.hip "grouped dense weight gradients") -----------------------------------------------
+# The C x C projections of a transformer block (to_out of both attentions, the cross-attention's to_q, proj_in / proj_out) and its
+# 77-token k|v projection each need ~56 pixel splits to fill the chip alone.  Their weight gradients are QUEUED here (operands kept
+# alive) and launched eight at a time as one grid + one slab reduction (sidlsg_wgrad_group_bf16); whatever is queued is launched when a
+# gradient-exchange marker fires, when the backward pass ends, or when somebody is about to read gradients (flush_deferred).
+# Only layers that would take the 128 x 128-tile kernel anyway; the wide FF / q|k|v layers keep their 160 x 160-tile launches.
+# SIDLSG_WGRAD_GROUP=0: one launch per layer (A/B, tests).
+_WG_GROUP = os.environ.get('SIDLSG_WGRAD_GROUP', '1') != '0'
+_WG_MAX = 8
+_wg_queues = {}          # stream handle -> [torch stream, [jobs]]
+
+
+class _WgJob(ctypes.Structure):
+    _fields_ = [('dY', ctypes.c_void_p), ('A', ctypes.c_void_p), ('dW', ctypes.c_void_p), ('dBias', ctypes.c_void_p),
+                ('ldy', ctypes.c_int), ('lda', ctypes.c_int), ('M', ctypes.c_int), ('N', ctypes.c_int), ('K', ctypes.c_int),
+                ('assign', ctypes.c_int), ('pad', ctypes.c_int * 2)]
+
+
+def _queue_dense_wgrad(dy, x, dw, dbias, M, N, K, assign):
+    """True: queued for a grouped launch (the caller must not launch it)."""
+    if not _WG_GROUP or dy.dtype != BF16 or x.dtype != BF16 or not dy.is_cuda:
+        return False
+    if (N | K | dy.stride(0) | x.stride(0)) & 7 or (dy.data_ptr() | x.data_ptr()) & 15:
+        return False
+    if N % 160 == 0 and K % 160 == 0 and N != K and (M >= 4096 or N * K >= (8 << 20)):
+        return False          # the 160 x 160-tile kernel's layers (launch_wgrad, sq160): faster alone
+    if torch._C._current_graph_task_id() < 0:
+        return False          # outside a backward pass nobody would flush
+    st = torch.cuda.current_stream(dy.device)
+    q = _wg_queues.setdefault(st.cuda_stream, [st, []])
+    q[1].append((dy, x, dw, dbias, M, N, K, 1 if assign else 0))
+    if len(q[1]) >= _WG_MAX:
+        _flush_wgrad_queue(q)
+    _arm_end_of_backward_flush()
+    return True
+
+
+def _flush_wgrad_queue(q):
+    st, jobs = q
+    if not jobs:
+        return
+    arr = (_WgJob * len(jobs))()
+    for i, (dy, x, dw, dbias, M, N, K, assign) in enumerate(jobs):
+        arr[i].dY, arr[i].A, arr[i].dW, arr[i].dBias = dy.data_ptr(), x.data_ptr(), dw.data_ptr(), (dbias.data_ptr() if dbias is not None else None)
+        arr[i].ldy, arr[i].lda, arr[i].M, arr[i].N, arr[i].K, arr[i].assign = dy.stride(0), x.stride(0), M, N, K, assign
+    tensors = [t for j in jobs for t in j[:2]]
+    with torch.cuda.stream(st):          # the stream the operands were produced on: the weight-gradient stream waits for IT
+        with _OnWgradStream(*tensors):
+            lib.sidlsg_wgrad_group_bf16(ctypes.addressof(arr), len(jobs), _s())
+    jobs.clear()
+
+
+def flush_wgrad_queues():
+    for q in _wg_queues.values():
+        _flush_wgrad_queue(q)
+
+
+def _arm_end_of_backward_flush():
+    tid = torch._C._current_graph_task_id()
+    if tid >= 0 and tid not in _defer_armed:
+        _defer_armed.clear()             # ids never repeat: anything left is from a pass that did not finish
+        _defer_armed.add(tid)
+
+        def done():
+            _defer_armed.discard(tid)
+            flush_deferred()
+        torch.autograd.Variable._execution_engine.queue_callback(done)
 
 
 def ensure_stream_workspace(stream, nbytes=256 << 20):
@@ -458,9 +522,11 @@ class _Linear(torch.autograd.Function):
         fused_b = need_b and not need_rv and _wants_grad(weight) and x.dtype == BF16
         if _wants_grad(weight):
             M, K = x.shape
-            wg = _fn('wgrad_assign', x.dtype, '_bf16') if _take_assign(weight, x.dtype) else _fn('wgrad', x.dtype, '_bf16')
-            with _OnWgradStream(dy, x):
-                wg(_p(dy), dy.stride(0), _p(x), x.stride(0), _p(weight.grad), _p(bias.grad) if fused_b else None, M, weight.shape[0], K, _s())
+            assign = _take_assign(weight, x.dtype)
+            if not _queue_dense_wgrad(dy, x, weight.grad, bias.grad if fused_b else None, M, weight.shape[0], K, assign):
+                wg = _fn('wgrad_assign', x.dtype, '_bf16') if assign else _fn('wgrad', x.dtype, '_bf16')
+                with _OnWgradStream(dy, x):
+                    wg(_p(dy), dy.stride(0), _p(x), x.stride(0), _p(weight.grad), _p(bias.grad) if fused_b else None, M, weight.shape[0], K, _s())
         drv = None
         if need_rv:
             drv = colsum(dy, ctx.rpb, per_batch=True, total=bias.grad if need_b else None)

@@ -127,6 +127,73 @@ def test_wgrad_dense(dev, M, N, K):
     close(dw2, ref, 2e-3, 'wgrad (no bias)')
 
 
+def test_wgrad_group(dev):
+    """Round 5: several dense weight gradients as ONE launch + one slab reduction (sidlsg_wgrad_group_bf16: every job keeps its own operands,
+    shapes and split count; the group fills the chip together).  A transformer block's square projections + its 77-token k|v projection,
+    mixed assign / accumulate, with and without bias gradients, ragged row counts, against fp32 references and against the single entry
+    points; a one-job group; the queue of ops._queue_dense_wgrad through autograd (six Linear layers in one backward pass)."""
+    import ctypes
+    from sid_lsg_amd import ops
+    from sid_lsg_amd._lib import lib
+    ops.ensure_workspace(dev)
+    st = ops._s()
+    shapes = [(16384, 320, 320, 0, True), (16384, 320, 320, 1, False), (16384, 320, 320, 1, True), (1232, 640, 768, 0, False), (16390, 320, 320, 0, True),
+              (4096, 1280, 1280, 1, True), (300, 64, 72, 0, True), (16384, 960, 320, 0, False)]
+    keep, refs = [], []
+    arr = (ops._WgJob * len(shapes))()
+    outs = []
+    for i, (M, N, K, assign, with_b) in enumerate(shapes):
+        dy, a = rnd(M, N, seed=50 + i).to(dev), rnd(M, K, seed=70 + i).to(dev)
+        dw = torch.full((N, K), float('nan') if assign else 0.5, device=dev, dtype=F32)
+        db = torch.full((N,), 0.25, device=dev, dtype=F32) if with_b else None
+        keep += [dy, a]
+        outs.append((dw, db))
+        refs.append((dy.float().t() @ a.float() + (0.0 if assign else 0.5), dy.float().sum(0) + 0.25))
+        arr[i].dY, arr[i].A, arr[i].dW, arr[i].dBias = dy.data_ptr(), a.data_ptr(), dw.data_ptr(), (db.data_ptr() if with_b else None)
+        arr[i].ldy, arr[i].lda, arr[i].M, arr[i].N, arr[i].K, arr[i].assign = N, K, M, N, K, assign
+    lib.sidlsg_wgrad_group_bf16(ctypes.addressof(arr), len(shapes), st)
+    torch.cuda.synchronize()
+    for (dw, db), (rw, rb), sh in zip(outs, refs, shapes):
+        close(dw, rw, 2e-3, f'grouped wgrad {sh}')
+        if db is not None:
+            close(db, rb, 2e-3, f'grouped bias gradient {sh}')
+    # one job alone = the single entry point's split model need not be matched, the value must
+    one = (ops._WgJob * 1)()
+    dy, a = keep[0], keep[1]
+    dw1 = torch.zeros(320, 320, device=dev)
+    one[0].dY, one[0].A, one[0].dW, one[0].dBias = dy.data_ptr(), a.data_ptr(), dw1.data_ptr(), None
+    one[0].ldy, one[0].lda, one[0].M, one[0].N, one[0].K, one[0].assign = 320, 320, 16384, 320, 320, 1
+    lib.sidlsg_wgrad_group_bf16(ctypes.addressof(one), 1, st)
+    close(dw1, refs[0][0] - 0.5, 2e-3, 'one-job group')
+    # unaligned operands are refused, nothing launched
+    one[0].K = 324
+    assert lib.sidlsg_wgrad_group_bf16.raw(ctypes.addressof(one), 1, st) != 0
+    # through autograd: six Linear layers in one backward pass are queued and launched together, results = ungrouped
+    res = {}
+    for mode in (True, False):
+        old = ops._WG_GROUP
+        ops._WG_GROUP = mode
+        try:
+            ws = [torch.nn.Parameter((torch.randn(320, 320, generator=torch.Generator().manual_seed(90 + i)) * 0.05).to(dev)) for i in range(6)]
+            bs = [torch.nn.Parameter(torch.zeros(320, device=dev)) for _ in range(6)]
+            for p_ in ws + bs:
+                p_.grad = torch.zeros_like(p_)
+            h = rnd(4096, 320, seed=3).to(dev).requires_grad_()
+            a_ = h
+            for w_, b_ in zip(ws, bs):
+                w16 = w_.detach().to(BF16)
+                a_ = ops.linear(a_, w_, b_, w16, w16.t().contiguous())
+            a_.backward(rnd(4096, 320, seed=4).to(dev))
+            torch.cuda.synchronize()
+            assert all(not q[1] for q in ops._wg_queues.values()), 'jobs left in the queue after the backward pass'
+            res[mode] = [w_.grad.clone() for w_ in ws] + [b_.grad.clone() for b_ in bs]
+        finally:
+            ops._WG_GROUP = old
+    for g_, r_ in zip(res[True], res[False]):
+        assert float(r_.abs().max()) > 0
+        close(g_, r_, 2e-3, 'grouped vs single launches through autograd')
+
+
 @pytest.mark.parametrize('M,N,K', [(512, 128, 128), (1000, 320, 72), (333, 8, 320), (8192, 960, 320), (65536, 320, 320), (100, 2560, 320),
                                    (16384, 1280, 1280), (700, 12, 64), (9000, 20, 128)])      # last two: the register-staged kernel (N % 8 != 0)
 def test_wgrad_assign_is_bit_equal_to_accumulating_onto_zeros(dev, M, N, K):
