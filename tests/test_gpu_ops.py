@@ -838,13 +838,15 @@ def test_dispatch_trace_reports_kernel_time(dev):
     for _ in range(3):
         ops.gemm(a, w, out=out)
     torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(40):
-        ops.gemm(a, w, out=out)
-    e1.record()
-    torch.cuda.synchronize()
-    batch_ms = e0.elapsed_time(e1) / 40
+    batch_ms = float('inf')
+    for _ in range(3):          # (the best of three batches: one round-5 suite run saw the first batch take 3.6x as long -- another tenant's burst)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(40):
+            ops.gemm(a, w, out=out)
+        e1.record()
+        torch.cuda.synchronize()
+        batch_ms = min(batch_ms, e0.elapsed_time(e1) / 40)
     lib.sidlsg_trace_enable(1024)
     lib.sidlsg_trace_set_stride(0, 3)
     for _ in range(40):
