@@ -92,6 +92,7 @@ int sidlsg_wgrad_assign_bf16(const void* dY, int ldy, const void* A, int lda, fl
  * 64 bytes  { const void* dY; const void* A; float* dW; float* dBias; int ldy, lda, M, N, K, assign; int pad[2]; }  with the meaning
  * of sidlsg_wgrad_bf16 (assign = 0) / sidlsg_wgrad_assign_bf16 (assign = 1) per record; N, K, ldy, lda % 8 == 0, 16-byte aligned operands. */
 int sidlsg_wgrad_group_bf16(const void* jobs, int njobs, void* stream);
+int sidlsg_wgrad_group160_bf16(const void* jobs, int njobs, void* stream); /* the same on 160 x 160 tiles: every N and K a multiple of 160 */
 int sidlsg_conv3x3_wgrad_assign_bf16(const void* dY, int ldy, const void* X, int ldx, float* dW, float* dBias, int B, int H, int Wd,
                                      int Cin, int Cout, int stride, int ups, void* stream);
 int sidlsg_debug_wgrad_blocks_per_cu(int which); /* host diagnostic: resident blocks per CU of the weight-gradient kernels (0: 128x128, 1: 160x128, 2: 160x160 tiles) */

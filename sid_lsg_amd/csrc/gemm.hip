@@ -2419,6 +2419,19 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad_v2g_kernel(WgradGroup g) {
     if (local >= nblk) return;              // (the job's range is padded to a multiple of 8 blocks: XCD = block index mod 8 inside a job too)
     wgrad_v2_body<0, 128, WG_T, false, 1>(p);
 }
+// the same for the layers of the 160 x 160-tile kernel (q|k|v, FF-in, FF-out: N and K multiples of 160)
+__global__ __launch_bounds__(NTHREADS, 2) void wgrad_v2sg_kernel(WgradGroup g) {
+    const int bx = blockIdx.x;
+    int j = 0;
+#pragma unroll
+    for (int i = 1; i < WG_GROUP; i++)
+        if (i < g.njobs && bx >= g.blk0[i]) j = i;
+    const WgradParams& p = g.j[j];
+    const int local = bx - g.blk0[j];
+    const int nblk = ((p.N / 160) * (p.K / 160)) * p.nsplits;
+    if (local >= nblk) return;
+    wgrad_v2_body<0, 160, 160, false, 1>(p);
+}
 struct WgradReduceGroup { int njobs; unsigned blk0[WG_GROUP + 1]; const float* ws[WG_GROUP]; float* dW[WG_GROUP]; unsigned n4[WG_GROUP]; int splits[WG_GROUP], assign[WG_GROUP]; };
 __global__ __launch_bounds__(256) void wgrad_reduce_g_kernel(WgradReduceGroup g) {
     int j = 0;
@@ -2571,14 +2584,14 @@ static bool fits31(unsigned long long bytes) { return bytes < 0x7FFFFFFFull; }
 // Host side of the grouped dense weight gradient.  Every job must be one the 128 x 128 direct-to-LDS kernel takes (aligned operands);
 // the split count is chosen for the GROUP: all jobs together should put ~512 blocks on the chip (whole rounds, like launch_wgrad's
 // model), each job splitting its pixel range in proportion to its own row count.
-static int launch_wgrad_group(WgradParams* jobs, int njobs, hipStream_t s) {
+static int launch_wgrad_group(WgradParams* jobs, int njobs, hipStream_t s, bool t160) {
     if (njobs < 1 || njobs > WG_GROUP) return SIDLSG_EINVAL;
     long long tiles[WG_GROUP], total_tiles = 0;
     for (int i = 0; i < njobs; i++) {
         const WgradParams& p = jobs[i];
         const bool aligned = !(p.N & 7) && !(p.K & 7) && !(p.ldy & 7) && !(p.lda & 7) && !(((uintptr_t)p.dY | (uintptr_t)p.A) & 15);
-        if (!aligned) return SIDLSG_EINVAL;
-        tiles[i] = (long long)((p.N + 127) / 128) * ((p.K + WG_T - 1) / WG_T);
+        if (!aligned || (t160 && (p.N % 160 || p.K % 160))) return SIDLSG_EINVAL;
+        tiles[i] = t160 ? (long long)(p.N / 160) * (p.K / 160) : (long long)((p.N + 127) / 128) * ((p.K + WG_T - 1) / WG_T);
         total_tiles += tiles[i];
     }
     const Ws wsl = ws_for(s);
@@ -2618,13 +2631,15 @@ static int launch_wgrad_group(WgradParams* jobs, int njobs, hipStream_t s) {
     }
     g.blk0[njobs] = blocks;
     rg.njobs = rjobs; rg.blk0[rjobs] = rblocks;
-    const size_t lds = (size_t)2 * WG_MB * (128 + WG_T) * sizeof(bf16);
+    const size_t lds = (size_t)2 * WG_MB * (t160 ? 320 : 128 + WG_T) * sizeof(bf16);
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_v2g_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * WG_MB * (128 + WG_T) * 2);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_v2sg_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * WG_MB * 320 * 2);
         attr_done = true;
     }
-    SIDLSG_LAUNCH(wgrad_v2g_kernel, dim3(blocks), dim3(NTHREADS), lds, s, g);
+    if (t160) SIDLSG_LAUNCH(wgrad_v2sg_kernel, dim3(blocks), dim3(NTHREADS), lds, s, g);
+    else SIDLSG_LAUNCH(wgrad_v2g_kernel, dim3(blocks), dim3(NTHREADS), lds, s, g);
     if (rjobs) SIDLSG_LAUNCH(wgrad_reduce_g_kernel, dim3(rblocks), dim3(256), 0, s, rg);
     return sidlsg_last_error();
 }
@@ -2825,7 +2840,7 @@ int sidlsg_wgrad_assign_bf16(const void* dY, int ldy, const void* A, int lda, fl
 // (N, K, ldy, lda multiples of 8, 16-byte aligned operands), else EINVAL and nothing is launched.  Bit-identical per job to the single
 // entry points wherever both choose the same split count; otherwise the fp32 summation order over pixels differs.
 struct sidlsg_wgrad_job { const void* dY; const void* A; float* dW; float* dBias; int ldy, lda, M, N, K, assign; int pad[2]; };
-int sidlsg_wgrad_group_bf16(const void* jobs, int njobs, void* stream) {
+static int wgrad_group_impl(const void* jobs, int njobs, void* stream, bool t160) {
     if (!jobs || njobs < 1 || njobs > WG_GROUP) return SIDLSG_EINVAL;
     const sidlsg_wgrad_job* in = (const sidlsg_wgrad_job*)jobs;
     WgradParams ps[WG_GROUP];
@@ -2844,8 +2859,11 @@ int sidlsg_wgrad_group_bf16(const void* jobs, int njobs, void* stream) {
         bytes += 2.0 * ((double)q.M * q.N + (double)q.M * q.K) + (q.assign ? 4.0 : 8.0) * q.N * q.K;
     }
     SidlsgTraceScope ts(SIDLSG_FAM_WGRAD, flop, bytes);
-    return launch_wgrad_group(ps, njobs, (hipStream_t)stream);
+    return launch_wgrad_group(ps, njobs, (hipStream_t)stream, t160);
 }
+int sidlsg_wgrad_group_bf16(const void* jobs, int njobs, void* stream) { return wgrad_group_impl(jobs, njobs, stream, false); }
+// The same on 160 x 160 tiles: every job's N and K must be multiples of 160 (the q|k|v, FF-in and FF-out projections of a transformer block)
+int sidlsg_wgrad_group160_bf16(const void* jobs, int njobs, void* stream) { return wgrad_group_impl(jobs, njobs, stream, true); }
 
 // dW[Cout][3][3][Cin] += conv3x3 weight gradient (same geometry arguments as sidlsg_conv3x3_bf16)
 static int wgrad_conv_impl(const void* dY, int ldy, const void* X, int ldx, float* dW, float* dBias, int B, int H, int Wd,

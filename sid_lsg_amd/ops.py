@@ -263,8 +263,10 @@ def flush_deferred():
 # Only layers that would take the 128 x 128-tile kernel anyway; the wide FF / q|k|v layers keep their 160 x 160-tile launches.
 # SIDLSG_WGRAD_GROUP=0: one launch per layer (A/B, tests).
 _WG_GROUP = os.environ.get('SIDLSG_WGRAD_GROUP', '1') != '0'
+_WG_GROUP160 = os.environ.get('SIDLSG_WGRAD_GROUP160', '1') != '0'      # A/B: the wide layers launch alone (round-5 first version)
 _WG_MAX = 8
-_wg_queues = {}          # stream handle -> [torch stream, [jobs]]
+_WG_MAX160 = 3         # the three wide layers of one transformer block (FF-out, FF-in, q|k|v in backward order): 60 tiles of 160 x 160
+_wg_queues = {}          # (stream handle, tile class) -> [torch stream, [jobs], tile class]
 
 
 class _WgJob(ctypes.Structure):
@@ -279,21 +281,24 @@ def _queue_dense_wgrad(dy, x, dw, dbias, M, N, K, assign):
         return False
     if (N | K | dy.stride(0) | x.stride(0)) & 7 or (dy.data_ptr() | x.data_ptr()) & 15:
         return False
-    if N % 160 == 0 and K % 160 == 0 and N != K and (M >= 4096 or N * K >= (8 << 20)):
-        return False          # the 160 x 160-tile kernel's layers (launch_wgrad, sq160): faster alone
+    # two classes, as in launch_wgrad: the layers of the 160 x 160-tile kernel (q|k|v, FF-in, FF-out: N, K multiples of 160, N != K) are
+    # grouped among themselves (sidlsg_wgrad_group160_bf16), everything else on 128 x 128 tiles
+    t160 = N % 160 == 0 and K % 160 == 0 and N != K and (M >= 4096 or N * K >= (8 << 20))
+    if t160 and not _WG_GROUP160:
+        return False
     if torch._C._current_graph_task_id() < 0:
         return False          # outside a backward pass nobody would flush
     st = torch.cuda.current_stream(dy.device)
-    q = _wg_queues.setdefault(st.cuda_stream, [st, []])
+    q = _wg_queues.setdefault((st.cuda_stream, t160), [st, [], t160])
     q[1].append((dy, x, dw, dbias, M, N, K, 1 if assign else 0))
-    if len(q[1]) >= _WG_MAX:
+    if len(q[1]) >= (_WG_MAX160 if t160 else _WG_MAX):
         _flush_wgrad_queue(q)
     _arm_end_of_backward_flush()
     return True
 
 
 def _flush_wgrad_queue(q):
-    st, jobs = q
+    st, jobs, t160 = q
     if not jobs:
         return
     arr = (_WgJob * len(jobs))()
@@ -303,7 +308,7 @@ def _flush_wgrad_queue(q):
     tensors = [t for j in jobs for t in j[:2]]
     with torch.cuda.stream(st):          # the stream the operands were produced on: the weight-gradient stream waits for IT
         with _OnWgradStream(*tensors):
-            lib.sidlsg_wgrad_group_bf16(ctypes.addressof(arr), len(jobs), _s())
+            (lib.sidlsg_wgrad_group160_bf16 if t160 else lib.sidlsg_wgrad_group_bf16)(ctypes.addressof(arr), len(jobs), _s())
     jobs.clear()
 
 
@@ -1189,9 +1194,11 @@ class _LinearGEGLU(torch.autograd.Function):
         if _wants_grad(weight):
             M, K = x.shape
             need_b = _wants_grad(bias)
-            wg = lib.sidlsg_wgrad_assign_bf16 if _take_assign(weight, BF16) else lib.sidlsg_wgrad_bf16
-            with _OnWgradStream(dh, x):
-                wg(_p(dh), dh.stride(0), _p(x), x.stride(0), _p(weight.grad), _p(bias.grad) if need_b else None, M, weight.shape[0], K, _s())
+            assign = _take_assign(weight, BF16)
+            if not _queue_dense_wgrad(dh, x, weight.grad, bias.grad if need_b else None, M, weight.shape[0], K, assign):
+                wg = lib.sidlsg_wgrad_assign_bf16 if assign else lib.sidlsg_wgrad_bf16
+                with _OnWgradStream(dh, x):
+                    wg(_p(dh), dh.stride(0), _p(x), x.stride(0), _p(weight.grad), _p(bias.grad) if need_b else None, M, weight.shape[0], K, _s())
         elif _wants_grad(bias):
             colsum(dh, dh.shape[0], total=bias.grad)
         return dx, None, None, None, None, None, None
@@ -1250,10 +1257,12 @@ class _GegluLinear(torch.autograd.Function):
             lib.sidlsg_gemm_geglu_bwd_bf16(_p(dout), dout.stride(0), _p(w16t), _p(h), _p(dh), F2, M, F2 // 2, K, _s())
         need_b = _wants_grad(bias)
         if _wants_grad(weight):
-            wgk = lib.sidlsg_wgrad_assign_bf16 if _take_assign(weight, BF16) else lib.sidlsg_wgrad_bf16
-            with _OnWgradStream(dout, y):
-                wgk(_p(dout), dout.stride(0), _p(y), y.stride(0), _p(weight.grad), _p(bias.grad) if need_b else None, M, weight.shape[0],
-                    F2 // 2, _s())
+            assign = _take_assign(weight, BF16)
+            if not _queue_dense_wgrad(dout, y, weight.grad, bias.grad if need_b else None, M, weight.shape[0], F2 // 2, assign):
+                wgk = lib.sidlsg_wgrad_assign_bf16 if assign else lib.sidlsg_wgrad_bf16
+                with _OnWgradStream(dout, y):
+                    wgk(_p(dout), dout.stride(0), _p(y), y.stride(0), _p(weight.grad), _p(bias.grad) if need_b else None, M, weight.shape[0],
+                        F2 // 2, _s())
         elif need_b:
             colsum(dout, dout.shape[0], total=bias.grad)
         dres = dout if (ctx.has_res and ctx.needs_input_grad[6]) else None

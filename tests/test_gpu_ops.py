@@ -157,6 +157,28 @@ def test_wgrad_group(dev):
         close(dw, rw, 2e-3, f'grouped wgrad {sh}')
         if db is not None:
             close(db, rb, 2e-3, f'grouped bias gradient {sh}')
+    # the 160 x 160-tile class (q|k|v, FF-in, FF-out of one transformer block) through its own entry point
+    shapes160 = [(16384, 320, 1280, 1, True), (16384, 2560, 320, 0, True), (16384, 960, 320, 1, False)]
+    arr160 = (ops._WgJob * 3)()
+    outs160, refs160 = [], []
+    for i, (M, N, K, assign, with_b) in enumerate(shapes160):
+        dy, a = rnd(M, N, seed=150 + i).to(dev), rnd(M, K, seed=170 + i).to(dev)
+        dw = torch.full((N, K), float('nan') if assign else 0.5, device=dev, dtype=F32)
+        db = torch.full((N,), 0.25, device=dev, dtype=F32) if with_b else None
+        keep += [dy, a]
+        outs160.append((dw, db))
+        refs160.append((dy.float().t() @ a.float() + (0.0 if assign else 0.5), dy.float().sum(0) + 0.25))
+        arr160[i].dY, arr160[i].A, arr160[i].dW, arr160[i].dBias = dy.data_ptr(), a.data_ptr(), dw.data_ptr(), (db.data_ptr() if with_b else None)
+        arr160[i].ldy, arr160[i].lda, arr160[i].M, arr160[i].N, arr160[i].K, arr160[i].assign = N, K, M, N, K, assign
+    lib.sidlsg_wgrad_group160_bf16(ctypes.addressof(arr160), 3, st)
+    torch.cuda.synchronize()
+    for (dw, db), (rw, rb), sh in zip(outs160, refs160, shapes160):
+        close(dw, rw, 2e-3, f'grouped wgrad, 160 x 160 tiles {sh}')
+        if db is not None:
+            close(db, rb, 2e-3, f'grouped bias gradient, 160 x 160 tiles {sh}')
+    bad = (ops._WgJob * 1)()
+    ctypes.memmove(bad, ctypes.byref(arr[3]), ctypes.sizeof(ops._WgJob))          # 640 x 768: K is not a multiple of 160
+    assert lib.sidlsg_wgrad_group160_bf16.raw(ctypes.addressof(bad), 1, st) != 0
     # one job alone = the single entry point's split model need not be matched, the value must
     one = (ops._WgJob * 1)()
     dy, a = keep[0], keep[1]
