@@ -128,7 +128,13 @@ def compact_line(full):
     if cb:
         out['cpu_baseline'] = {'value': _r(cb['value'], 5), 'unit': cb['unit'], 'cores': cb['cores'], 'kind': cb['kind'], 'sample': cb['sample'][:120]}
     out['detail'] = 'bench_detail.json'
-    assert len(json.dumps(out)) < LINE_LIMIT, 'bench line outgrew the driver\'s tail'
+    # the line must fit the driver's tail: shed optional keys rather than end a finished run in an AssertionError with no line
+    for key in ('fracs_legend', 'fracs', 'comm', 'teacher_pass', 'frozen_pair_pass'):
+        if len(json.dumps(out)) < LINE_LIMIT:
+            break
+        out.pop(key, None)
+    if len(json.dumps(out)) >= LINE_LIMIT and 'cpu_baseline' in out:
+        out['cpu_baseline']['sample'] = out['cpu_baseline']['sample'][:40]
     return out
 
 

@@ -96,6 +96,7 @@ int sidlsg_wgrad_group160_bf16(const void* jobs, int njobs, void* stream); /* th
 int sidlsg_conv3x3_wgrad_assign_bf16(const void* dY, int ldy, const void* X, int ldx, float* dW, float* dBias, int B, int H, int Wd,
                                      int Cin, int Cout, int stride, int ups, void* stream);
 int sidlsg_debug_wgrad_blocks_per_cu(int which); /* host diagnostic: resident blocks per CU of the weight-gradient kernels (0: 128x128, 1: 160x128, 2: 160x160 tiles) */
+int sidlsg_debug_set_p8(int mode); /* A/B switch: which GEMM / conv calls take the 256-row-tile kernels (csrc/gemm_p8.h): -1 by rule (default), 0 never, 1 / 2 always the 256x160 / 256x320 configuration when admissible; returns the previous setting */
 int sidlsg_conv3x3_wgrad_bf16(const void* dY, int ldy, const void* X, int ldx, float* dW, float* dBias, int B, int H, int Wd,
                               int Cin, int Cout, int stride, int ups, void* stream);
 

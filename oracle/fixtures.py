@@ -60,6 +60,28 @@ def make_unet(cfg_name, seed=1234, perturb=0.0):
     return unet
 
 
+_UNET_WEIGHTS = {}      # (cfg_name, seed) -> freshly initialised state dict (never handed out: callers get clones)
+
+
+def make_unet_cached(cfg_name, seed=1234):
+    """make_unet(cfg_name, seed), bit for bit, without paying the initialisation twice: seeding + default nn init of the full-size
+    networks is ~20 s of serial random-number generation per call, and the full-size parity tests of the GPU suite asked for the
+    same four (architecture, seed) pairs 24 times.  The first call builds the network the ordinary way and keeps a private copy
+    of its weights; later calls construct the module on the meta device (no init) and adopt clones of that copy."""
+    key = (cfg_name, seed)
+    if key not in _UNET_WEIGHTS:
+        unet = make_unet(cfg_name, seed)
+        _UNET_WEIGHTS[key] = {k: v.detach().clone() for k, v in unet.state_dict().items()}
+        return unet
+    g = torch.random.get_rng_state()
+    with torch.device('meta'):
+        unet = UNet2DConditionRef(CONFIGS[cfg_name])
+    torch.random.set_rng_state(g)
+    unet.load_state_dict({k: v.clone() for k, v in _UNET_WEIGHTS[key].items()}, assign=True)
+    assert not any(p.is_meta for p in unet.parameters()) and not any(b.is_meta for b in unet.buffers())
+    return unet
+
+
 def factory(cfg_name='tiny', seed=1234):
     """Same 5-tuple as the reference's load_sd15 (training/sid_sd_util.py:118)."""
     te, tok = text_stack(cfg_name)

@@ -17,7 +17,7 @@ EXTRA = {'attention.hip': ['-mllvm', '-amdgpu-mfma-vgpr-form', '-fno-honor-nans'
 
 def digest():
     h = hashlib.md5()
-    for f in SOURCES + ['common.h']:
+    for f in SOURCES + ['common.h', 'gemm_p8.h', 'bias_act_kernel.h']:
         with open(os.path.join(HERE, f), 'rb') as fh:
             h.update(fh.read())
     h.update((' '.join(FLAGS) + repr(sorted(EXTRA.items()))).encode())

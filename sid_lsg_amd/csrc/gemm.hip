@@ -1220,6 +1220,8 @@ static int launch_gemm_v3(const GemmParams& p, hipStream_t s) {
     return sidlsg_last_error();
 }
 
+#include "gemm_p8.h"
+
 // ---------------------------------------------------------------------------------------------------------------------
 // MX-fp8 dense GEMM for FROZEN networks:  C[m][n] = wscale[n] * sum_k A8[m][k] * W8[n][k]  (+ the shared epilogue)
 // with BOTH operands OCP e4m3 bytes (A8: activations the producing GroupNorm / LayerNorm kernel wrote as e4m3 at unit
@@ -1805,6 +1807,48 @@ static int launch_gemm(const GemmParams& p, hipStream_t s) {
     return sidlsg_last_error();
 }
 
+static int g_p8_mode = -2;        // -2: not read yet
+static int p8_mode() {
+    if (g_p8_mode == -2) g_p8_mode = getenv("SIDLSG_GEMM_P8") ? atoi(getenv("SIDLSG_GEMM_P8")) : -1;
+    return g_p8_mode;
+}
+// Which p8 configuration a call takes when nothing forces one (-1: none, the v3 / bf16 kernels), and with how many K splits.
+// A small cost model with constants measured by tools/ubench/p8_bench on MI355X (profiles/r06_p8_ab.txt), microseconds:
+//   v3  (128 x 160 tiles, 512 resident):  rounds * (11 + 1.03 * k-tiles per split)
+//   p8W (256 x 320 tiles, 256 resident):  rounds * (F  + 1.61 * k-tiles per split),  F = 29 with the epilogue, 15 with slab stores
+//   split-K adds the slab round trip + gemm_finish_kernel: (8 * splits + 4) * M * N bytes at ~10 TB/s (the slabs stay in the Infinity Cache)
+// i.e. the W tile's K loop runs at 1.67 PFLOP/s against 1.30, and costs a whole-chip epilogue (every block finishes at the same
+// time: residual reads + output writes of the entire launch with no MFMA work beside them) where v3's two blocks per CU overlap theirs.
+// The 256 x 160 configuration ("S") has v3's bytes-per-MFMA and measured v3's speed on every shape: never chosen by rule.
+struct P8Choice { int cfg, splits; };
+template <int MODE>
+static P8Choice p8_rule(const GemmParams& p, long long ws_bytes) {
+    static const int margin_pct = getenv("SIDLSG_P8_MARGIN") ? atoi(getenv("SIDLSG_P8_MARGIN")) : 5;
+    static const bool dense_too = getenv("SIDLSG_P8_DENSE") && atoi(getenv("SIDLSG_P8_DENSE")) != 0;
+    if ((MODE == 0 && !dense_too) || !p8_ok<MODE>(p, 1)) return {-1, 1};
+    const int nk = p.K / BK;
+    const double mn = (double)p.M * p.N;
+    auto fin = [&](int s) { return s > 1 ? (8.0 * s + 4.0) * mn / 10e6 : 0.0; };
+    const long long cap = ws_bytes > 0 ? ws_bytes / (long long)(mn * 4) : 1;
+    // v3 as dispatch_gemm would launch it
+    const long long t3 = (long long)m_tiles_rt(p, 128) * (p.N / 160);
+    int s3 = 1;
+    if (t3 < 384 && nk >= 32 && cap >= 2) {
+        s3 = (int)std::min<long long>(std::min<long long>((512 + t3 - 1) / t3, cap), std::min(nk / 8, 16));
+        if (s3 < 2) s3 = 1;
+    }
+    const double v3_us = (double)((t3 * s3 + 511) / 512) * (11.0 + 1.03 * ((nk + s3 - 1) / s3)) + fin(s3);
+    const long long tw = (long long)m_tiles_rt(p, 256) * (p.N / 320);
+    double best = 1e30;
+    int bs = 1;
+    for (int s = 1; s <= 8; s++) {
+        if (s > 1 && (s > cap || nk / s < 12 || (tw * s > 256 && tw * (s - 1) >= 256))) break;
+        const double us = (double)((tw * s + 255) / 256) * ((s > 1 ? 15.0 : 29.0) + 1.61 * ((nk + s - 1) / s)) + fin(s);
+        if (us < best) { best = us; bs = s; }
+    }
+    return best * (100 + margin_pct) < v3_us * 100 ? P8Choice{1, bs} : P8Choice{-1, 1};
+}
+
 template <int MODE>
 static int dispatch_gemm(const GemmParams& pin, hipStream_t s) {
     GemmParams p = pin;
@@ -1826,6 +1870,27 @@ static int dispatch_gemm(const GemmParams& pin, hipStream_t s) {
             return launch_gemm_as<5>(p, s);
     }
     auto tiles = [&](int bm, int bn) { return (long long)m_tiles_rt(p, bm) * ((p.N + bn - 1) / bn); };
+    // p8 kernels (gemm_p8.h): 256-row tiles, one block per CU.  g_p8_mode: -1 = by rule, 0 = never, 1 / 2 = always the S / W
+    // configuration when the call is admissible (A/B switch: SIDLSG_GEMM_P8, sidlsg_debug_set_p8)
+    if constexpr (MODE != 2) {
+        const int mode = p8_mode();
+        const Ws w = ws_for(s);
+        const int nk = p.K / BK;
+        P8Choice ch{-1, 1};
+        if (mode == 1 || mode == 2) {           // forced configuration: split K towards one block per CU
+            ch.cfg = p8_ok<MODE>(p, mode - 1) ? mode - 1 : -1;
+            const long long t = tiles(256, ch.cfg == 1 ? 320 : 160);
+            if (ch.cfg >= 0 && t < 192 && w.ptr && (long long)p.M * p.N * 8 <= w.bytes)
+                ch.splits = std::max(1, (int)std::min<long long>(std::min<long long>((256 + t - 1) / t, w.bytes / ((long long)p.M * p.N * 4)), std::min(nk / 12, 16)));
+        } else if (mode < 0) {
+            ch = p8_rule<MODE>(p, w.ptr ? w.bytes : 0);
+        }
+        if (ch.cfg >= 0) {
+            GemmParams q = p;
+            if (ch.splits >= 2) { q.kt_per_split = (nk + ch.splits - 1) / ch.splits; q.ws = w.ptr; }
+            return ch.cfg ? launch_gemm_p8<MODE == 2 ? 0 : MODE, 1>(q, s) : launch_gemm_p8<MODE == 2 ? 0 : MODE, 0>(q, s);
+        }
+    }
     const bool n160 = p.N % 160 == 0;
     static const bool v3_on = !(getenv("SIDLSG_GEMM_V3") && atoi(getenv("SIDLSG_GEMM_V3")) == 0);   // A/B switch
     const bool v3 = n160 && v3_on && MODE != 2;
@@ -2655,6 +2720,14 @@ int sidlsg_debug_wgrad_blocks_per_cu(int which) {
     (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, f, NTHREADS, lds) != hipSuccess) return -1;
     return n;
+}
+
+// (A/B switch) which GEMM / conv calls take the 256-row-tile kernels of gemm_p8.h: -1 by rule (default), 0 never, 1 / 2 every
+// admissible call on the 256 x 160 / 256 x 320 configuration.  Returns the previous setting.
+int sidlsg_debug_set_p8(int mode) {
+    const int old = p8_mode();
+    g_p8_mode = mode;
+    return old;
 }
 
 // Optional scratch for split-K GEMMs and weight gradients: `ptr` = device memory of `bytes` bytes, owned by the

@@ -1196,7 +1196,7 @@ extern "C" {
 // of launching it; the partial sums stay in the caller's `ws` (which must stay allocated and untouched) until
 // sidlsg_flush_reductions(stream) launches all queued reductions as one kernel on that stream.  on = 2: later calls launch their own
 // reduction again, what is queued stays queued (the host wrapper brackets exactly ITS calls with 1 / 2, so direct users of the C ABI
-// on the same stream are never deferred behind their back).  on = 0: flush and forget the stream.  Returns the number of reductions flushed (>= 0) or a negative error.
+// on the same stream are never deferred behind their back).  on = 0: flush and forget the stream.  on = 3: forget the stream WITHOUT launching what is queued (the queue of a backward pass that raised).  Returns the number of reductions flushed (>= 0) or a negative error.
 int sidlsg_defer_reductions(void* stream, int on) {
     DeferState& d = dst();
     std::lock_guard<std::mutex> lk(d.mu);
@@ -1205,6 +1205,7 @@ int sidlsg_defer_reductions(void* stream, int on) {
     auto it = d.q.find(s);
     if (it == d.q.end()) return 0;
     if (on == 2) { it->second.accepting = false; return 0; }          // stop queuing, keep what is queued
+    if (on == 3) { const int n = (int)it->second.jobs.size(); d.q.erase(it); return n; }      // DISCARD what is queued (a backward pass that died): nothing is launched
     const int n = flush_pairs_locked(s, it->second.jobs);
     d.q.erase(it);
     return sidlsg_last_error() == SIDLSG_OK ? n : -1;

@@ -13,6 +13,7 @@ weight/bias gradients are ACCUMULATED IN PLACE by the kernels (atomics / +=) and
 functions return None for them, so no per-parameter gradient tensors are ever materialised.
 """
 import ctypes
+import weakref
 import os
 
 import torch
@@ -267,6 +268,7 @@ _WG_GROUP160 = os.environ.get('SIDLSG_WGRAD_GROUP160', '1') != '0'      # A/B: t
 _WG_MAX = 8
 _WG_MAX160 = 3         # the three wide layers of one transformer block (FF-out, FF-in, q|k|v in backward order): 60 tiles of 160 x 160
 _wg_queues = {}          # (stream handle, tile class) -> [torch stream, [jobs], tile class]
+_wg_queued_dw = set()    # data_ptr of every dW with a queued job
 
 
 class _WgJob(ctypes.Structure):
@@ -276,7 +278,12 @@ class _WgJob(ctypes.Structure):
 
 
 def _queue_dense_wgrad(dy, x, dw, dbias, M, N, K, assign):
-    """True: queued for a grouped launch (the caller must not launch it)."""
+    """True: queued for a grouped launch (the caller must not launch it).
+    The jobs of one grouped launch must have DISTINCT dW (include/sidlsg_hip.h): a parameter that reaches its weight gradient twice in
+    one backward pass (a shared / re-applied layer; one use queued and another one launched directly) first flushes what is queued,
+    so the two gradients stay ordered on the weight-gradient stream (the `assign` mark was taken by the earlier one)."""
+    if dw.data_ptr() in _wg_queued_dw:
+        flush_wgrad_queues()
     if not _WG_GROUP or dy.dtype != BF16 or x.dtype != BF16 or not dy.is_cuda:
         return False
     if (N | K | dy.stride(0) | x.stride(0)) & 7 or (dy.data_ptr() | x.data_ptr()) & 15:
@@ -291,6 +298,7 @@ def _queue_dense_wgrad(dy, x, dw, dbias, M, N, K, assign):
     st = torch.cuda.current_stream(dy.device)
     q = _wg_queues.setdefault((st.cuda_stream, t160), [st, [], t160])
     q[1].append((dy, x, dw, dbias, M, N, K, 1 if assign else 0))
+    _wg_queued_dw.add(dw.data_ptr())
     if len(q[1]) >= (_WG_MAX160 if t160 else _WG_MAX):
         _flush_wgrad_queue(q)
     _arm_end_of_backward_flush()
@@ -309,6 +317,8 @@ def _flush_wgrad_queue(q):
     with torch.cuda.stream(st):          # the stream the operands were produced on: the weight-gradient stream waits for IT
         with _OnWgradStream(*tensors):
             (lib.sidlsg_wgrad_group160_bf16 if t160 else lib.sidlsg_wgrad_group_bf16)(ctypes.addressof(arr), len(jobs), _s())
+    for j in jobs:
+        _wg_queued_dw.discard(j[2].data_ptr())
     jobs.clear()
 
 
@@ -317,10 +327,26 @@ def flush_wgrad_queues():
         _flush_wgrad_queue(q)
 
 
+def _discard_stale_backward_state():
+    """A backward pass that raised left its queues behind (weight-gradient jobs, dgamma / dbeta reductions on the C side, partial-sum
+    workspaces, the shared column-gradient buffer): launching them into .grad during the NEXT pass -- possibly after an optimizer step
+    re-marked the gradients -- would apply stale gradients silently.  Drop them."""
+    for q in _wg_queues.values():
+        q[1].clear()
+    _wg_queued_dw.clear()
+    for h, (st, keep) in _defer_streams.items():
+        lib.sidlsg_defer_reductions.raw(h, 3)
+        keep.clear()
+    for holder in list(_ColumnGrads.live):
+        holder.buf = None
+
+
 def _arm_end_of_backward_flush():
     tid = torch._C._current_graph_task_id()
     if tid >= 0 and tid not in _defer_armed:
-        _defer_armed.clear()             # ids never repeat: anything left is from a pass that did not finish
+        if _defer_armed:                 # ids never repeat: anything left is from a pass that did not finish
+            _defer_armed.clear()
+            _discard_stale_backward_state()
         _defer_armed.add(tid)
 
         def done():
@@ -1482,8 +1508,11 @@ class _ColumnGrads:
     first use) into whose column slices the consumers' backward kernels accumulate (ops.colsum(slot=...)); _SplitColumns.backward
     hands it on as it is.  22 fills + a concat kernel per pass become one fill."""
 
+    live = weakref.WeakSet()         # every holder, so that a pass that raised can be cleaned up after (_discard_stale_backward_state)
+
     def __init__(self, sizes):
         self.total, self.buf = sum(sizes), None
+        _ColumnGrads.live.add(self)
 
     def buffer(self, n, device):
         if self.buf is None:

@@ -207,7 +207,11 @@ class FusedAdamEMA:
         theirs = sd.get('layout')
         if theirs is None and mine is not None and sd.get('flat_layout', 1) != FLAT_LAYOUT:
             theirs = self._owner.flat_layout_table(version=sd.get('flat_layout', 1))
-        if theirs is None or mine is None or theirs == mine:
+        if theirs is not None and mine is None:
+            raise ValueError('optimizer state with a name -> offset table, but this optimizer has no owner network to compare it with: '
+                             'attach(owner=net) / set_owner(net) before load_state_dict (the moments are never loaded positionally '
+                             'under an unchecked parameter order)')
+        if theirs is None or theirs == mine:
             if theirs is None and sd.get('flat_layout', 1) != FLAT_LAYOUT:
                 raise ValueError(f"optimizer state of flat-buffer layout {sd.get('flat_layout', 1)} without a name table, this build uses "
                                  f'layout {FLAT_LAYOUT}, and the optimizer has no owner network to rebuild the table from: attach(owner=net) first')

@@ -129,12 +129,12 @@ def _run_bench(nproc, *flags, env_extra=None, timeout=1500):
 
 
 def test_bench_under_torchrun_two_ranks(dev):
-    import json
     """The driver's scaling run: `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`.  Two ranks share
     the one GPU of this box (SIDLSG_BENCH_SHARE_GPU=1: gloo carries the exchange), DEFAULT flags otherwise -- per-family
     kernel timing on, i.e. including the extra `isolated` iterations after the timed region, which exchange gradients and
     therefore must be executed by every rank (a rank-0-only version of them paired rank 0's gradient all-reduce with the
     other ranks' timing all-reduce).  One JSON line, whole-job images/s, all ranks exit cleanly."""
+    import json
     # (a small network: gloo moves the 2 x 3.4 GB of SD1.5 gradients through the host at ~40 s per iteration)
     out = _run_bench(2, '--steps', '2', '--warmup', '1', '--batch-gpu', '2', '--arch', 'tiny40', '--resolution', '128',
                      env_extra=dict(SIDLSG_BENCH_SHARE_GPU='1'))

@@ -186,7 +186,7 @@ def test_sd21_base_768px_forward_backward(dev):
     cfg = RC[cfg_name]
     torch.set_num_threads(min(64, os.cpu_count() or 8))
     try:
-        ref = fixtures.make_unet(cfg_name)
+        ref = fixtures.make_unet_cached(cfg_name)
         g = torch.Generator().manual_seed(0)
         x = torch.randn(B, 4, lat, lat, generator=g)
         t = torch.tensor([625])
@@ -274,8 +274,9 @@ def _iteration_parity(dev, cfg_name, lat, b, rounds, lr, kappa, alpha, iters, em
     cfg = RC[cfg_name]
     if cfg_name in ('sd15', 'sd21-base'):          # the full-size oracle iteration wants the host's cores (conftest caps the default at 8)
         torch.set_num_threads(min(64, os.cpu_count() or 8))
-    phi_r = fixtures.make_unet(cfg_name).eval().requires_grad_(False)
-    psi_r = fixtures.make_unet(cfg_name, seed=77).requires_grad_(False)   # psi != phi so the G loss is non-trivial at step 0
+    # (cached construction: the suite asked for the same full-size (architecture, seed) pairs 24 times at ~20 s of serial init each)
+    phi_r = fixtures.make_unet_cached(cfg_name).eval().requires_grad_(False)
+    psi_r = fixtures.make_unet_cached(cfg_name, seed=77).requires_grad_(False)   # psi != phi so the G loss is non-trivial at step 0
     G_r = copy.deepcopy(phi_r)
     Gema_r = copy.deepcopy(G_r)
     nets_r = dict(true_score=phi_r, fake_score=psi_r, G=G_r, G_ema=Gema_r)
@@ -343,7 +344,7 @@ def _iteration_parity(dev, cfg_name, lat, b, rounds, lr, kappa, alpha, iters, em
     if teacher_forced:
         return curve
     # parameters: Adam(beta1=0) moves every weight by ~lr*sign(g); compare the UPDATE direction statistically
-    init = {name: dict(fixtures.make_unet(cfg_name, seed=seed).named_parameters()) for name, seed in (('fake_score', 77), ('G', 1234))}
+    init = {name: dict(fixtures.make_unet_cached(cfg_name, seed=seed).named_parameters()) for name, seed in (('fake_score', 77), ('G', 1234))}
     for mode in modes:
         cd, variant = mode
         teacher_fp8, frozen_fp8 = variant in ('fp8-teacher', 'fp8-frozen'), variant == 'fp8-frozen'

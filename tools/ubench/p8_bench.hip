@@ -1,0 +1,146 @@
+// A/B harness for the 256-row-tile kernels (csrc/gemm_p8.h) against gemm_v3_kernel, through the C ABI of libsidlsg_hip.so.
+// Per shape: v3, p8 "S" (256 x 160), p8 "W" (256 x 320) -- time per call (HIP events, random data) and the output compared
+// with v3's bit for bit (identical accumulation order without split-K; with split-K the maximum relative difference).
+//   hipcc --offload-arch=gfx950 -O2 tools/ubench/p8_bench.hip -o tools/ubench/p8_bench -Lsid_lsg_amd -l:libsidlsg_hip.so -Wl,-rpath,'$ORIGIN/../../sid_lsg_amd'
+//   tools/ubench/p8_bench [conv|gemm|all] [batch] [rounds]
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <math.h>
+#include <vector>
+#include <algorithm>
+
+extern "C" {
+int sidlsg_conv3x3_bf16(const void* X, int ldx, const void* W, void* Y, int ldc, const float* bias, const void* res, int ldres, const float* rowvec,
+                        int ld_rowvec, int B, int H, int Wd, int Cin, int Cout, int stride, int ups, float alpha, int flags, void* stream);
+int sidlsg_gemm_bf16(const void* A, int lda, const void* W, void* C, int ldc, const float* bias, const void* res, int ldres, const float* rowvec,
+                     int ld_rowvec, int rows_per_batch, int M, int N, int K, float alpha, int flags, void* stream);
+int sidlsg_set_workspace(void* ptr, long long bytes);
+int sidlsg_debug_set_p8(int mode);
+}
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
+
+static uint16_t f2bf(float f) { uint32_t u; memcpy(&u, &f, 4); u += 0x7FFF + ((u >> 16) & 1); return (uint16_t)(u >> 16); }
+static float bf2f(uint16_t h) { uint32_t u = (uint32_t)h << 16; float f; memcpy(&f, &u, 4); return f; }
+static uint64_t rng_state = 0x1234567887654321ull;
+static float rnd() {      // uniform [-1, 1)
+    rng_state = rng_state * 6364136223846793005ull + 1442695040888963407ull;
+    return (float)((rng_state >> 40) & 0xFFFFFF) / 8388608.0f - 1.0f;
+}
+static void* dev_random_bf16(size_t n, float scale) {
+    std::vector<uint16_t> h(n);
+    for (size_t i = 0; i < n; i++) h[i] = f2bf(rnd() * scale);
+    void* d; CK(hipMalloc(&d, n * 2)); CK(hipMemcpy(d, h.data(), n * 2, hipMemcpyHostToDevice));
+    return d;
+}
+static float* dev_random_f32(size_t n) {
+    std::vector<float> h(n);
+    for (size_t i = 0; i < n; i++) h[i] = rnd();
+    float* d; CK(hipMalloc(&d, n * 4)); CK(hipMemcpy(d, h.data(), n * 4, hipMemcpyHostToDevice));
+    return d;
+}
+
+struct Case { int conv, B, H, cin, cout, stride; int M, N, K; int res, rowvec; };
+
+template <typename F>
+static double time_us(F fn, int iters) {
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int i = 0; i < 2; i++) fn();
+    CK(hipEventRecord(e0, 0));
+    for (int i = 0; i < iters; i++) fn();
+    CK(hipEventRecord(e1, 0));
+    CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    CK(hipEventDestroy(e0)); CK(hipEventDestroy(e1));
+    return ms * 1e3 / iters;
+}
+
+int main(int argc, char** argv) {
+    const char* what = argc > 1 ? argv[1] : "all";
+    const int B = argc > 2 ? atoi(argv[2]) : 16;
+    const int rounds = argc > 3 ? atoi(argv[3]) : 3;
+    const long long ws_bytes = 2ll << 30;
+    void* ws; CK(hipMalloc(&ws, ws_bytes));
+    sidlsg_set_workspace(ws, ws_bytes);
+    std::vector<Case> cases;
+    if (strcmp(what, "gemm")) {
+        const int cv[][4] = {{64, 320, 320, 1}, {64, 640, 320, 1}, {64, 960, 320, 1}, {32, 640, 640, 1}, {32, 1280, 640, 1}, {32, 1920, 640, 1},
+                             {16, 1280, 1280, 1}, {16, 2560, 1280, 1}, {8, 1280, 1280, 1}, {8, 2560, 1280, 1}, {64, 320, 320, 2}, {32, 640, 640, 2}};
+        int k = 0;
+        for (auto& c : cv) { cases.push_back({1, B, c[0], c[1], c[2], c[3], 0, 0, 0, k & 1, !(k & 1)}); k++; }      // ResBlock conv1: + time-embedding row vector; conv2: + skip
+    }
+    if (strcmp(what, "conv")) {
+        for (int lv = 0; lv < 3; lv++) {
+            const int hw = 4096 >> (2 * lv), c = 320 << lv, M = B * hw;
+            const int g[][2] = {{3 * c, c}, {c, c}, {8 * c, c}, {c, 4 * c}};
+            for (auto& s : g) cases.push_back({0, 0, 0, 0, 0, 0, M, s[0], s[1], 1, 0});
+        }
+        cases.push_back({0, 0, 0, 0, 0, 0, B * 4096, 320, 640, 0, 0});
+        cases.push_back({0, 0, 0, 0, 0, 0, B * 4096, 320, 64, 0, 0});      // one K-tile: the fixed cost of a tile
+        cases.push_back({0, 0, 0, 0, 0, 0, B * 4096, 320, 64, 1, 0});
+        cases.push_back({0, 0, 0, 0, 0, 0, B * 256, 1280, 5120, 0, 0});
+    }
+    double tot_f = 0, tot_t[4] = {0, 0, 0, 0};
+    int bad = 0;
+    for (auto& c : cases) {
+        int M, N, K, Ho = 0;
+        size_t a_elems;
+        if (c.conv) { Ho = (c.H - 1) / c.stride + 1; M = c.B * Ho * Ho; N = c.cout; K = 9 * c.cin; a_elems = (size_t)c.B * c.H * c.H * c.cin; }
+        else { M = c.M; N = c.N; K = c.K; a_elems = (size_t)M * K; }
+        void* A = dev_random_bf16(a_elems, 1.0f);
+        void* W = dev_random_bf16((size_t)N * K, 0.03f);
+        float* bias = dev_random_f32(N);
+        void* res = c.res ? dev_random_bf16((size_t)M * N, 1.0f) : nullptr;
+        float* rv = c.rowvec ? dev_random_f32((size_t)c.B * N) : nullptr;
+        void* out[4];
+        for (int i = 0; i < 4; i++) { CK(hipMalloc(&out[i], (size_t)M * N * 2)); CK(hipMemset(out[i], 0xFF, (size_t)M * N * 2)); }
+        auto call = [&](int mode, void* C) {
+            sidlsg_debug_set_p8(mode == 3 ? -1 : mode);
+            int e;
+            if (c.conv) e = sidlsg_conv3x3_bf16(A, c.cin, W, C, N, bias, res, N, rv, N, c.B, c.H, c.H, c.cin, N, c.stride, 0, 1.0f, 0, nullptr);
+            else e = sidlsg_gemm_bf16(A, K, W, C, N, bias, res, N, nullptr, 0, 1, M, N, K, 1.0f, 0, nullptr);
+            if (e) { printf("call failed: %d\n", e); exit(1); }
+        };
+        double best[4] = {1e30, 1e30, 1e30, 1e30};
+        for (int r = 0; r < rounds; r++)              // interleaved rounds, best of
+            for (int mode = 0; mode < 4; mode++) best[mode] = std::min(best[mode], time_us([&] { call(mode, out[mode]); }, 10));
+        CK(hipDeviceSynchronize());
+        // correctness: 8 more calls of each p8 mode compared with v3 (race screen)
+        std::vector<uint16_t> h0((size_t)M * N), h1((size_t)M * N);
+        CK(hipMemcpy(h0.data(), out[0], h0.size() * 2, hipMemcpyDeviceToHost));
+        char verdict[4][64] = {"ref", "", "", ""};
+        for (int mode = 1; mode < 4; mode++) {
+            size_t diff = 0; double maxrel = 0;
+            for (int rep = 0; rep < 4; rep++) {
+                CK(hipMemset(out[mode], 0xFF, (size_t)M * N * 2));
+                call(mode, out[mode]);
+                CK(hipMemcpy(h1.data(), out[mode], h1.size() * 2, hipMemcpyDeviceToHost));
+                for (size_t i = 0; i < h0.size(); i++)
+                    if (h0[i] != h1[i]) {
+                        diff++;
+                        const double a = bf2f(h0[i]), b = bf2f(h1[i]);
+                        const double rel = fabs(a - b) / (fabs(a) + 1.0);
+                        if (!(rel <= maxrel)) maxrel = rel;      // NaN-propagating
+                    }
+            }
+            if (diff == 0) snprintf(verdict[mode], 64, "bit-equal");
+            else { snprintf(verdict[mode], 64, "%zu diff, max rel %.2e", diff, maxrel); if (!(maxrel < 2e-2)) bad++; }
+        }
+        const double fl = 2.0 * M * (double)N * K;
+        if (c.conv) printf("conv B%d %dx%d %d->%d s%d  (M %d N %d K %d)\n", c.B, c.H, c.H, c.cin, c.cout, c.stride, M, N, K);
+        else printf("gemm M %d N %d K %d\n", M, N, K);
+        const char* nm[4] = {"v3 ", "p8S", "p8W", "rule"};
+        for (int mode = 0; mode < 4; mode++)
+            printf("    %s %9.1f us %8.1f TF/s   %s\n", nm[mode], best[mode], fl / best[mode] / 1e6, verdict[mode]);
+        tot_f += fl;
+        for (int mode = 0; mode < 4; mode++) tot_t[mode] += best[mode];
+        hipFree(A); hipFree(W); hipFree(bias); if (res) hipFree(res); if (rv) hipFree(rv);
+        for (int i = 0; i < 4; i++) hipFree(out[i]);
+        fflush(stdout);
+    }
+    printf("aggregate TF/s: v3 %.1f  p8S %.1f  p8W %.1f  rule %.1f   (%d shapes out of tolerance)\n", tot_f / tot_t[0] / 1e6, tot_f / tot_t[1] / 1e6, tot_f / tot_t[2] / 1e6, tot_f / tot_t[3] / 1e6, bad);
+    return bad ? 2 : 0;
+}
