@@ -485,7 +485,7 @@ def main():
     out = {
         'metric': 'distillation images/sec (512^2, SD1.5, kappa=1.5)' if (args.arch, args.resolution, args.kappa) == ('sd15', 512, 1.5) else f'distillation images/sec ({args.resolution}^2, {args.arch}, kappa={args.kappa})', 'value': value, 'unit': 'images/s', 'n_gpus': world,
         'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1000.0, 'higher_is_better': True,
-        'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
+        'scaling': 'weak', 'vs_baseline': None, 'dtype': {'bf16': 'bf16', 'fp8': 'bf16 (teacher forward: e4m3 weights + MX-fp8 MFMA)', 'fp8-frozen': 'bf16 (passes without weight gradients: e4m3 weights + MX-fp8 MFMA)'}[args.teacher_weights], 'data': 'synthetic',
         'config': {'workload': f'{args.arch} SiD-LSG inner step, kappa={args.kappa} on all branches, {args.resolution}x{args.resolution} ({lat}x{lat}x4 latents), '
                                f'batch_gpu={b}, fp32 masters + bf16 MFMA compute, Adam(beta1=0)+EMA, random-init weights',
                    'global_batch': batch_size, 'parallelism': f'dp{world}' + ('+forced-exchange(world-1 RCCL)' if args.force_exchange and world == 1 else ''),

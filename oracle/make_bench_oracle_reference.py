@@ -10,10 +10,15 @@ sums over samples x scale / batch_gpu_total and GroupNorm / LayerNorm / attentio
 to the one-round loss bench.py reports and the accumulated gradient is the one-round gradient (fp32 summation order aside);
 a CFG batch of 16 with autograd state does not fit this container's 62 GB.
 
-Writes `oracle_fp32` (iteration-0 loss_fake / loss_G) into tests/golden/bench_loss_reference.json next to the HIP fp32-mode values;
+Writes `oracle_fp32` (loss_fake / loss_G per iteration) into tests/golden/bench_loss_reference.json next to the HIP fp32-mode values;
 tests/test_gpu_bench_parity.py and bench.py's `loss_check` compare against it.
 
-    python oracle/make_bench_oracle_reference.py [--threads 8]"""
+`--iterations n` (round 6): iterations 0 .. n-1 in sequence, each on its own committed inputs (tests/golden/bench_it<i>_inputs.npz,
+tools/dump_bench_it0_inputs.py --iterations n), carrying the fake-score / generator weights and their Adam state
+(training/sid_training_loop.py:443-445, 522-530) from one iteration to the next, so that the stored references after optimizer
+steps are the ORACLE's too, not the HIP fp32 mode's.  The file is rewritten after every finished iteration (~25-30 min each on 8 cores).
+
+    python oracle/make_bench_oracle_reference.py [--threads 8] [--iterations 3]"""
 import argparse
 import copy
 import json
@@ -36,6 +41,7 @@ def main():
     ap.add_argument('--kappa', type=float, default=1.5)
     ap.add_argument('--threads', type=int, default=os.cpu_count())
     ap.add_argument('--samples', type=int, default=None, help='debug: only the first n samples (the result is then NOT stored)')
+    ap.add_argument('--iterations', type=int, default=1)
     args = ap.parse_args()
     torch.set_num_threads(args.threads)
     from oracle import sid_ref
@@ -54,61 +60,76 @@ def main():
     assert abs(s - float(d['weights_sum'])) < 1e-6 * sa and abs(sa - float(d['weights_abs_sum'])) < 1e-9 * sa, 'not the weights bench.py built'
     psi, G = copy.deepcopy(phi), copy.deepcopy(phi)                          # bench: psi, G = clones of phi
     sched = DDPMSchedulerRef()
+    st_psi, st_G = [{} for _ in psi.parameters()], [{} for _ in G.parameters()]      # Adam state, carried across iterations
 
     def bf16(a):
         return torch.from_numpy(a.copy()).view(torch.bfloat16).float()
-
-    def rounds(ph):
-        cond, unc = bf16(d[f'{ph}_cond_bf16']), bf16(d[f'{ph}_uncond_bf16'])
-        n = b if args.samples is None else args.samples
-        return [dict(z=torch.from_numpy(d[f'{ph}_z'][i:i + 1]), noise=torch.from_numpy(d[f'{ph}_noise'][i:i + 1]),
-                     t=torch.from_numpy(d[f'{ph}_t'][i:i + 1]), cond=cond[i:i + 1], uncond=unc) for i in range(n)]
     k = args.kappa
-    # ---- phase A (sid_iteration_ref's phase A, per-round losses summed)
-    psi.requires_grad_(True)
-    loss_fake = 0.0
-    for i, r in enumerate(rounds('A')):
-        init_t = torch.full((1,), 625, dtype=torch.long)
-        with torch.no_grad():
-            images = sid_ref.sampler_ref(G, r['z'], r['cond'], init_t, sched)
-        nf = sid_ref.denoise_ref(psi, images, r['noise'], r['cond'], r['uncond'], r['t'], sched, predict_x0=False, guidance_scale=k)
-        loss, n = sid_ref.fake_score_loss_ref(nf, r['noise'], 1.0, b)
-        assert n == 1
-        loss.backward()
-        loss_fake += float(loss.detach())
-        print(f'phase A sample {i}: {float(loss.detach()):.6f}  [{time.time() - t0:.0f} s]', flush=True)
-    psi.requires_grad_(False)
-    with torch.no_grad():
-        for p in psi.parameters():
-            sid_ref.adam_step_ref(p, p.grad, {}, 1e-6, (0.0, 0.999), 1e-8)
-            p.grad = None
-    # ---- phase B
-    G.requires_grad_(True)
-    loss_G = 0.0
-    for i, r in enumerate(rounds('B')):
-        init_t = torch.full((1,), 625, dtype=torch.long)
-        images = sid_ref.sampler_ref(G, r['z'], r['cond'], init_t, sched)
-        y_fake = sid_ref.denoise_ref(psi, images, r['noise'], r['cond'], r['uncond'], r['t'], sched, guidance_scale=k)
-        y_real = sid_ref.denoise_ref(phi, images, r['noise'], r['cond'], r['uncond'], r['t'], sched, guidance_scale=k)
-        loss, n = sid_ref.generator_loss_ref(images, y_real, y_fake, 1.0, 1.0, b)
-        assert n == 1
-        loss.backward()
-        loss_G += float(loss.detach())
-        print(f'phase B sample {i}: {float(loss.detach()):.6f}  [{time.time() - t0:.0f} s]', flush=True)
-    print(f'oracle fp32, {key}, iteration 0: loss_fake {loss_fake:.6f} loss_G {loss_G:.6f}', flush=True)
-    if args.samples is not None:
-        return
-    data = {}
-    if os.path.isfile(args.out):
-        with open(args.out) as f:
-            data = json.load(f)
-    ent = data.setdefault(key, {})
-    ent['oracle_fp32'] = dict(made_by='oracle/make_bench_oracle_reference.py: fp32 CPU oracle (oracle/sid_ref.py) on tests/golden/bench_it0_inputs.npz, '
-                                      f'{b} accumulation rounds of one sample', loss_fake=[loss_fake], loss_G=[loss_G])
-    with open(args.out, 'w') as f:
-        json.dump(data, f, indent=1)
-    print('wrote', args.out)
+    losses_f, losses_g = [], []
+    for it in range(args.iterations):
+        if it:
+            path = os.path.join(os.path.dirname(args.inputs), f'bench_it{it}_inputs.npz')
+            d = np.load(path)
+            assert str(d['key']) == key and int(d['iteration']) == it, path
 
+        def rounds(ph):
+            cond, unc = bf16(d[f'{ph}_cond_bf16']), bf16(d[f'{ph}_uncond_bf16'])
+            n = b if args.samples is None else args.samples
+            return [dict(z=torch.from_numpy(d[f'{ph}_z'][i:i + 1]), noise=torch.from_numpy(d[f'{ph}_noise'][i:i + 1]),
+                         t=torch.from_numpy(d[f'{ph}_t'][i:i + 1]), cond=cond[i:i + 1], uncond=unc) for i in range(n)]
+        # ---- phase A (sid_iteration_ref's phase A, per-round losses summed)
+        psi.requires_grad_(True)
+        loss_fake = 0.0
+        for i, r in enumerate(rounds('A')):
+            init_t = torch.full((1,), 625, dtype=torch.long)
+            with torch.no_grad():
+                images = sid_ref.sampler_ref(G, r['z'], r['cond'], init_t, sched)
+            nf = sid_ref.denoise_ref(psi, images, r['noise'], r['cond'], r['uncond'], r['t'], sched, predict_x0=False, guidance_scale=k)
+            loss, n = sid_ref.fake_score_loss_ref(nf, r['noise'], 1.0, b)
+            assert n == 1
+            loss.backward()
+            loss_fake += float(loss.detach())
+            print(f'iteration {it} phase A sample {i}: {float(loss.detach()):.6f}  [{time.time() - t0:.0f} s]', flush=True)
+        psi.requires_grad_(False)
+        with torch.no_grad():
+            for p, stt in zip(psi.parameters(), st_psi):
+                sid_ref.adam_step_ref(p, p.grad, stt, 1e-6, (0.0, 0.999), 1e-8)
+                p.grad = None
+        # ---- phase B
+        G.requires_grad_(True)
+        loss_G = 0.0
+        for i, r in enumerate(rounds('B')):
+            init_t = torch.full((1,), 625, dtype=torch.long)
+            images = sid_ref.sampler_ref(G, r['z'], r['cond'], init_t, sched)
+            y_fake = sid_ref.denoise_ref(psi, images, r['noise'], r['cond'], r['uncond'], r['t'], sched, guidance_scale=k)
+            y_real = sid_ref.denoise_ref(phi, images, r['noise'], r['cond'], r['uncond'], r['t'], sched, guidance_scale=k)
+            loss, n = sid_ref.generator_loss_ref(images, y_real, y_fake, 1.0, 1.0, b)
+            assert n == 1
+            loss.backward()
+            loss_G += float(loss.detach())
+            print(f'iteration {it} phase B sample {i}: {float(loss.detach()):.6f}  [{time.time() - t0:.0f} s]', flush=True)
+        G.requires_grad_(False)
+        print(f'oracle fp32, {key}, iteration {it}: loss_fake {loss_fake:.6f} loss_G {loss_G:.6f}', flush=True)
+        losses_f.append(loss_fake); losses_g.append(loss_G)
+        if args.samples is not None:
+            return
+        data = {}
+        if os.path.isfile(args.out):
+            with open(args.out) as f:
+                data = json.load(f)
+        ent = data.setdefault(key, {})
+        ent['oracle_fp32'] = dict(made_by='oracle/make_bench_oracle_reference.py: fp32 CPU oracle (oracle/sid_ref.py) on tests/golden/bench_it<i>_inputs.npz, '
+                                          f'{b} accumulation rounds of one sample per iteration, weights + Adam state carried across iterations',
+                                  loss_fake=list(losses_f), loss_G=list(losses_g))
+        with open(args.out, 'w') as f:
+            json.dump(data, f, indent=1)
+        print('wrote', args.out, flush=True)
+        if it + 1 < args.iterations:           # the generator's step (the last iteration's is not needed for any stored loss)
+            with torch.no_grad():
+                for p, stt in zip(G.parameters(), st_G):
+                    sid_ref.adam_step_ref(p, p.grad, stt, 1e-6, (0.0, 0.999), 1e-8)
+        for p in G.parameters():
+            p.grad = None
 
 if __name__ == '__main__':
     main()

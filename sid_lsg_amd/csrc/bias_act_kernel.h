@@ -70,17 +70,19 @@ __global__ void bias_act_kernel(const T* __restrict__ x, const T* __restrict__ b
     out[i] = (T)o;
 }
 
-// dtype 0 = fp32, 1 = bf16
+// dtype 0 = fp32, 1 = bf16, 2 = fp16, 3 = fp64 (the reference dispatches AT_DISPATCH_FLOATING_TYPES_AND_HALF: bias_act.cpp:77; every
+// type computes in fp32 registers like the reference's `scalar_t = float` for half, fp64 included: the plugin is an activation epilogue)
+#define SIDLSG_BIAS_ACT_LAUNCH(T)                                                                                                      \
+    hipLaunchKernelGGL(bias_act_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, (const T*)x, (const T*)b, (const T*)dy, (const T*)ddx, \
+                       (T*)out, (size_t)n, stepB, sizeB, act, alpha, gain, clamp, grad)
 static inline int bias_act_launch(const void* x, const void* b, const void* dy, const void* ddx, void* out, long long n, int stepB,
                                   int sizeB, int act, float alpha, float gain, float clamp, int grad, int dtype, void* stream) {
-    if (act < 1 || act > 9 || grad < 0 || grad > 2 || (grad >= 1 && !dy) || (grad == 2 && !ddx) || n < 0) return SIDLSG_EINVAL;
+    if (act < 1 || act > 9 || grad < 0 || grad > 2 || (grad >= 1 && !dy) || (grad == 2 && !ddx) || n < 0 || dtype < 0 || dtype > 3) return SIDLSG_EINVAL;
     if (n == 0) return SIDLSG_OK;
     const dim3 grid((unsigned)((n + 255) / 256));
-    if (dtype == 0)
-        hipLaunchKernelGGL(bias_act_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)x, (const float*)b,
-                           (const float*)dy, (const float*)ddx, (float*)out, (size_t)n, stepB, sizeB, act, alpha, gain, clamp, grad);
-    else
-        hipLaunchKernelGGL(bias_act_kernel<bf16>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)x, (const bf16*)b,
-                           (const bf16*)dy, (const bf16*)ddx, (bf16*)out, (size_t)n, stepB, sizeB, act, alpha, gain, clamp, grad);
+    if (dtype == 0) SIDLSG_BIAS_ACT_LAUNCH(float);
+    else if (dtype == 1) SIDLSG_BIAS_ACT_LAUNCH(bf16);
+    else if (dtype == 2) SIDLSG_BIAS_ACT_LAUNCH(_Float16);
+    else SIDLSG_BIAS_ACT_LAUNCH(double);
     return sidlsg_last_error();
 }

@@ -94,6 +94,41 @@ template <> DEVFN void ldv8<float>(const float* p, float (&v)[8]) {
     const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
     v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
 }
+// 8 consecutive activation elements as they are in memory (no conversion: the registers are not touched until unpack(), so a
+// load can stay in flight across control flow and stores -- see the prefetching row loops of norm.hip)
+template <typename T> struct Raw8;
+template <> struct Raw8<bf16> {
+    bf16x8 v;
+    DEVFN void load(const bf16* p) { v = ld8(p); }
+    DEVFN void unpack(float (&o)[8]) const {
+#pragma unroll
+        for (int e = 0; e < 8; e++) o[e] = bf2f(v[e]);
+    }
+};
+template <> struct Raw8<float> {
+    f32x4 a, b;
+    DEVFN void load(const float* p) { a = *reinterpret_cast<const f32x4*>(p); b = *reinterpret_cast<const f32x4*>(p + 4); }
+    DEVFN void unpack(float (&o)[8]) const { o[0] = a[0]; o[1] = a[1]; o[2] = a[2]; o[3] = a[3]; o[4] = b[0]; o[5] = b[1]; o[6] = b[2]; o[7] = b[3]; }
+};
+// Branch-free predicated accesses through a buffer descriptor: an offset >= SIDLSG_OOB is out of range for every descriptor
+// (< 2 GiB of records), so the load returns zeros and the store is dropped -- no `if (valid)` around the access.  That matters beyond
+// the saved branch: gfx950 retires loads and stores through ONE in-order counter and the compiler merges the counter state of the two
+// arms of a branch conservatively, so a store inside a divergent `if` turns every later counted wait into s_waitcnt vmcnt(0), i.e. a
+// prefetched load can no longer be waited for without also waiting for the stores issued behind it.
+constexpr unsigned SIDLSG_OOB = 0x80000000u;
+DEVFN __amdgpu_buffer_rsrc_t mk_buf(const void* p, long long bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)(bytes > 0x7FFFFFFFll ? 0x7FFFFFFFll : bytes), 0x00020000);
+}
+DEVFN void Raw8_bload(Raw8<bf16>& r, __amdgpu_buffer_rsrc_t rs, unsigned elem) {
+    r.v = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, elem >= SIDLSG_OOB ? elem : elem * 2u, 0, 0));
+}
+DEVFN void Raw8_bload(Raw8<float>& r, __amdgpu_buffer_rsrc_t rs, unsigned elem) {
+    const unsigned o = elem >= SIDLSG_OOB ? elem : elem * 4u;
+    r.a = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, o, 0, 0));
+    r.b = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, o, 16, 0));
+}
+// 8 consecutive outputs at ELEMENT index `elem` (or SIDLSG_OOB: dropped) of a [..][C] tensor of T, or (F8) of e4m3 bytes
+template <typename T, bool F8> DEVFN void bst8_out(__amdgpu_buffer_rsrc_t rs, unsigned elem, const float (&v)[8]);
 template <typename T> DEVFN void stv8(T* p, const float (&v)[8]);
 template <> DEVFN void stv8<bf16>(bf16* p, const float (&v)[8]) {
     bf16x8 o;
@@ -124,6 +159,22 @@ DEVFN void st8_out(T* y, size_t idx, const float (&v)[8]) {
         *reinterpret_cast<u32x2*>(reinterpret_cast<unsigned char*>(y) + idx) = q;
     } else {
         stv8<T>(y + idx, v);
+    }
+}
+template <typename T, bool F8> DEVFN void bst8_out(__amdgpu_buffer_rsrc_t rs, unsigned elem, const float (&v)[8]) {
+    const bool oob = elem >= SIDLSG_OOB;
+    if constexpr (F8) {
+        const u32x2 q = {cvt4_fp8(v[0], v[1], v[2], v[3]), cvt4_fp8(v[4], v[5], v[6], v[7])};
+        __builtin_amdgcn_raw_buffer_store_b64(q, rs, elem, 0, 0);
+    } else if constexpr (sizeof(T) == 2) {
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; e++) o[e] = f2bf(v[e]);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rs, oob ? elem : elem * 2u, 0, 0);
+    } else {
+        const unsigned o = oob ? elem : elem * 4u;
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, (f32x4){v[0], v[1], v[2], v[3]}), rs, o, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, (f32x4){v[4], v[5], v[6], v[7]}), rs, o, 16, 0);
     }
 }
 template <typename T> DEVFN void zerov8(T* p) {

@@ -1814,18 +1814,23 @@ static int p8_mode() {
 }
 // Which p8 configuration a call takes when nothing forces one (-1: none, the v3 / bf16 kernels), and with how many K splits.
 // A small cost model with constants measured by tools/ubench/p8_bench on MI355X (profiles/r06_p8_ab.txt), microseconds:
-//   v3  (128 x 160 tiles, 512 resident):  rounds * (11 + 1.03 * k-tiles per split)
-//   p8W (256 x 320 tiles, 256 resident):  rounds * (F  + 1.61 * k-tiles per split),  F = 29 with the epilogue, 15 with slab stores
+//   v3  (128 x 160 tiles, 512 resident):  rounds * (11  + 1.03 * k-tiles per split)
+//   p8W (256 x 320 tiles, 256 resident):  rounds * (16  + 1.61 * k-tiles per split)      13 with slab stores instead of the epilogue
+//   p8S (256 x 160 tiles, 256 resident):  rounds * (8.5 + 1.03 * k-tiles per split)       7
 //   split-K adds the slab round trip + gemm_finish_kernel: (8 * splits + 4) * M * N bytes at ~10 TB/s (the slabs stay in the Infinity Cache)
-// i.e. the W tile's K loop runs at 1.67 PFLOP/s against 1.30, and costs a whole-chip epilogue (every block finishes at the same
-// time: residual reads + output writes of the entire launch with no MFMA work beside them) where v3's two blocks per CU overlap theirs.
-// The 256 x 160 configuration ("S") has v3's bytes-per-MFMA and measured v3's speed on every shape: never chosen by rule.
+// i.e. the W tile's K loop runs at 1.67 PFLOP/s against 1.30 (half the staged bytes and 0.7x the fragment reads per MFMA); its
+// blocks all finish at the same time (residual reads + output writes of the entire launch with no MFMA work beside them), which
+// the row-major epilogue of gemm_p8.h keeps at the HBM time of those bytes.  The S tile has v3's bytes per MFMA and v3's K loop; what
+// it saves is epilogue time per output byte -- worth 8-10 % stand-alone on the short-K dense GEMMs (K = 320 ... 640: five to ten
+// K-tiles per tile), nothing on the convolutions (+-3 %), and nothing in the step (201.7 vs 201.8 ms per iteration with / without it,
+// profiles/r06_p8_step_ab.txt): the rule offers it to dense calls only and only with SIDLSG_P8_S=1.
 struct P8Choice { int cfg, splits; };
 template <int MODE>
 static P8Choice p8_rule(const GemmParams& p, long long ws_bytes) {
-    static const int margin_pct = getenv("SIDLSG_P8_MARGIN") ? atoi(getenv("SIDLSG_P8_MARGIN")) : 5;
-    static const bool dense_too = getenv("SIDLSG_P8_DENSE") && atoi(getenv("SIDLSG_P8_DENSE")) != 0;
-    if ((MODE == 0 && !dense_too) || !p8_ok<MODE>(p, 1)) return {-1, 1};
+    static const int margin_pct = getenv("SIDLSG_P8_MARGIN") ? atoi(getenv("SIDLSG_P8_MARGIN")) : 3;
+    static const bool dense_too = !(getenv("SIDLSG_P8_DENSE") && atoi(getenv("SIDLSG_P8_DENSE")) == 0);      // A/B switch: dense GEMMs by the same model
+    static const bool s_too = getenv("SIDLSG_P8_S") && atoi(getenv("SIDLSG_P8_S")) != 0;                     // A/B switch: the 256 x 160 configuration for dense GEMMs (off: neutral in the step)
+    if ((MODE == 0 && !dense_too) || p.N % 160 || p.K % BK || p.M <= 0) return {-1, 1};      // (nothing below divides by a zero tile count)
     const int nk = p.K / BK;
     const double mn = (double)p.M * p.N;
     auto fin = [&](int s) { return s > 1 ? (8.0 * s + 4.0) * mn / 10e6 : 0.0; };
@@ -1838,15 +1843,19 @@ static P8Choice p8_rule(const GemmParams& p, long long ws_bytes) {
         if (s3 < 2) s3 = 1;
     }
     const double v3_us = (double)((t3 * s3 + 511) / 512) * (11.0 + 1.03 * ((nk + s3 - 1) / s3)) + fin(s3);
-    const long long tw = (long long)m_tiles_rt(p, 256) * (p.N / 320);
-    double best = 1e30;
-    int bs = 1;
-    for (int s = 1; s <= 8; s++) {
-        if (s > 1 && (s > cap || nk / s < 12 || (tw * s > 256 && tw * (s - 1) >= 256))) break;
-        const double us = (double)((tw * s + 255) / 256) * ((s > 1 ? 15.0 : 29.0) + 1.61 * ((nk + s - 1) / s)) + fin(s);
-        if (us < best) { best = us; bs = s; }
+    P8Choice best{-1, 1};
+    double best_us = v3_us * 100.0 / (100 + margin_pct);
+    for (int cfg = 1; cfg >= 0; cfg--) {
+        if ((cfg == 0 && (MODE != 0 || !s_too)) || !p8_ok<MODE>(p, cfg)) continue;
+        const long long t = (long long)m_tiles_rt(p, 256) * (p.N / (cfg ? 320 : 160));
+        const double f1 = cfg ? 16.0 : 8.5, fs = cfg ? 13.0 : 7.0, slope = cfg ? 1.61 : 1.03;
+        for (int s = 1; s <= 8; s++) {
+            if (s > 1 && (s > cap || nk / s < 12 || (t * s > 256 && t * (s - 1) >= 256))) break;
+            const double us = (double)((t * s + 255) / 256) * ((s > 1 ? fs : f1) + slope * ((nk + s - 1) / s)) + fin(s);
+            if (us < best_us) { best_us = us; best = {cfg, s}; }
+        }
     }
-    return best * (100 + margin_pct) < v3_us * 100 ? P8Choice{1, bs} : P8Choice{-1, 1};
+    return best;
 }
 
 template <int MODE>

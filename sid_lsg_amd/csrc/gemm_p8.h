@@ -66,35 +66,73 @@ DEVFN int wsw80(int r) {        // W-tile swizzle of a row, relative to its wave
 // code cost ~90 us per tile in the first measurement -- more than the K loop of a 320 -> 320 conv).  Here the accumulators go through
 // LDS as fp32, 32 rows per wave and pass (MT / 2 passes, 80 KiB image), and the tile is finished ROW-MAJOR: a thread owns 8
 // consecutive channels of a row, loads the residual with one coalesced 16-byte load (the fragment layout fetched 64-byte pieces of
-// 16 rows per instruction), bias and row vector from the caches, and stores 16 bytes.  Every load of a pass is issued before its
-// first store.  Arithmetic and its order are those of epilogue_rows8: x = acc * alpha + bias; x += rowvec; x += res; SiLU; round.
-template <int CFG>
-DEVFN void p8_epilogue(const GemmParams& p, f32x4 (&acc)[5][4 * (CFG ? 2 : 1)], float* img, int m0, int n0, int wr, int wn0, int li, int lg, int tid) {
+// 16 rows per instruction) and stores 16 bytes.
+// gfx950 retires loads AND stores through one in-order counter, so a load issued behind a pass's stores cannot be waited for before
+// those stores are acknowledged by the memory system: with bias / row-vector loads inside the passes every pass paid a store round
+// trip (one-K-tile launch: 25 us for a 256 x 320 tile against an 8 us HBM floor).  Hence: bias and the row vectors of the (at most
+// P8_RV_IMGS) images the tile touches are copied to LDS once, before the first store, and the residual chunks of pass p + 1 are
+// requested BEFORE the stores of pass p -- the wait for them then leaves those stores (and the next request) in flight.
+// Arithmetic and its order are those of epilogue_rows8: x = acc * alpha + bias; x += rowvec; x += res; SiLU; round.
+// The hot feature sets (bf16 output, no activation: bias only / + residual / + row vector) are straight-line instantiations with
+// branch-free range handling (rows >= M get an out-of-range buffer offset: loads return zeros, stores are dropped) -- with per-chunk
+// branches the compiler merges the paths with s_waitcnt vmcnt(0) and the counted waits are gone; FEAT 3 reads the flags at run time.
+constexpr int P8_RV_IMGS = 5;
+template <int CFG, int FEAT>      // FEAT 0: bias only, 1: + residual, 2: + row vector, 3: generic
+DEVFN void p8_epilogue_t(const GemmParams& p, f32x4 (&acc)[5][4 * (CFG ? 2 : 1)], float* img, int m0, int n0, int wr, int wn0, int li, int lg, int tid) {
     constexpr int BN = CFG ? 320 : 160, MT = CFG ? 8 : 4;
     constexpr int LDI = BN + 4;                  // fp32 image row stride: + 16 bytes, the 8 rows of a b128 write phase fall on 8 distinct slots
+    constexpr int ROWS = CFG ? 64 : 128;         // image rows per pass
     constexpr int CPR = BN / 8;                  // 8-channel chunks per row
-    constexpr int NCH = (CFG ? 64 : 128) * CPR / 512;      // chunks per thread and pass (5)
-    const bf16* __restrict__ res = p.res;
+    constexpr int NCH = ROWS * CPR / 512;        // chunks per thread and pass (5)
+    constexpr int NPASS = MT / 2;
+    constexpr bool GENERIC = FEAT == 3;
+    float* sbias = img + ROWS * LDI;             // [BN]
+    float* srv = sbias + BN;                     // [P8_RV_IMGS][BN]
+    const bool has_res = GENERIC ? p.res != nullptr : FEAT == 1;
+    const bool has_rv = GENERIC ? p.rowvec != nullptr : FEAT == 2;
+    const int flags = GENERIC ? p.flags : 0;
     const float* __restrict__ bias = p.bias;
     const float* __restrict__ rowvec = p.rowvec;
-    const int flags = p.flags;
+    const int esz = (flags & F_OUT_F32) ? 4 : 2;
+    const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(p.C, 0, (int)(((long long)(p.M - 1) * p.ldc + p.N) * esz), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(has_res ? p.res : reinterpret_cast<const bf16*>(p.C)), 0,
+                                                                        has_res ? (int)(((long long)(p.M - 1) * p.ldres + p.N) * 2) : 0, 0x00020000);
+    const int mlast = min(m0 + 255, p.M - 1);
+    const int img0 = has_rv ? m0 / p.rows_per_batch : 0;
+    const int nimg = has_rv ? mlast / p.rows_per_batch - img0 + 1 : 0;
+    const bool rv_lds = has_rv && (!GENERIC || nimg <= P8_RV_IMGS);
+    for (int c = tid; c < BN / 4; c += 512) {
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        *reinterpret_cast<f32x4*>(sbias + c * 4) = bias ? *reinterpret_cast<const f32x4*>(bias + n0 + c * 4) : z;
+    }
+    if (rv_lds)
+        for (int c = tid; c < nimg * (BN / 4); c += 512) {
+            const int k = c / (BN / 4), cc = c - k * (BN / 4);
+            *reinterpret_cast<f32x4*>(srv + k * BN + cc * 4) = *reinterpret_cast<const f32x4*>(rowvec + (size_t)(img0 + k) * p.ldrv + n0 + cc * 4);
+        }
+    int ccol[NCH], clr[NCH];
 #pragma unroll
-    for (int pass = 0; pass < MT / 2; pass++) {
-        // this pass's rows / columns per thread, and the residual loads (the HBM-latency ones) before the image is even written
-        int mrow[NCH], ncol[NCH], ioff[NCH];
-        bool ok[NCH];
-        bf16x8 rs[NCH];
+    for (int i = 0; i < NCH; i++) {
+        const int c = tid + i * 512;
+        clr[i] = c / CPR;
+        ccol[i] = (c - clr[i] * CPR) * 8;
+    }
+    auto chunk_row = [&](int pass, int i) {
+        const int lr = clr[i];
+        return m0 + (CFG ? (pass >> 1) * 128 + (lr >> 5) * 64 + (pass & 1) * 32 + (lr & 31) : (lr >> 5) * 64 + pass * 32 + (lr & 31));
+    };
+    bf16x8 rs[2][NCH];
+    auto request_res = [&](int pass, bf16x8 (&dst)[NCH]) {
 #pragma unroll
         for (int i = 0; i < NCH; i++) {
-            const int c = tid + i * 512;
-            const int lr = c / CPR, col = (c - lr * CPR) * 8;
-            mrow[i] = m0 + (CFG ? (pass >> 1) * 128 + (lr >> 5) * 64 + (pass & 1) * 32 + (lr & 31) : (lr >> 5) * 64 + pass * 32 + (lr & 31));
-            ncol[i] = n0 + col;
-            ioff[i] = lr * LDI + col;
-            ok[i] = mrow[i] < p.M;
-            rs[i] = zero8();
-            if (ok[i] && res) rs[i] = ld8(res + (size_t)mrow[i] * p.ldres + ncol[i]);
+            const int m = chunk_row(pass, i);
+            const unsigned off = m < p.M ? ((unsigned)m * (unsigned)p.ldres + n0 + ccol[i]) * 2u : OOB;
+            dst[i] = has_res ? buf_ld8(rr, off) : zero8();
         }
+    };
+    request_res(0, rs[0]);
+#pragma unroll
+    for (int pass = 0; pass < NPASS; pass++) {
         if (pass) __syncthreads();               // the previous image has been consumed
 #pragma unroll
         for (int h = 0; h < 2; h++) {
@@ -104,36 +142,39 @@ DEVFN void p8_epilogue(const GemmParams& p, f32x4 (&acc)[5][4 * (CFG ? 2 : 1)], 
             for (int ni = 0; ni < 5; ni++)
                 *reinterpret_cast<f32x4*>(row + (ni < 4 ? 32 * (ni >> 1) + lg * 8 + (ni & 1) * 4 : 64 + lg * 4)) = acc[ni][mi];
         }
-        __syncthreads();
-        f32x4 b0[NCH], b1[NCH], r0[NCH], r1[NCH], v0[NCH], v1[NCH];
+        __syncthreads();                         // (pass 0: also publishes sbias / srv)
+        if (pass + 1 < NPASS) request_res(pass + 1, rs[(pass + 1) & 1]);
 #pragma unroll
         for (int i = 0; i < NCH; i++) {
-            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-            b0[i] = b1[i] = r0[i] = r1[i] = z;
-            if (ok[i]) {
-                if (bias) { b0[i] = *reinterpret_cast<const f32x4*>(bias + ncol[i]); b1[i] = *reinterpret_cast<const f32x4*>(bias + ncol[i] + 4); }
-                if (rowvec) {
-                    const float* rv = rowvec + (size_t)(mrow[i] / p.rows_per_batch) * p.ldrv + ncol[i];
-                    r0[i] = *reinterpret_cast<const f32x4*>(rv); r1[i] = *reinterpret_cast<const f32x4*>(rv + 4);
+            const int m = chunk_row(pass, i), col = ccol[i];
+            const bool ok = m < p.M;
+            const float* ip = img + clr[i] * LDI + col;
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(ip), v1 = *reinterpret_cast<const f32x4*>(ip + 4);
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(sbias + col), b1 = *reinterpret_cast<const f32x4*>(sbias + col + 4);
+            f32x4 r0 = {0.f, 0.f, 0.f, 0.f}, r1 = r0;
+            if (has_rv) {
+                const int im = (ok ? m : m0) / p.rows_per_batch;
+                if (rv_lds) {
+                    const float* rv = srv + (im - img0) * BN + col;
+                    r0 = *reinterpret_cast<const f32x4*>(rv); r1 = *reinterpret_cast<const f32x4*>(rv + 4);
+                } else {
+                    const float* rv = rowvec + (size_t)im * p.ldrv + n0 + col;
+                    r0 = *reinterpret_cast<const f32x4*>(rv); r1 = *reinterpret_cast<const f32x4*>(rv + 4);
                 }
             }
-            v0[i] = *reinterpret_cast<const f32x4*>(img + ioff[i]);
-            v1[i] = *reinterpret_cast<const f32x4*>(img + ioff[i] + 4);
-        }
-#pragma unroll
-        for (int i = 0; i < NCH; i++) {
-            if (!ok[i]) continue;
+            const bf16x8 rsv = rs[pass & 1][i];
             float x[8];
 #pragma unroll
             for (int e = 0; e < 8; e++) {
-                float t = (e < 4 ? v0[i][e] : v1[i][e - 4]) * p.alpha + (e < 4 ? b0[i][e] : b1[i][e - 4]);
-                if (rowvec) t += e < 4 ? r0[i][e] : r1[i][e - 4];
-                if (res) t += bf2f(rs[i][e]);
-                if (flags & F_SILU) t = silu_f(t);
+                float t = (e < 4 ? v0[e] : v1[e - 4]) * p.alpha + (e < 4 ? b0[e] : b1[e - 4]);
+                if (has_rv) t += e < 4 ? r0[e] : r1[e - 4];
+                if (has_res) t += bf2f(rsv[e]);
+                if (GENERIC && (flags & F_SILU)) t = silu_f(t);
                 x[e] = t;
             }
-            if (flags & F_OUT_F32) {
-                float* c = reinterpret_cast<float*>(p.C) + (size_t)mrow[i] * p.ldc + ncol[i];
+            if (GENERIC && (flags & F_OUT_F32)) {
+                if (!ok) continue;
+                float* c = reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n0 + col;
                 if (flags & F_ACCUM) {
                     const f32x4 c0 = *reinterpret_cast<const f32x4*>(c), c1 = *reinterpret_cast<const f32x4*>(c + 4);
 #pragma unroll
@@ -145,10 +186,21 @@ DEVFN void p8_epilogue(const GemmParams& p, f32x4 (&acc)[5][4 * (CFG ? 2 : 1)], 
                 bf16x8 o;
 #pragma unroll
                 for (int e = 0; e < 8; e++) o[e] = f2bf(x[e]);
-                st8(reinterpret_cast<bf16*>(p.C) + (size_t)mrow[i] * p.ldc + ncol[i], o);
+                const unsigned off = ok ? ((unsigned)m * (unsigned)p.ldc + n0 + col) * 2u : OOB;
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rc, off, 0, 0);
             }
         }
     }
+}
+
+template <int CFG>
+DEVFN void p8_epilogue(const GemmParams& p, f32x4 (&acc)[5][4 * (CFG ? 2 : 1)], float* img, int m0, int n0, int wr, int wn0, int li, int lg, int tid) {
+    const bool plain = !(p.flags & (F_SILU | F_OUT_F32 | F_ACCUM));
+    const int nimg = p.rowvec ? min(m0 + 255, p.M - 1) / p.rows_per_batch - m0 / p.rows_per_batch + 1 : 0;
+    if (plain && !p.rowvec && !p.res) p8_epilogue_t<CFG, 0>(p, acc, img, m0, n0, wr, wn0, li, lg, tid);
+    else if (plain && !p.rowvec) p8_epilogue_t<CFG, 1>(p, acc, img, m0, n0, wr, wn0, li, lg, tid);
+    else if (plain && !p.res && nimg <= P8_RV_IMGS) p8_epilogue_t<CFG, 2>(p, acc, img, m0, n0, wr, wn0, li, lg, tid);
+    else p8_epilogue_t<CFG, 3>(p, acc, img, m0, n0, wr, wn0, li, lg, tid);
 }
 
 template <int MODE, int CFG>   // MODE 0 dense rows, 1 conv3x3 (Cin % 64 == 0, no upsampling)
@@ -421,6 +473,8 @@ static bool p8_ok(const GemmParams& p, int cfg) {
     if ((p.ldc & 7) || ((uintptr_t)p.C & 15) || (p.res && ((p.ldres & 7) || ((uintptr_t)p.res & 15)))) return false;
     if (p.rowvec && ((p.ldrv & 3) || ((uintptr_t)p.rowvec & 15) || p.rows_per_batch <= 0)) return false;
     if ((p.bias && ((uintptr_t)p.bias & 15)) || (p.Mg && p.bias1 && ((uintptr_t)p.bias1 & 15))) return false;
+    const long long mrows = p.Mtot > p.M ? p.Mtot : p.M;          // (C / res are addressed through 31-bit buffer descriptors)
+    if (((mrows - 1) * p.ldc + p.N) * ((p.flags & F_OUT_F32) ? 4 : 2) >= 0x7FFFFFFFll || (p.res && ((mrows - 1) * p.ldres + p.N) * 2 >= 0x7FFFFFFFll)) return false;
     return true;
 }
 

@@ -132,12 +132,29 @@ __global__ void gn_apply_kernel(const T* __restrict__ x, const float* __restrict
         sh[e] = beta[ch] - sm[grp] * sc[e];
     }
     const int p0 = chunk * g.ppb, p1 = min(g.HW, p0 + g.ppb);
-    const size_t base = (size_t)b * g.HW * g.C + cc * 8;
+    // Branch-free, prefetching row loop (see ln_fwd_kernel): descriptors over this SAMPLE's [HW][C] slab, pixel rows >= p1 get an
+    // out-of-range offset (zeros in, store dropped), and the next GN_U rows are requested before the current ones are stored --
+    // "load; normalise; store" per iteration made every iteration's loads wait for the previous iteration's stores.
+    const __amdgpu_buffer_rsrc_t rx = mk_buf(x + (size_t)b * g.HW * g.C, (long long)g.HW * g.C * sizeof(T));
+    const __amdgpu_buffer_rsrc_t ry = mk_buf(reinterpret_cast<unsigned char*>(y) + (size_t)b * g.HW * g.C * (F8 ? 1 : sizeof(T)),
+                                             (long long)g.HW * g.C * (F8 ? 1 : sizeof(T)));
+    auto off = [&](int p) { return p < p1 ? (unsigned)p * (unsigned)g.C + cc * 8 : SIDLSG_OOB; };
+    // (the wait for the prefetched rows -- the unpack -- sits at the END of the body, behind the stores: at the loop header the
+    // compiler would merge the entry state (loads only) with the back edge (loads + stores) into s_waitcnt vmcnt(0); the
+    // sched_barrier keeps the scheduler from sinking the requests below the stores)
+    Raw8<T> raw[GN_U];
+    float v[GN_U][8];
     int p = p0 + rl;
-    for (; p + (GN_U - 1) * g.rows < p1; p += GN_U * g.rows) {
-        float v[GN_U][8];
+    if (p >= p1) return;
 #pragma unroll
-        for (int u = 0; u < GN_U; u++) ldv8<T>(x + base + (size_t)(p + u * g.rows) * g.C, v[u]);
+    for (int u = 0; u < GN_U; u++) Raw8_bload(raw[u], rx, off(p + u * g.rows));
+#pragma unroll
+    for (int u = 0; u < GN_U; u++) raw[u].unpack(v[u]);
+    do {
+        const int pn = p + GN_U * g.rows;
+#pragma unroll
+        for (int u = 0; u < GN_U; u++) Raw8_bload(raw[u], rx, off(pn + u * g.rows));
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int u = 0; u < GN_U; u++) {
 #pragma unroll
@@ -146,20 +163,13 @@ __global__ void gn_apply_kernel(const T* __restrict__ x, const float* __restrict
                 if (act) f = silu_t<T>(f);
                 v[u][e] = f;
             }
-            st8_out<T, F8>(y, base + (size_t)(p + u * g.rows) * g.C, v[u]);
+            bst8_out<T, F8>(ry, off(p + u * g.rows), v[u]);
         }
-    }
-    for (; p < p1; p += g.rows) {
-        float v[8];
-        ldv8<T>(x + base + (size_t)p * g.C, v);
+        __builtin_amdgcn_sched_barrier(0);       // (... and from hoisting the unpack, i.e. the wait, above the stores)
 #pragma unroll
-        for (int e = 0; e < 8; e++) {
-            float f = v[e] * sc[e] + sh[e];
-            if (act) f = silu_t<T>(f);
-            v[e] = f;
-        }
-        st8_out<T, F8>(y, base + (size_t)p * g.C, v);
-    }
+        for (int u = 0; u < GN_U; u++) raw[u].unpack(v[u]);
+        p = pn;
+    } while (p < p1);
 }
 
 template <typename T>
@@ -227,8 +237,8 @@ __global__ void gn_bwd_stats_kernel(const T* __restrict__ x, const T* __restrict
     }
 }
 
-template <typename T>
-__global__ void gn_bwd_apply_kernel(const T* __restrict__ x, const T* __restrict__ dy,
+template <typename T, bool ACT>      // ACT (SiLU behind the norm) is a template parameter: a run-time `if (act)` per element is control flow inside the row loop,
+__global__ void gn_bwd_apply_kernel(const T* __restrict__ x, const T* __restrict__ dy,      // behind which the compiler waits s_waitcnt vmcnt(0)
                                     const float* __restrict__ stats, const float* __restrict__ gamma,
                                     const float* __restrict__ beta, const float* __restrict__ part,
                                     const T* __restrict__ add, T* __restrict__ dx, GnGeom g, int act,
@@ -254,39 +264,44 @@ __global__ void gn_bwd_apply_kernel(const T* __restrict__ x, const T* __restrict
         ga[e] = gamma[ch]; be[e] = beta[ch]; m1[e] = sm[grp]; m2[e] = sm[g.G + grp];
     }
     const int p0 = chunk * g.ppb, p1 = min(g.HW, p0 + g.ppb);
-    const size_t base = (size_t)b * g.HW * g.C + cc * 8;
-    int p = p0 + rl;
-    for (; p + g.rows < p1; p += 2 * g.rows) {
-        float xv[2][8], dv[2][8];
+    // branch-free, prefetching row loop (see gn_apply_kernel / ln_fwd_kernel); `add` == null is a descriptor of zero records
+    const size_t sb = (size_t)b * g.HW * g.C;
+    const long long sbytes = (long long)g.HW * g.C * sizeof(T);
+    const __amdgpu_buffer_rsrc_t rx = mk_buf(x + sb, sbytes), rdy = mk_buf(dy + sb, sbytes), rdx = mk_buf(dx + sb, sbytes);
+    const __amdgpu_buffer_rsrc_t radd = mk_buf(add ? add + sb : x, add ? sbytes : 0);
+    auto off = [&](int p) { return p < p1 ? (unsigned)p * (unsigned)g.C + cc * 8 : SIDLSG_OOB; };
+    // (rows stay RAW until they are used -- two raw sets instead of a raw set + unpacked floats: the kernel may run with 1024-thread
+    // blocks, i.e. 128 registers, and 48 of them hold the per-channel constants)
+    struct Rows { Raw8<T> x[2], dy[2], add[2]; };
+    auto request = [&](int p, Rows& r) {
 #pragma unroll
-        for (int u = 0; u < 2; u++) { ldv8<T>(x + base + (size_t)(p + u * g.rows) * g.C, xv[u]); ldv8<T>(dy + base + (size_t)(p + u * g.rows) * g.C, dv[u]); }
+        for (int u = 0; u < 2; u++) { const unsigned o = off(p + u * g.rows); Raw8_bload(r.x[u], rx, o); Raw8_bload(r.dy[u], rdy, o); Raw8_bload(r.add[u], radd, o); }
+    };
+    int p = p0 + rl;
+    if (p >= p1) return;
+    Rows cur, nxt;
+    request(p, cur);
+    do {
+        const int pn = p + 2 * g.rows;
+        request(pn, nxt);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int u = 0; u < 2; u++) {
-            float o[8], av[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (add) ldv8<T>(add + base + (size_t)(p + u * g.rows) * g.C, av);
+            float o[8], xv[8], dv[8], av[8];
+            cur.x[u].unpack(xv); cur.dy[u].unpack(dv); cur.add[u].unpack(av);
 #pragma unroll
             for (int e = 0; e < 8; e++) {
-                const float xh = (xv[u][e] - mu[e]) * rs[e];
-                float d = dv[u][e];
-                if (act) d *= silu_grad_t<T>(xh * ga[e] + be[e]);
+                const float xh = (xv[e] - mu[e]) * rs[e];
+                float d = dv[e];
+                if (ACT) d *= silu_grad_t<T>(xh * ga[e] + be[e]);
                 o[e] = rs[e] * (d * ga[e] - m1[e] - xh * m2[e]) + av[e];
             }
-            stv8<T>(dx + base + (size_t)(p + u * g.rows) * g.C, o);
+            bst8_out<T, false>(rdx, off(p + u * g.rows), o);
         }
-    }
-    for (; p < p1; p += g.rows) {
-        float xv[8], dv[8], o[8], av[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        ldv8<T>(x + base + (size_t)p * g.C, xv); ldv8<T>(dy + base + (size_t)p * g.C, dv);
-        if (add) ldv8<T>(add + base + (size_t)p * g.C, av);
-#pragma unroll
-        for (int e = 0; e < 8; e++) {
-            const float xh = (xv[e] - mu[e]) * rs[e];
-            float d = dv[e];
-            if (act) d *= silu_grad_t<T>(xh * ga[e] + be[e]);
-            o[e] = rs[e] * (d * ga[e] - m1[e] - xh * m2[e]) + av[e];
-        }
-        stv8<T>(dx + base + (size_t)p * g.C, o);
-    }
+        __builtin_amdgcn_sched_barrier(0);
+        cur = nxt;
+        p = pn;
+    } while (p < p1);
 }
 
 // dgamma[i] += sum_p part[p][i][0], dbeta[i] += sum_p part[p][i][1] in ONE launch (the partials are (d.xhat, d) pairs):
@@ -411,19 +426,25 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
         for (int e = 0; e < 8; e++) { ga[i][e] = cc < C8 ? gamma[cc * 8 + e] : 0.f; be[i][e] = cc < C8 ? beta[cc * 8 + e] : 0.f; }
     }
     const float invC = 1.0f / (float)C;
-    for (int r0 = rbeg; r0 < rend; r0 += R) {
-        float v[R][NCH][8];
+    // gfx950 retires loads and stores through ONE in-order counter: a load issued behind a row group's stores cannot be waited for
+    // before those stores are acknowledged, so "load R rows; normalise; store; next group" paid a load AND a store round trip per
+    // group and wave (and with the loads inside `if (valid) ... else zeros` the compiler waited for each ROW at the end of its branch).
+    // Now: every access is branch-free (buffer descriptors: out-of-range offsets read zeros / drop the store), the loads stay raw
+    // registers until they are unpacked, and the next group is requested BEFORE the current one is stored -- the wait for it then
+    // leaves the stores in flight.  The last group is peeled (no wasted prefetch, no branch inside the loop body).
+    const __amdgpu_buffer_rsrc_t rx = mk_buf(x, (long long)rows * C * sizeof(T));
+    const __amdgpu_buffer_rsrc_t ry = mk_buf(y, (long long)rows * C * (F8 ? 1 : sizeof(T)));
+    const __amdgpu_buffer_rsrc_t rst = mk_buf(stats, stats ? (long long)rows * 8 : 0);
+    auto load_group = [&](int r0, Raw8<T> (&raw)[R][NCH]) {
 #pragma unroll
         for (int r = 0; r < R; r++)
 #pragma unroll
             for (int i = 0; i < NCH; i++) {
                 const int cc = lane + 64 * i;
-                if (r0 + r < rend && cc < C8) ldv8<T>(x + (size_t)(r0 + r) * C + cc * 8, v[r][i]);
-                else {
-#pragma unroll
-                    for (int e = 0; e < 8; e++) v[r][i][e] = 0.f;
-                }
+                Raw8_bload(raw[r][i], rx, (r0 + r < rend && cc < C8) ? (unsigned)(r0 + r) * (unsigned)C + cc * 8 : SIDLSG_OOB);
             }
+    };
+    auto finish_group = [&](int r0, const float (&v)[R][NCH][8]) {
         float mean[R], rstd[R];
 #pragma unroll
         for (int r = 0; r < R; r++) {
@@ -441,11 +462,9 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
             float q = 0.f;
 #pragma unroll
             for (int i = 0; i < NCH; i++) {
-                const int cc = lane + 64 * i;
-                if (cc < C8) {
+                const float in = lane + 64 * i < C8 ? 1.f : 0.f;       // (pad lanes hold zeros: their (0 - mean)^2 must not count)
 #pragma unroll
-                    for (int e = 0; e < 8; e++) { const float d = v[r][i][e] - mean[r]; q += d * d; }
-                }
+                for (int e = 0; e < 8; e++) { const float d = v[r][i][e] - mean[r]; q += in * d * d; }
             }
             rstd[r] = q;
         }
@@ -454,20 +473,38 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
 #pragma unroll
         for (int r = 0; r < R; r++) {
             const int row = r0 + r;
-            if (row >= rend) break;
-            if (lane == 0 && stats) { stats[(size_t)row * 2] = mean[r]; stats[(size_t)row * 2 + 1] = rstd[r]; }
+            const bool okr = row < rend;
+            __builtin_amdgcn_raw_buffer_store_b64((u32x2){__float_as_uint(mean[r]), __float_as_uint(rstd[r])}, rst,
+                                                  (okr && lane == 0) ? (unsigned)row * 8u : SIDLSG_OOB, 0, 0);
 #pragma unroll
             for (int i = 0; i < NCH; i++) {
                 const int cc = lane + 64 * i;
-                if (cc < C8) {
-                    float o[8];
+                float o[8];
 #pragma unroll
-                    for (int e = 0; e < 8; e++) o[e] = (v[r][i][e] - mean[r]) * rstd[r] * ga[i][e] + be[i][e];
-                    st8_out<T, F8>(y, (size_t)row * C + cc * 8, o);
-                }
+                for (int e = 0; e < 8; e++) o[e] = (v[r][i][e] - mean[r]) * rstd[r] * ga[i][e] + be[i][e];
+                bst8_out<T, F8>(ry, (okr && cc < C8) ? (unsigned)row * (unsigned)C + cc * 8 : SIDLSG_OOB, o);
             }
         }
+    };
+    auto unpack = [&](const Raw8<T> (&raw)[R][NCH], float (&v)[R][NCH][8]) {
+#pragma unroll
+        for (int r = 0; r < R; r++)
+#pragma unroll
+            for (int i = 0; i < NCH; i++) raw[r][i].unpack(v[r][i]);
+    };
+    Raw8<T> raw[R][NCH];
+    float v[R][NCH][8];
+    load_group(rbeg, raw);
+    unpack(raw, v);
+    int r0 = rbeg;
+    for (; r0 + R < rend; r0 += R) {
+        load_group(r0 + R, raw);
+        __builtin_amdgcn_sched_barrier(0);       // (keep the scheduler from sinking the requests below the stores)
+        finish_group(r0, v);
+        __builtin_amdgcn_sched_barrier(0);       // (... and from hoisting the unpack, i.e. the wait, above the stores)
+        unpack(raw, v);
     }
+    finish_group(r0, v);
 }
 
 // dx = rstd*(dy*gamma - mean(dy*gamma) - xhat*mean(dy*gamma*xhat)); per-block partial dgamma/dbeta.
@@ -492,39 +529,50 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ x, co
         }
     const float invC = 1.0f / (float)C;
     const int rbeg = blockIdx.x * rows_per_block, rend = min(rows, rbeg + rows_per_block);
-    for (int r0 = rbeg + wave * R; r0 < rend; r0 += 4 * R) {
-        float xv[R][NCH][8], dv[R][NCH][8];
-        float mean[R], rstd[R];
+    // Same structure as ln_fwd_kernel: branch-free accesses through buffer descriptors (rows >= rend / pad lanes read zeros, their
+    // stores are dropped; `add` == null is a descriptor of zero records), every load of a row group -- x, dy, the residual-branch
+    // gradient and the statistics -- issued together and kept raw, and the NEXT group requested before the current one is stored.
+    // (The former loop fetched `add` chunk by chunk between the stores: each chunk waited for the previous chunk's store.)
+    const __amdgpu_buffer_rsrc_t rx = mk_buf(x, (long long)rows * C * sizeof(T)), rdy = mk_buf(dy, (long long)rows * C * sizeof(T));
+    const __amdgpu_buffer_rsrc_t radd = mk_buf(add ? add : x, add ? (long long)rows * C * sizeof(T) : 0);
+    const __amdgpu_buffer_rsrc_t rdx = mk_buf(dx, (long long)rows * C * sizeof(T)), rst = mk_buf(stats, (long long)rows * 8);
+    struct Group { Raw8<T> x[R][NCH], dy[R][NCH], add[R][NCH]; u32x2 st[R]; };
+    auto load_group = [&](int r0, Group& g) {
 #pragma unroll
         for (int r = 0; r < R; r++) {
-            const bool ok = r0 + r < rend;
-            mean[r] = ok ? stats[(size_t)(r0 + r) * 2] : 0.f;
-            rstd[r] = ok ? stats[(size_t)(r0 + r) * 2 + 1] : 0.f;
+            const bool okr = r0 + r < rend;
+            g.st[r] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rst, okr ? (unsigned)(r0 + r) * 8u : SIDLSG_OOB, 0, 0));
 #pragma unroll
             for (int i = 0; i < NCH; i++) {
                 const int cc = lane + 64 * i;
-                const bool okc = ok && cc < C8;
-                if (okc) { ldv8<T>(x + (size_t)(r0 + r) * C + cc * 8, xv[r][i]); ldv8<T>(dy + (size_t)(r0 + r) * C + cc * 8, dv[r][i]); }
-                else {
-#pragma unroll
-                    for (int e = 0; e < 8; e++) xv[r][i][e] = dv[r][i][e] = 0.f;
-                }
+                const unsigned o = (okr && cc < C8) ? (unsigned)(r0 + r) * (unsigned)C + cc * 8 : SIDLSG_OOB;
+                Raw8_bload(g.x[r][i], rx, o);
+                Raw8_bload(g.dy[r][i], rdy, o);
+                Raw8_bload(g.add[r][i], radd, o);
             }
         }
-        float s1[R], s2[R];
+    };
+    // (the group stays RAW -- 12 registers per 8 elements of x, dy, add -- and is converted where it is used, twice: two register sets of
+    // unpacked floats next to the partial-sum accumulators cost the wide variants their occupancy: 312 registers at NCH = 2)
+    auto finish_group = [&](int r0, const Group& g) {
+        float s1[R], s2[R], mean[R], rstd[R];
 #pragma unroll
         for (int r = 0; r < R; r++) {
+            mean[r] = __uint_as_float(g.st[r][0]); rstd[r] = __uint_as_float(g.st[r][1]);      // zero rows: mean = rstd = 0 -> xh = 0
             float a = 0.f, c = 0.f;
 #pragma unroll
-            for (int i = 0; i < NCH; i++)
+            for (int i = 0; i < NCH; i++) {
+                float xv[8], dv[8];
+                g.x[r][i].unpack(xv); g.dy[r][i].unpack(dv);
 #pragma unroll
                 for (int e = 0; e < 8; e++) {
-                    const float xh = (xv[r][i][e] - mean[r]) * rstd[r];     // zero rows: mean = rstd = 0 -> xh = 0
-                    const float d = dv[r][i][e];
+                    const float xh = (xv[e] - mean[r]) * rstd[r];
+                    const float d = dv[e];
                     pg[i][e] += d * xh; pb[i][e] += d;
                     const float dg = d * ga[i][e];
                     a += dg; c += dg * xh;
                 }
+            }
             s1[r] = a; s2[r] = c;
         }
 #pragma unroll
@@ -532,22 +580,32 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ x, co
 #pragma unroll
         for (int r = 0; r < R; r++) {
             const int row = r0 + r;
-            if (row >= rend) break;
 #pragma unroll
             for (int i = 0; i < NCH; i++) {
                 const int cc = lane + 64 * i;
-                if (cc < C8) {
-                    float o[8], av[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-                    if (add) ldv8<T>(add + (size_t)row * C + cc * 8, av);       // residual-branch gradient, summed here
+                float o[8], xv[8], dv[8], a8[8];
+                g.x[r][i].unpack(xv); g.dy[r][i].unpack(dv); g.add[r][i].unpack(a8);
 #pragma unroll
-                    for (int e = 0; e < 8; e++) {
-                        const float xh = (xv[r][i][e] - mean[r]) * rstd[r];
-                        o[e] = rstd[r] * (dv[r][i][e] * ga[i][e] - s1[r] - xh * s2[r]) + av[e];
-                    }
-                    stv8<T>(dx + (size_t)row * C + cc * 8, o);
+                for (int e = 0; e < 8; e++) {
+                    const float xh = (xv[e] - mean[r]) * rstd[r];
+                    o[e] = rstd[r] * (dv[e] * ga[i][e] - s1[r] - xh * s2[r]) + a8[e];
                 }
+                bst8_out<T, false>(rdx, (row < rend && cc < C8) ? (unsigned)row * (unsigned)C + cc * 8 : SIDLSG_OOB, o);
             }
         }
+    };
+    int r0 = rbeg + wave * R;
+    if (r0 < rend) {
+        Group cur, nxt;
+        load_group(r0, cur);
+        for (; r0 + 4 * R < rend; r0 += 4 * R) {
+            load_group(r0 + 4 * R, nxt);
+            __builtin_amdgcn_sched_barrier(0);   // (keep the scheduler from sinking the requests below the stores)
+            finish_group(r0, cur);
+            __builtin_amdgcn_sched_barrier(0);
+            cur = nxt;
+        }
+        finish_group(r0, cur);
     }
     if (part) {
 #pragma unroll
@@ -1122,7 +1180,9 @@ static int groupnorm_bwd_t(const void* x, const void* dy, const float* stats, co
     const int threads = g.C8 * g.rows;
     SIDLSG_LAUNCH(gn_bwd_stats_kernel<T>, dim3(g.nch, B), dim3(threads), (size_t)g.rows * C * 2 * sizeof(float), s,
                        (const T*)x, (const T*)dy, stats, gamma, beta, ws, g, silu, gamma1, beta1, B / 2);
-    SIDLSG_LAUNCH(gn_bwd_apply_kernel<T>, dim3(g.nch, B), dim3(threads), (size_t)2 * G * (1 + GN_FOLD) * sizeof(float), s,
+    if (silu) SIDLSG_LAUNCH((gn_bwd_apply_kernel<T, true>), dim3(g.nch, B), dim3(threads), (size_t)2 * G * (1 + GN_FOLD) * sizeof(float), s,
+                       (const T*)x, (const T*)dy, stats, gamma, beta, ws, (const T*)dres, (T*)dx, g, silu, gamma1, beta1, B / 2);
+    else SIDLSG_LAUNCH((gn_bwd_apply_kernel<T, false>), dim3(g.nch, B), dim3(threads), (size_t)2 * G * (1 + GN_FOLD) * sizeof(float), s,
                        (const T*)x, (const T*)dy, stats, gamma, beta, ws, (const T*)dres, (T*)dx, g, silu, gamma1, beta1, B / 2);
     if (dgamma && dbeta) {
         const int P = B * g.nch;

@@ -6,6 +6,10 @@ import ctypes
 import torch
 
 
+# the reference plugin takes fp64 / fp32 / fp16 (bias_act.cpp:77); bf16 is this package's production activation type
+_DTYPES = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2, torch.float64: 3}
+
+
 def bind(dll):
     fn = dll.bias_act_plugin_launch
     fn.restype = ctypes.c_int
@@ -23,7 +27,7 @@ def bind(dll):
         src = x if grad == 0 else xref
         if not src.is_cuda:
             raise RuntimeError('bias_act plugin: tensors must be on the GPU')
-        if src.dtype not in (torch.float32, torch.bfloat16):
+        if src.dtype not in _DTYPES:
             raise RuntimeError(f'bias_act plugin: unsupported dtype {src.dtype}')
         src = src.contiguous()
         out = torch.empty_like(src)
@@ -35,7 +39,7 @@ def bind(dll):
         g1 = g1.contiguous().to(src.dtype) if (grad >= 1) else None
         g2 = x.contiguous().to(src.dtype) if grad == 2 else None
         rc = fn(src.data_ptr(), ptr(bb), ptr(g1), ptr(g2), out.data_ptr(), src.numel(), step, src.shape[dim] if src.ndim else 1,
-                int(act), float(alpha), float(gain), float(clamp), int(grad), {torch.float32: 0, torch.bfloat16: 1}[src.dtype],
+                int(act), float(alpha), float(gain), float(clamp), int(grad), _DTYPES[src.dtype],
                 torch.cuda.current_stream().cuda_stream)
         if rc != 0:
             raise RuntimeError(f'bias_act_plugin_launch failed with code {rc}')

@@ -25,6 +25,11 @@ _DEFAULT_FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-share
 
 def get_plugin(module_name, sources, build_directory=None, extra_cflags=(), headers=(), **build_kwargs):
     assert verbosity in ['none', 'brief', 'full']
+    if build_kwargs:
+        # the reference forwards **build_kwargs to torch.utils.cpp_extension.load (custom_ops.py:46); this loader drives hipcc itself and
+        # has no use for them -- silently dropping e.g. extra_cuda_cflags / with_cuda would hide a build the caller did not get
+        raise TypeError(f'get_plugin: unsupported build option(s) {sorted(build_kwargs)} (this loader takes sources, build_directory, '
+                        'extra_cflags, headers)')
     if module_name in _cached_plugins:
         return _cached_plugins[module_name]
     if verbosity != 'none':

@@ -810,6 +810,15 @@ def test_bias_act_matches_reference_golden(dev, golden_dir):
     # bf16 tensors go through the same plugin
     yb = ba.bias_act(x.to(BF16), b.to(BF16), dim=1, act='swish')
     close(yb, torch.from_numpy(g['swish_gNone_cNone_y']), 1.2e-2, 'bf16 swish')
+    # the reference plugin's own dtypes (AT_DISPATCH_FLOATING_TYPES_AND_HALF, bias_act.cpp:77): fp16 and fp64 tensors, same golden
+    yh = ba.bias_act(x.to(torch.float16), b.to(torch.float16), dim=1, act='swish')
+    assert yh.dtype == torch.float16
+    close(yh, torch.from_numpy(g['swish_gNone_cNone_y']), 2e-3, 'fp16 swish')
+    yd = ba.bias_act(x.double(), b.double(), dim=1, act='swish')
+    assert yd.dtype == torch.float64
+    close(yd, torch.from_numpy(g['swish_gNone_cNone_y']), 1e-5, 'fp64 swish')
+    with pytest.raises(TypeError):
+        custom_ops.get_plugin('bias_act_plugin', sources=['x'], with_cuda=True)      # unknown build options are refused, not dropped
 
 
 @pytest.mark.parametrize('heads,d', [(2, 40), (2, 64)])
