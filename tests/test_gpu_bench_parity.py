@@ -56,13 +56,18 @@ def test_bench_workload_bf16_matches_stored_fp32_losses(dev):
 
 
 def test_fp32_mode_matches_the_cpu_oracle_at_the_bench_workload(dev):
-    """The bench workload against the fp32 CPU oracle DIRECTLY: (a) the inputs bench.py draws for iteration 0
-    are the committed fixture the oracle ran on, bit for bit, and the weights are the CPU-seeded ones (checksum); (b) the HIP fp32
-    mode at batch_gpu 8 is within north_star's 1e-3 of the oracle's losses (observed ~1e-7); (c) the stored fp32-mode values are
-    not stale (iterations 0 and 1 re-derived live, 1e-5: fp32 atomics order)."""
+    """The bench workload against the fp32 CPU oracle DIRECTLY: (a) the inputs bench.py draws for
+    iterations 0, 1, 2 are the committed fixtures the oracle ran on, bit for bit, and the weights are the CPU-seeded ones (checksum);
+    (b) the HIP fp32 mode at batch_gpu 8 is within north_star's 1e-3 of the ORACLE's losses on all three iterations -- i.e. after the
+    fake-score and generator Adam steps too (the oracle carried its weights and Adam state across iterations:
+    oracle/make_bench_oracle_reference.py --iterations 3; observed 4e-8 ... 2e-6); (c) the stored fp32-mode values are not stale
+    (re-derived live, 1e-5 / 1e-4: fp32 atomics order)."""
     import numpy as np
     import bench
     ref = _reference()
+    orc = ref['oracle_fp32']
+    n_orc = len(orc['loss_fake'])
+    assert n_orc >= 3, 'the oracle reference of the bench workload holds iterations 0-2 since round 6'
     fx = np.load(os.path.join(ROOT, 'tests', 'golden', 'bench_it0_inputs.npz'))
     S = bench.setup_step('sd15', 8, 512, 1.5, dev, compute_dtype=torch.float32)
     p = S.phi.flat_params.double()
@@ -70,18 +75,20 @@ def test_fp32_mode_matches_the_cpu_oracle_at_the_bench_workload(dev):
     assert abs(float(p.abs().sum()) - float(fx['weights_abs_sum'])) < 1e-9 * float(fx['weights_abs_sum'])
     del p
     S16 = bench.setup_step('sd15', 8, 512, 1.5, dev)          # the text states of the bench are bf16: compare in the bench's own mode
-    inputs, _ = S16.prepare(0)
-    torch.cuda.synchronize()
-    for ph in ('A', 'B'):
-        (r,) = inputs[ph]
-        assert np.array_equal(r['z'].cpu().numpy(), fx[f'{ph}_z']) and np.array_equal(r['noise'].cpu().numpy(), fx[f'{ph}_noise'])
-        assert np.array_equal(r['t'].cpu().numpy(), fx[f'{ph}_t'])
-        assert np.array_equal(r['cond'].contiguous().view(torch.int16).cpu().numpy(), fx[f'{ph}_cond_bf16'])
-        assert np.array_equal(r['uncond'][:1].contiguous().view(torch.int16).cpu().numpy(), fx[f'{ph}_uncond_bf16'])
-    del S16, inputs
+    for it in range(n_orc):
+        fxi = fx if it == 0 else np.load(os.path.join(ROOT, 'tests', 'golden', f'bench_it{it}_inputs.npz'))
+        inputs, _ = S16.prepare(it)
+        torch.cuda.synchronize()
+        for ph in ('A', 'B'):
+            (r,) = inputs[ph]
+            assert np.array_equal(r['z'].cpu().numpy(), fxi[f'{ph}_z']) and np.array_equal(r['noise'].cpu().numpy(), fxi[f'{ph}_noise'])
+            assert np.array_equal(r['t'].cpu().numpy(), fxi[f'{ph}_t'])
+            assert np.array_equal(r['cond'].contiguous().view(torch.int16).cpu().numpy(), fxi[f'{ph}_cond_bf16'])
+            assert np.array_equal(r['uncond'][:1].contiguous().view(torch.int16).cpu().numpy(), fxi[f'{ph}_uncond_bf16'])
+        del inputs
+    del S16
     torch.cuda.empty_cache()
-    orc = ref['oracle_fp32']
-    for it in range(2):
+    for it in range(n_orc):
         lf, lg = S.one_iteration(it)
         ef = abs(float(lf) - ref['loss_fake'][it]) / abs(ref['loss_fake'][it])
         eg = abs(float(lg) - ref['loss_G'][it]) / abs(ref['loss_G'][it])
