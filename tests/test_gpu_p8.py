@@ -64,6 +64,12 @@ def v3_runs_unsplit(M, N, K):
     return N % 160 == 0 and ((M + 127) // 128) * (N // 160) >= 256
 
 
+def p8_runs_unsplit(mode, M, N, K):
+    """The FORCED p8 configurations split K towards one block per CU (gemm.hip::dispatch_gemm: fewer than 192 tiles of 256 x 320 / 256 x 160
+    and at least 24 K-tiles): a split launch sums its slabs in another order than gemm_v3_kernel's single accumulation chain."""
+    return ((M + 255) // 256) * (N // (320 if mode == 2 else 160)) >= 192 or (K // 64) // 12 < 2
+
+
 @pytest.mark.parametrize('B,H,Cin,Cout,stride', CONV)
 @pytest.mark.parametrize('mode', [1, 2])
 def test_conv_forced(dev, p8, mode, B, H, Cin, Cout, stride):
@@ -85,7 +91,7 @@ def test_conv_forced(dev, p8, mode, B, H, Cin, Cout, stride):
         y8 = ops.conv3x3(xd, wd, stride=stride, **kw)
         r = ref + (bias if 'bias' in kw else 0) + (res.float() if 'res' in kw else 0) + (rv[:, None, None, :] if 'rowvec' in kw else 0)
         close(y8, r, 2e-3 if kw.get('out_f32') else 1.2e-2, f'conv {name}')
-        if v3_runs_unsplit(ref.shape[0] * ref.shape[1] * ref.shape[2], Cout, 9 * Cin):
+        if v3_runs_unsplit(ref.shape[0] * ref.shape[1] * ref.shape[2], Cout, 9 * Cin) and p8_runs_unsplit(mode, ref.shape[0] * ref.shape[1] * ref.shape[2], Cout, 9 * Cin):
             assert torch.equal(y8, y3), f'conv {name}: not bit-identical to gemm_v3_kernel'
     # race screen: 20 launches, one answer
     p8.set(mode)
@@ -115,7 +121,7 @@ def test_gemm_forced(dev, p8, mode, M, N, K):
         p8.set(mode)
         y8 = ops.gemm(ad, wd, **kw)
         close(y8, r, 2e-3 if kw.get('out_f32') else 1.2e-2, f'gemm {name}')
-        if v3_runs_unsplit(M, N, K):
+        if v3_runs_unsplit(M, N, K) and p8_runs_unsplit(mode, M, N, K):
             assert torch.equal(y8, y3), f'gemm {name}: not bit-identical to gemm_v3_kernel'
     # SiLU and fp32 accumulate through the raw entry point (flags 2 / 1 | 4)
     p8.set(mode)
@@ -142,8 +148,8 @@ def test_grouped_conv_forced(dev, p8, mode):
     ya = ops.conv3x3(x[:B // 2].contiguous(), w0, bias=b0, res=res[:B // 2].contiguous())
     yb = ops.conv3x3(x[B // 2:].contiguous(), w1, bias=b1, res=res[B // 2:].contiguous())
     assert torch.equal(y[:B // 2], ya) and torch.equal(y[B // 2:], yb)
-    p8.set(0)
-    assert torch.equal(ops.conv3x3(x, ops.Pair(w0, w1), bias=ops.Pair(b0, b1), res=res), y)
+    p8.set(0)      # 12 tiles of 128 x 160: dispatch_gemm takes gemm_bf16_kernel here (tap-major K order), so equal up to the summation order only
+    close(ops.conv3x3(x, ops.Pair(w0, w1), bias=ops.Pair(b0, b1), res=res), y, 1.2e-2, 'grouped conv: p8 vs the default kernels')
 
 
 def test_rule_takes_the_wide_tile_for_the_big_convs(dev, p8):
