@@ -139,3 +139,41 @@ class StandInDetector(torch.nn.Module):
         x = F.conv2d(img.to(torch.float32) / 255.0 - 0.5, self.w, stride=8)
         x = torch.tanh(x).mean(dim=(2, 3))
         return x @ self.mix
+
+
+# ---- one SiD iteration on seeded inputs: shared by tests/test_gpu_unet.py (live oracle) and oracle/make_fullsize_fixtures.py (stored oracle) ----
+def iteration_inputs(cfg_name, lat, b, rounds, gen):
+    """The (z, noise, t, cond, uncond) draws of one iteration -- phase A rounds, then phase B rounds -- from `gen` (a CPU generator)."""
+    cfg = CONFIGS[cfg_name]
+    bf = torch.bfloat16
+    inputs = dict(A=[], B=[])
+    for ph in ('A', 'B'):
+        for _ in range(rounds):
+            inputs[ph].append(dict(z=torch.randn(b, 4, lat, lat, generator=gen), noise=torch.randn(b, 4, lat, lat, generator=gen),
+                                   t=torch.randint(20, 980, (b,), generator=gen),
+                                   cond=torch.randn(b, cfg.text_len, cfg.cross_attention_dim, generator=gen).to(bf).float(),
+                                   uncond=torch.randn(1, cfg.text_len, cfg.cross_attention_dim, generator=gen).to(bf).float().expand(b, -1, -1).contiguous()))
+    return inputs
+
+
+def iteration_hp(b, rounds, lr, kappa, alpha):
+    return dict(alpha=alpha, kappa1=kappa, kappa2=kappa, kappa4=kappa, ls=1.0, lsg=1.0, batch_gpu_total=b * rounds, lr=lr, glr=lr,
+                betas=(0.0, 0.999), eps=1e-8, init_t=625, batch_size=b * rounds, ema_halflife_kimg=50, ema_rampup_ratio=0.05)
+
+
+SAMPLE_STRIDE = 431      # the stored full-size oracle iterations keep every 431st entry of each parameter tensor (all of a small one)
+
+
+def sample_index(numel):
+    return torch.arange(0, numel, SAMPLE_STRIDE) if numel > 10 * SAMPLE_STRIDE else torch.arange(numel)
+
+
+# (name, architecture, latent size, batch, kappa): the full-size iterations whose oracle result is STORED (tests/golden/fullsize_*.npz)
+FULLSIZE_CASES = {
+    'sd15_k45_b1': ('sd15', 64, 1, 4.5),
+    'sd21_k2_b1': ('sd21-base', 64, 1, 2.0),
+    'sd21_k2_768': ('sd21-base', 96, 1, 2.0),
+    'sd15_k15_b2': ('sd15', 64, 2, 1.5),
+    'sd21_k15_b1': ('sd21-base', 64, 1, 1.5),
+}
+FULLSIZE_LR, FULLSIZE_SEED, FULLSIZE_EMA_NAMES = 1e-6, 5, ('conv_in.weight', 'conv_out.bias')

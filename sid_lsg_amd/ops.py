@@ -139,10 +139,32 @@ _wgrad_rr = {}
 _wgrad_join_armed = set()
 
 
+# SIDLSG_WGRAD_PRIO=low: the weight-gradient streams are created with the LOWEST HIP stream priority (hipStreamCreateWithPriority; torch
+# itself only offers priorities at or above its default stream's), so that the workgroup dispatcher serves the main stream -- the
+# backward-data chain, i.e. the critical path -- first and the weight gradients fill what it leaves idle.  A/B knob (profiles/r06_*prio*).
+_WGRAD_PRIO = os.environ.get('SIDLSG_WGRAD_PRIO', '')
+_hip_rt = None
+
+
+def _low_priority_stream(device):
+    global _hip_rt
+    if _hip_rt is None:
+        _hip_rt = ctypes.CDLL('libamdhip64.so')          # already in the process (torch's own runtime: same soname)
+    least, greatest = ctypes.c_int(0), ctypes.c_int(0)
+    if _hip_rt.hipDeviceGetStreamPriorityRange(ctypes.byref(least), ctypes.byref(greatest)) != 0:
+        raise RuntimeError('hipDeviceGetStreamPriorityRange failed')
+    h = ctypes.c_void_p()
+    with torch.cuda.device(device):
+        rc = _hip_rt.hipStreamCreateWithPriority(ctypes.byref(h), ctypes.c_uint(1), ctypes.c_int(least.value))      # 1 = hipStreamNonBlocking
+    if rc != 0 or not h.value:
+        raise RuntimeError(f'hipStreamCreateWithPriority failed with {rc}')
+    return torch.cuda.ExternalStream(h.value, device=device)
+
+
 def _wgrad_stream_list(device):
     key = _dev_key(device)
     if key not in _wgrad_streams:
-        lst = [torch.cuda.Stream(device=device) for _ in range(_WGRAD_NSTREAMS)]
+        lst = [(_low_priority_stream(device) if _WGRAD_PRIO == 'low' else torch.cuda.Stream(device=device)) for _ in range(_WGRAD_NSTREAMS)]
         for st in lst:
             ensure_stream_workspace(st, nbytes=(256 << 20) // _WGRAD_NSTREAMS if _WGRAD_NSTREAMS > 1 else 256 << 20)
         _wgrad_streams[key] = lst
