@@ -43,6 +43,13 @@ def make(case):
     hp = fixtures.iteration_hp(b, 1, lr, kappa, 1.0)
     hp['cur_nimg'] = 0
     inputs = fixtures.iteration_inputs(cfg_name, lat, b, 1, torch.Generator().manual_seed(fixtures.FULLSIZE_SEED))
+    if b > 1:
+        # A CFG batch of 2b samples with autograd state does not fit this container's 62 GB: the batch is evaluated as b accumulation rounds of
+        # one sample with batch_gpu_total = b -- the reference's own gradient accumulation (training/sid_training_loop.py:246-249, 389-450).  The
+        # losses are sums over samples x scale / batch_gpu_total and GroupNorm / LayerNorm / attention never mix samples, so the round losses add up
+        # to the one-round loss and the accumulated gradient is the one-round gradient (fp32 summation order aside).
+        inputs = {ph: [{k: v[i:i + 1].contiguous() for k, v in inputs[ph][0].items()} for i in range(b)] for ph in inputs}
+        hp['sum_round_losses'] = True
     out_r = sid_ref.sid_iteration_ref(nets_r, st, DDPMSchedulerRef(), inputs, hp)
     rec = dict(loss_fake=np.float64(out_r['loss_fake']), loss_G=np.float64(out_r['loss_G']), weight_checksum=cks,
                case=np.array([cfg_name, str(lat), str(b), str(kappa), str(lr)]))
@@ -67,6 +74,6 @@ def make(case):
 
 
 if __name__ == '__main__':
-    torch.set_num_threads(os.cpu_count() or 8)
+    torch.set_num_threads(min(48, os.cpu_count() or 8))      # (one OpenMP thread per core of a 256-core host crawls: 20 min without finishing one case)
     for case in (sys.argv[1:] or list(fixtures.FULLSIZE_CASES)):
         make(case)

@@ -132,6 +132,7 @@ def sid_iteration_ref(nets, opt_states, sched, inputs, hp):
     """
     G, psi, phi = nets['G'], nets['fake_score'], nets['true_score']
     out = {}
+    tot_f = tot_g = 0.0
     # ---- phase A  (sid_training_loop.py:389-462)
     psi.requires_grad_(True)
     for p in psi.parameters():
@@ -145,7 +146,10 @@ def sid_iteration_ref(nets, opt_states, sched, inputs, hp):
         loss, n = fake_score_loss_ref(nf, r['noise'], hp['ls'], hp['batch_gpu_total'])
         if n > 0:
             loss.backward()                                                           # :449-450
-    out['loss_fake'] = float(loss.detach())
+        tot_f = tot_f + float(loss.detach())
+    # hp['sum_round_losses'] (oracle/make_fullsize_fixtures.py, make_bench_oracle_reference.py): the SUM over the accumulation rounds = the loss of the
+    # same samples as one batch (the losses are sums over samples x scale / batch_gpu_total); the reference itself reports the last round's value
+    out['loss_fake'] = tot_f if hp.get('sum_round_losses') else float(loss.detach())
     psi.requires_grad_(False)
     for p, st in zip(psi.parameters(), opt_states['fake_score']):
         if p.grad is not None:
@@ -165,7 +169,8 @@ def sid_iteration_ref(nets, opt_states, sched, inputs, hp):
         loss, n = generator_loss_ref(images, y_real, y_fake, hp['alpha'], hp['lsg'], hp['batch_gpu_total'])
         if n > 0:
             loss.backward()                                                           # :532-533
-    out['loss_G'] = float(loss.detach())
+        tot_g = tot_g + float(loss.detach())
+    out['loss_G'] = tot_g if hp.get('sum_round_losses') else float(loss.detach())
     G.requires_grad_(False)
     for p, st in zip(G.parameters(), opt_states['G']):
         if p.grad is not None:
