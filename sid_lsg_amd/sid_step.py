@@ -359,6 +359,11 @@ class SiDStep:
                 # the stream they were recorded on (the backend's own) has joined a capture, taking the process down from the
                 # watchdog thread ("operation not permitted on an event last recorded in a capturing stream"; 1-2 in 10 runs
                 # of tests/test_gpu_dist.py::test_rccl_collectives_inside_the_captured_iteration without this pause).
+                # Why a pause and not a handshake: the works ARE complete, what has to happen is one pass of the watchdog's clean-up loop
+                # (ProcessGroupNCCL::watchdogHandler sleeps kWatchdogThreadSleepMillis = 100 ms between passes and drops every completed
+                # work in one pass), and this torch build exposes nothing to wait for that pass: the flight recorder
+                # (_dump_nccl_trace) keeps no entries unless TORCH_NCCL_TRACE_BUFFER_SIZE was set before the group was created
+                # (tools/nccl_trace_probe.py: 0 entries on the GPU box).  0.5 s = five watchdog periods, once per captured signature.
                 import time
                 time.sleep(0.5)
             try:
