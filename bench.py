@@ -112,6 +112,10 @@ def compact_line(full):
                        'messages_per_step': _r(cm['messages_per_step'], 2), 'bytes_per_step': cm['bytes_per_step'],
                        'allreduce_algbw_GBps': _r(cm['allreduce_algbw_GBps'], 2), 'allreduce_busbw_GBps': _r(cm['allreduce_busbw_GBps'], 2),
                        'backend': cm['backend']}
+        if cm.get('expected'):
+            out['comm']['expected_allreduce_ms'] = _r(cm['expected']['allreduce_ms_per_step'], 2)
+            out['comm']['expected_exposed_ms'] = _r(cm['expected']['exposed_ms_per_step'], 2)
+            out['comm']['allreduce_ms_per_step'] = _r(cm['allreduce_ms_per_step'], 2)
     r = full.get('roofline')
     if r:
         iso = r.get('isolated') or {}
@@ -512,6 +516,16 @@ def main():
                        'allreduce_algbw_GBps': comm['algbw_GBps'], 'allreduce_busbw_GBps': comm['busbw_GBps'],
                        'backend': torch.distributed.get_backend(), 'note': 'events on the waiting stream around FlatGradReducer.wait (exposed) and on the '
                        'communication stream around every message (rate); warmup + timed iterations'}
+        # What the first multi-GPU run should see, next to what it did see: ring all-reduce of the two networks' fp32
+        # gradients, 2 (n - 1) / n x bytes over the slowest link pair; ASSUMED bus bandwidth 300 GB/s (RCCL rings over 7 x ~153 GB/s xGMI
+        # links per GPU; nobody has measured it on this pool).  Six segments per network start under the backward that produces them; the
+        # last segment (4.4 % of a network) cannot start before its backward ends: that tail is the exposed part by construction.
+        if world > 1:
+            bus = 300.0
+            tot = out['comm']['bytes_per_step'] * 2.0 * (world - 1) / world / (bus * 1e9) * 1e3
+            out['comm']['expected'] = {'assumed_busbw_GBps': bus, 'allreduce_ms_per_step': tot, 'exposed_ms_per_step': 0.044 * tot,
+                                       'hidden_if_step_ms_above': tot, 'note': 'ring model, 6 segments per network overlapped with its backward; '
+                                       'compare with allreduce_ms_per_step / comm_exposed_ms (measured)'}
     else:
         out['comm'] = None
     if teacher is not None:
