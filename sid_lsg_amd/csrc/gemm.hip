@@ -2657,7 +2657,8 @@ static bool fits31(unsigned long long bytes) { return bytes < 0x7FFFFFFFull; }
 
 // Host side of the grouped dense weight gradient.  Every job must be one the 128 x 128 direct-to-LDS kernel takes (aligned operands);
 // the split count is chosen for the GROUP: all jobs together should put ~512 blocks on the chip (whole rounds, like launch_wgrad's
-// model), each job splitting its pixel range in proportion to its own row count.
+// model): every job gets the same split count `want` = slots / (tiles of all jobs), limited by its own row count (>= 4 stages per split) and by
+// what is left of the stream's workspace for its slabs.
 static int launch_wgrad_group(WgradParams* jobs, int njobs, hipStream_t s, bool t160) {
     if (njobs < 1 || njobs > WG_GROUP) return SIDLSG_EINVAL;
     long long tiles[WG_GROUP], total_tiles = 0;
@@ -2687,8 +2688,14 @@ static int launch_wgrad_group(WgradParams* jobs, int njobs, hipStream_t s, bool 
         const long long nk = (long long)p.N * p.K;
         p.ws = nullptr;
         if (splits > 1) {
-            if (!wsl.ptr || ws_used + (long long)splits * nk * 4 > wsl.bytes || (nk & 3)) { splits = 1; mps = (p.M + WG_MB - 1) / WG_MB * WG_MB; }
-            else { p.ws = reinterpret_cast<float*>(reinterpret_cast<char*>(wsl.ptr) + ws_used); ws_used += ((long long)splits * nk * 4 + 255) / 256 * 256; }
+            // slabs that do not fit what is left of the workspace: as many splits as do fit (launch_wgrad does the same), one only when not even two fit
+            const long long fit = (wsl.ptr && !(nk & 3)) ? (wsl.bytes - ws_used) / (nk * 4) : 0;
+            if (fit < splits) {
+                splits = fit >= 2 ? (int)fit : 1;
+                mps = ((p.M + splits - 1) / splits + WG_MB - 1) / WG_MB * WG_MB;
+                splits = (p.M + mps - 1) / mps;
+            }
+            if (splits > 1) { p.ws = reinterpret_cast<float*>(reinterpret_cast<char*>(wsl.ptr) + ws_used); ws_used += ((long long)splits * nk * 4 + 255) / 256 * 256; }
         }
         p.m_per_split = mps;
         p.nsplits = splits;
