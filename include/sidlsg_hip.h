@@ -90,7 +90,8 @@ int sidlsg_wgrad_assign_bf16(const void* dY, int ldy, const void* A, int lda, fl
 /* Several dense weight gradients as ONE launch + one slab-reduction launch (round 5: the C x C projections of a transformer block each
  * need ~56 pixel splits to fill the chip alone; grouped, the group fills it with ~6 each).  jobs: HOST array of njobs <= 8 records of
  * 64 bytes  { const void* dY; const void* A; float* dW; float* dBias; int ldy, lda, M, N, K, assign; int pad[2]; }  with the meaning
- * of sidlsg_wgrad_bf16 (assign = 0) / sidlsg_wgrad_assign_bf16 (assign = 1) per record; N, K, ldy, lda % 8 == 0, 16-byte aligned operands. */
+ * of sidlsg_wgrad_bf16 (assign = 0) / sidlsg_wgrad_assign_bf16 (assign = 1) per record; N, K, ldy, lda % 8 == 0, 16-byte aligned operands.
+ * The dW of the records of one call must be DISTINCT buffers (the jobs run as one grid: two jobs on one dW would race). */
 int sidlsg_wgrad_group_bf16(const void* jobs, int njobs, void* stream);
 int sidlsg_wgrad_group160_bf16(const void* jobs, int njobs, void* stream); /* the same on 160 x 160 tiles: every N and K a multiple of 160 */
 int sidlsg_conv3x3_wgrad_assign_bf16(const void* dY, int ldy, const void* X, int ldx, float* dW, float* dBias, int B, int H, int Wd,
