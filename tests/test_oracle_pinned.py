@@ -157,3 +157,58 @@ def test_unet_layers_match_reference_networks_py(golden_dir, tag):
         gw = torch.cat([attn.to_q.weight.grad, attn.to_k.weight.grad, attn.to_v.weight.grad])
         np.testing.assert_allclose(gw.numpy(), qkv_rows_to_sd(t['g_qkv.weight'].flatten(1), heads).numpy(), rtol=5e-4, atol=5e-5)
         np.testing.assert_allclose(attn.to_out[0].weight.grad.numpy(), g[f'{tag}_g_proj.weight'].reshape(cout, cout), rtol=5e-4, atol=5e-5)
+
+
+@pytest.mark.parametrize('case', sorted(fixtures.FULLSIZE_CASES))
+def test_stored_fullsize_oracle_iterations_are_well_formed(golden_dir, case):
+    """tests/golden/fullsize_<case>.npz (oracle/make_fullsize_fixtures.py; consumed by tests/test_gpu_unet.py::_iteration_parity): the
+    record names the case it was made for, the bit-packed update signs cover exactly the sampled weights of the architecture
+    (fixtures.sample_index over named_parameters order, network built on the meta device: no weights needed), the EMA tensors
+    have the parameters' shapes, and the tiny-network counterpart of the stored quantities -- computed here from a live oracle
+    iteration -- obeys what the GPU test assumes about them (almost every sampled weight moves by more than lr / 2 under
+    Adam(beta1 = 0))."""
+    from oracle.unet_ref import CONFIGS, UNet2DConditionRef
+    fx = _load(golden_dir, f'fullsize_{case}.npz')
+    cfg_name, lat, b, kappa = fixtures.FULLSIZE_CASES[case]
+    assert [str(v) for v in fx['case']] == [cfg_name, str(lat), str(b), str(kappa), str(fixtures.FULLSIZE_LR)]
+    assert np.isfinite(float(fx['loss_fake'])) and np.isfinite(float(fx['loss_G'])) and float(fx['loss_fake']) > 0
+    with torch.device('meta'):
+        net = UNet2DConditionRef(CONFIGS[cfg_name])
+    n = sum(int(fixtures.sample_index(p.numel()).numel()) for p in net.parameters())
+    shapes = {k: tuple(p.shape) for k, p in net.named_parameters()}
+    for name in ('fake_score', 'G'):
+        assert int(fx[name + '/n']) == n
+        assert fx[name + '/sign'].shape == fx[name + '/big'].shape == ((n + 7) // 8,)
+        big = np.unpackbits(fx[name + '/big'])[:n]
+        assert big.mean() > 0.999          # beta1 = 0: |update| ~ lr for every weight with a non-zero gradient
+    for k in fixtures.FULLSIZE_EMA_NAMES:
+        assert tuple(fx['ema/' + k].shape) == shapes[k]
+    assert fx['weight_checksum'].shape == (4,)
+
+
+def test_sum_of_round_losses_equals_the_one_batch_loss():
+    """oracle/make_fullsize_fixtures.py evaluates the batch-2 case as two accumulation rounds of one sample (`sum_round_losses`): on the
+    tiny network the summed round losses and the updated weights equal the one-batch iteration's (fp32 summation order aside)."""
+    import copy
+    from oracle.scheduler_ref import DDPMSchedulerRef
+    outs = []
+    for split in (False, True):
+        phi = fixtures.make_unet('tiny').eval().requires_grad_(False)
+        psi = fixtures.make_unet('tiny', seed=77).requires_grad_(False)
+        G = copy.deepcopy(phi)
+        nets = dict(true_score=phi, fake_score=psi, G=G, G_ema=copy.deepcopy(G))
+        st = dict(fake_score=[{} for _ in psi.parameters()], G=[{} for _ in G.parameters()])
+        hp = fixtures.iteration_hp(2, 1, 2e-5, 1.5, 1.0)
+        hp['cur_nimg'] = 0
+        inputs = fixtures.iteration_inputs('tiny', 8, 2, 1, torch.Generator().manual_seed(5))
+        if split:
+            inputs = {ph: [{k: v[i:i + 1].contiguous() for k, v in inputs[ph][0].items()} for i in range(2)] for ph in inputs}
+            hp['sum_round_losses'] = True
+        out = sid_ref.sid_iteration_ref(nets, st, DDPMSchedulerRef(), inputs, hp)
+        outs.append((out, [p.detach().clone() for p in G.parameters()]))
+    (a, pa), (b2, pb) = outs
+    assert abs(a['loss_fake'] - b2['loss_fake']) <= 1e-5 * abs(a['loss_fake'])
+    assert abs(a['loss_G'] - b2['loss_G']) <= 1e-4 * abs(a['loss_fake'])
+    same = sum(int((torch.sign(x - y) == 0).sum()) for x, y in zip(pa, pb))
+    total = sum(x.numel() for x in pa)
+    assert same > 0.99 * total          # Adam(beta1 = 0) steps are +-lr: identical wherever the gradient sign is
