@@ -65,6 +65,14 @@ int sidlsg_gemm_geglu_bf16(const void* A, int lda, const void* W, void* H, int l
 int sidlsg_gemm_geglu_bwd_ok(int M, int F, int K);
 int sidlsg_gemm_geglu_bwd_bf16(const void* dOut, int lda, const void* Wt, const void* H, void* dH, int ldh, int M, int F, int K,
                                void* stream);
+/* Grouped variants of the two GEGLU fusions (two frozen networks of one shape on one stacked batch, M even: rows [0, M/2) are contracted
+ * with (W, bias) / Wt, rows [M/2, M) with (W1, bias1) / Wt1; otherwise as the single-set entry points above).  The grouped frozen pass of
+ * phase B (sid_training_loop.py:494-506: fake-score network and teacher evaluate the same images) takes its FeedForward blocks through
+ * these; its backward is the data gradient only. */
+int sidlsg_gemm_geglu_bf16_g2(const void* A, int lda, const void* W, const void* W1, void* H, int ldh, void* Y, int ldy, const float* bias,
+                              const float* bias1, int M, int N2, int K, void* stream);
+int sidlsg_gemm_geglu_bwd_bf16_g2(const void* dOut, int lda, const void* Wt, const void* Wt1, const void* H, void* dH, int ldh, int M, int F,
+                                  int K, void* stream);
 
 /* Optional fp32 scratch (device memory owned by the caller): per-split partial-sum slabs for split-K GEMMs/convs with few
  * output tiles and long K (8x8 / 16x16 stages) and for the pixel-split weight gradients (without it they fall back to

@@ -2824,6 +2824,7 @@ int sidlsg_gemm_geglu_bf16(const void* A, int lda, const void* W, void* H, int l
     if (!fits31(ab) || !fits31(wb)) return SIDLSG_EINVAL;
     p.a_bytes = (unsigned)ab; p.w_bytes = (unsigned)wb;
     SidlsgTraceScope ts(SIDLSG_FAM_GEMM, 2.0 * M * (double)N2 * K, 2.0 * ((double)M * K + (double)N2 * K + (double)M * N2 * (H ? 1.5 : 0.5)));
+    if (p8_geglu_takes(p)) return launch_gemm_p8_geglu<1>(p, (hipStream_t)stream);
     return launch_gemm_v3<0>(p, (hipStream_t)stream);
 }
 
@@ -2848,6 +2849,41 @@ int sidlsg_gemm_geglu_bwd_bf16(const void* dOut, int lda, const void* Wt, const 
     if (!fits31(ab) || !fits31(wb)) return SIDLSG_EINVAL;
     p.a_bytes = (unsigned)ab; p.w_bytes = (unsigned)wb;
     SidlsgTraceScope ts(SIDLSG_FAM_GEMM, 2.0 * M * (double)F * K, 2.0 * ((double)M * K + (double)F * K + 4.0 * (double)M * F));
+    if (p8_geglu_takes(p)) return launch_gemm_p8_geglu<2>(p, (hipStream_t)stream);
+    return launch_gemm_v3<0>(p, (hipStream_t)stream);
+}
+
+// Grouped variants of the two GEGLU fusions (round 6: the grouped frozen pass of phase B -- 64 of an iteration's 144 sample-passes -- had fallen back
+// to the unfused chain: grouped FF-in GEMM, stand-alone GEGLU, grouped FF-out dgrad, stand-alone GEGLU backward).  Rows [0, M/2) use (W, bias) / Wt,
+// rows [M/2, M) use (W1, bias1) / Wt1; everything else as in the single-set entry points (group_select narrows each block to its set, the epilogues
+// only see the block's rows).
+int sidlsg_gemm_geglu_bf16_g2(const void* A, int lda, const void* W, const void* W1, void* H, int ldh, void* Y, int ldy, const float* bias,
+                              const float* bias1, int M, int N2, int K, void* stream) {
+    if (!sidlsg_gemm_geglu_ok(M, N2, K) || !Y || (ldy & 7) || (ldh & 7) || (lda & 7) || (M & 1) || !W1 || (bias != nullptr) != (bias1 != nullptr)) return SIDLSG_EINVAL;
+    GemmParams p{};
+    p.A = (const bf16*)A; p.W = (const bf16*)W; p.C = H; p.bias = bias; p.Y = (bf16*)Y; p.ldy = ldy; p.geglu = N2 / 2;
+    p.W1 = (const bf16*)W1; p.bias1 = bias1; p.Mg = M / 2;
+    p.ldrv = N2; p.M = M; p.N = N2; p.K = K; p.lda = lda; p.ldc = ldh; p.rows_per_batch = 1; p.alpha = 1.f; p.Mtot = M;
+    if (!A || !W) return SIDLSG_EINVAL;
+    const unsigned long long ab = ((unsigned long long)(M - 1) * lda + K) * 2ull, wb = (unsigned long long)N2 * K * 2ull;
+    if (!fits31(ab) || !fits31(wb)) return SIDLSG_EINVAL;
+    p.a_bytes = (unsigned)ab; p.w_bytes = (unsigned)wb;
+    SidlsgTraceScope ts(SIDLSG_FAM_GEMM, 2.0 * M * (double)N2 * K, 2.0 * ((double)M * K + 2.0 * (double)N2 * K + (double)M * N2 * (H ? 1.5 : 0.5)));
+    if (p8_geglu_takes(p)) return launch_gemm_p8_geglu<1>(p, (hipStream_t)stream);
+    return launch_gemm_v3<0>(p, (hipStream_t)stream);
+}
+int sidlsg_gemm_geglu_bwd_bf16_g2(const void* dOut, int lda, const void* Wt, const void* Wt1, const void* H, void* dH, int ldh, int M, int F, int K,
+                                  void* stream) {
+    if (!sidlsg_gemm_geglu_bwd_ok(M, F, K) || !dOut || !Wt || !Wt1 || !H || !dH || (ldh & 7) || (lda & 7) || ldh < 2 * F || (M & 1)) return SIDLSG_EINVAL;
+    GemmParams p{};
+    p.A = (const bf16*)dOut; p.W = (const bf16*)Wt; p.C = nullptr; p.Y = (bf16*)dH; p.Hin = (const bf16*)H; p.ldy = ldh; p.geglu_bwd = F;
+    p.W1 = (const bf16*)Wt1; p.Mg = M / 2;
+    p.ldrv = F; p.M = M; p.N = F; p.K = K; p.lda = lda; p.ldc = F; p.rows_per_batch = 1; p.alpha = 1.f; p.Mtot = M;
+    const unsigned long long ab = ((unsigned long long)(M - 1) * lda + K) * 2ull, wb = (unsigned long long)F * K * 2ull;
+    if (!fits31(ab) || !fits31(wb)) return SIDLSG_EINVAL;
+    p.a_bytes = (unsigned)ab; p.w_bytes = (unsigned)wb;
+    SidlsgTraceScope ts(SIDLSG_FAM_GEMM, 2.0 * M * (double)F * K, 2.0 * ((double)M * K + 2.0 * (double)F * K + 4.0 * (double)M * F));
+    if (p8_geglu_takes(p)) return launch_gemm_p8_geglu<2>(p, (hipStream_t)stream);
     return launch_gemm_v3<0>(p, (hipStream_t)stream);
 }
 

@@ -31,7 +31,8 @@
 // through the scalar offset + halo masks, "transposed" MFMA so that a lane owns 8 consecutive output channels), same K order
 // (conv: channel chunk outer, tap inner) and the same MFMA operand placement: an output element is accumulated in exactly
 // the order of gemm_v3_kernel -- without split-K the two kernels are bit-identical.
-// Takes: N % (80 WN) == 0, K % 64 == 0, dense rows or conv with Cin % 64 == 0 and no fused upsampling; no GEGLU epilogues.
+// Takes: N % (80 WN) == 0, K % 64 == 0, dense rows or conv with Cin % 64 == 0 and no fused upsampling; the GEGLU fusions through their own two
+// instantiations of the 256 x 320 configuration (p8_epilogue_geglu / _bwd below).
 template <int CFG>
 struct P8 {
     static constexpr int WN = CFG ? 4 : 2;
@@ -203,7 +204,134 @@ DEVFN void p8_epilogue(const GemmParams& p, f32x4 (&acc)[5][4 * (CFG ? 2 : 1)], 
     else p8_epilogue_t<CFG, 3>(p, acc, img, m0, n0, wr, wn0, li, lg, tid);
 }
 
-template <int MODE, int CFG>   // MODE 0 dense rows, 1 conv3x3 (Cin % 64 == 0, no upsampling)
+// ---- GEGLU epilogues of the 256 x 320 configuration (round 6, late): the transformer FeedForward of the grouped frozen pass and of the batch-16 passes are
+// the long dense launches of an iteration, and the v3-only fusions (sidlsg_gemm_geglu_bf16 / _bwd_bf16) kept them off these kernels.  Same pass structure as
+// p8_epilogue_t (accumulators -> fp32 LDS image, 64 rows per pass, row-major finish, every access branch-free through buffer descriptors); same arithmetic and
+// rounding points as the v3 epilogues (gemm.hip): h = bf16(acc * alpha + bias), y = bf16(a * gelu(g)) from the ROUNDED a, g; dy = bf16(acc * alpha).
+// Forward: the tile's 320 columns are 160 "a" features [160 nt, +160) and the SAME 160 features of the gate half (W rows F + ...: see the loader), so a row of the
+// image holds both operands of its 160 outputs.  Chunks of the a half store y and h[:, f]; chunks of the gate half store h[:, F + f] (a descriptor of zero records
+// when the caller keeps no h: those stores are dropped).
+DEVFN void p8_epilogue_geglu(const GemmParams& p, f32x4 (&acc)[5][8], float* img, int m0, int nt, int wr, int wn0, int li, int lg, int tid) {
+    constexpr int BN = 320, HB = 160, LDI = BN + 4, ROWS = 64, CPR = BN / 8, NCH = ROWS * CPR / 512, NPASS = 4;
+    float* sbias = img + ROWS * LDI;
+    const int F = p.geglu;
+    const float* __restrict__ bias = p.bias;
+    bf16* H = reinterpret_cast<bf16*>(p.C);
+    const __amdgpu_buffer_rsrc_t rh = __builtin_amdgcn_make_buffer_rsrc(H ? H : p.Y, 0, H ? (int)(((long long)(p.M - 1) * p.ldc + p.N) * 2) : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(p.Y, 0, (int)(((long long)(p.M - 1) * p.ldy + F) * 2), 0x00020000);
+    for (int c = tid; c < BN / 4; c += 512) {
+        const int col = c * 4;
+        const int gcol = col < HB ? nt * HB + col : F + nt * HB + (col - HB);
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        *reinterpret_cast<f32x4*>(sbias + col) = bias ? *reinterpret_cast<const f32x4*>(bias + gcol) : z;
+    }
+    int ccol[NCH], clr[NCH];
+#pragma unroll
+    for (int i = 0; i < NCH; i++) {
+        const int c = tid + i * 512;
+        clr[i] = c / CPR;
+        ccol[i] = (c - clr[i] * CPR) * 8;
+    }
+#pragma unroll
+    for (int pass = 0; pass < NPASS; pass++) {
+        if (pass) __syncthreads();
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const int mi = 2 * pass + h;
+            float* row = img + (wr * 32 + h * 16 + li) * LDI + wn0;
+#pragma unroll
+            for (int ni = 0; ni < 5; ni++)
+                *reinterpret_cast<f32x4*>(row + (ni < 4 ? 32 * (ni >> 1) + lg * 8 + (ni & 1) * 4 : 64 + lg * 4)) = acc[ni][mi];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < NCH; i++) {
+            const int lr = clr[i], col = ccol[i];
+            const int m = m0 + (pass >> 1) * 128 + (lr >> 5) * 64 + (pass & 1) * 32 + (lr & 31);
+            const bool ok = m < p.M, gate = col >= HB;
+            const int ca = gate ? col - HB : col;
+            const float* ip = img + lr * LDI + ca;
+            bf16x8 av, gv, yv;
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                av[e] = f2bf(ip[e] * p.alpha + sbias[ca + e]);
+                gv[e] = f2bf(ip[HB + e] * p.alpha + sbias[HB + ca + e]);
+                yv[e] = f2bf(bf2f(av[e]) * gelu_t<bf16>(bf2f(gv[e])));
+            }
+            const int f = nt * HB + ca;
+            const unsigned oy = (ok && !gate) ? ((unsigned)m * (unsigned)p.ldy + f) * 2u : OOB;
+            const unsigned oa = (ok && !gate) ? ((unsigned)m * (unsigned)p.ldc + f) * 2u : OOB;
+            const unsigned og = (ok && gate) ? ((unsigned)m * (unsigned)p.ldc + F + f) * 2u : OOB;
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, yv), ry, oy, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, av), rh, oa, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, gv), rh, og, 0, 0);
+        }
+    }
+}
+// Backward: the tile is dy[:, n0 .. n0 + 320) = dOut W2 (never stored); the epilogue reads h[:, n] / h[:, F + n] (requested one pass ahead, before the previous
+// pass's stores: one in-order memory counter) and writes dH[:, n] = dy * gelu(g), dH[:, F + n] = dy * a * gelu'(g).
+DEVFN void p8_epilogue_geglu_bwd(const GemmParams& p, f32x4 (&acc)[5][8], float* img, int m0, int n0, int wr, int wn0, int li, int lg, int tid) {
+    constexpr int BN = 320, LDI = BN + 4, ROWS = 64, CPR = BN / 8, NCH = ROWS * CPR / 512, NPASS = 4;
+    const int F = p.geglu_bwd;
+    const int bytes = (int)(((long long)(p.M - 1) * p.ldy + 2 * F) * 2);
+    const __amdgpu_buffer_rsrc_t rhin = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(p.Hin), 0, bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rdh = __builtin_amdgcn_make_buffer_rsrc(p.Y, 0, bytes, 0x00020000);
+    int ccol[NCH], clr[NCH];
+#pragma unroll
+    for (int i = 0; i < NCH; i++) {
+        const int c = tid + i * 512;
+        clr[i] = c / CPR;
+        ccol[i] = (c - clr[i] * CPR) * 8;
+    }
+    auto chunk_off = [&](int pass, int i) -> unsigned {
+        const int lr = clr[i];
+        const int m = m0 + (pass >> 1) * 128 + (lr >> 5) * 64 + (pass & 1) * 32 + (lr & 31);
+        return m < p.M ? ((unsigned)m * (unsigned)p.ldy + n0 + ccol[i]) * 2u : OOB;
+    };
+    bf16x8 ha[2][NCH], hg[2][NCH];
+    auto request = [&](int pass, bf16x8 (&a)[NCH], bf16x8 (&g)[NCH]) {
+#pragma unroll
+        for (int i = 0; i < NCH; i++) {
+            const unsigned off = chunk_off(pass, i);
+            a[i] = buf_ld8(rhin, off);
+            g[i] = buf_ld8(rhin, off + (unsigned)F * 2u);      // (an out-of-range offset stays out of range)
+        }
+    };
+    request(0, ha[0], hg[0]);
+#pragma unroll
+    for (int pass = 0; pass < NPASS; pass++) {
+        if (pass) __syncthreads();
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const int mi = 2 * pass + h;
+            float* row = img + (wr * 32 + h * 16 + li) * LDI + wn0;
+#pragma unroll
+            for (int ni = 0; ni < 5; ni++)
+                *reinterpret_cast<f32x4*>(row + (ni < 4 ? 32 * (ni >> 1) + lg * 8 + (ni & 1) * 4 : 64 + lg * 4)) = acc[ni][mi];
+        }
+        __syncthreads();
+        if (pass + 1 < NPASS) request(pass + 1, ha[(pass + 1) & 1], hg[(pass + 1) & 1]);
+#pragma unroll
+        for (int i = 0; i < NCH; i++) {
+            const float* ip = img + clr[i] * LDI + ccol[i];
+            const bf16x8 av = ha[pass & 1][i], gv = hg[pass & 1][i];
+            bf16x8 da, dg;
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                float gl, gd;
+                gelu_pair_t<bf16>(bf2f(gv[e]), gl, gd);
+                const float d = bf2f(f2bf(ip[e] * p.alpha));
+                da[e] = f2bf(d * gl);
+                dg[e] = f2bf(d * bf2f(av[e]) * gd);
+            }
+            const unsigned off = chunk_off(pass, i);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, da), rdh, off, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, dg), rdh, off + (unsigned)F * 2u, 0, 0);
+        }
+    }
+}
+
+template <int MODE, int CFG, int EPI = 0>   // MODE 0 dense rows, 1 conv3x3 (Cin % 64 == 0, no upsampling); EPI 1 / 2: GEGLU forward / backward epilogue (dense, CFG 1)
 DEVFN void gemm_p8_body(GemmParams& p) {
     using G = P8<CFG>;
     constexpr int BM = G::BM, BN = G::BN, MT = G::MT, NT = G::NT, R = G::R, STAGE = G::STAGE;
@@ -280,7 +408,8 @@ DEVFN void gemm_p8_body(GemmParams& p) {
     for (int j = 0; j < G::NWJ; j++) {
         const int r = (j * 8 + wave) * 8 + lrow;
         const int kcs = lslot ^ wsw80(r);
-        const int n = n0 + r;
+        // (EPI 1, fused GEGLU: the tile's W rows are 160 "a" rows [160 nt, +160) and the same 160 rows of the gate half, F rows further down)
+        const int n = EPI == 1 ? (r < 160 ? nt * 160 + r : p.geglu + nt * 160 + (r - 160)) : n0 + r;
         boff[j] = (r < BN && n < p.N) ? ((unsigned)n * (unsigned)p.K + kcs * 8) * 2u : OOB;
     }
     const int kt_begin = p.kt_per_split ? split * p.kt_per_split : 0;
@@ -450,13 +579,53 @@ DEVFN void gemm_p8_body(GemmParams& p) {
         }
         return;
     }
-    p8_epilogue<CFG>(p, acc, reinterpret_cast<float*>(smem), m0, n0, wr, wn0, li, lg, tid);
+    if constexpr (EPI == 1) p8_epilogue_geglu(p, acc, reinterpret_cast<float*>(smem), m0, nt, wr, wn0, li, lg, tid);
+    else if constexpr (EPI == 2) p8_epilogue_geglu_bwd(p, acc, reinterpret_cast<float*>(smem), m0, n0, wr, wn0, li, lg, tid);
+    else p8_epilogue<CFG>(p, acc, reinterpret_cast<float*>(smem), m0, n0, wr, wn0, li, lg, tid);
 }
 
 template <int MODE>
 __global__ __launch_bounds__(512, 1) void gemm_p8s_kernel(GemmParams p) { gemm_p8_body<MODE, 0>(p); }
 template <int MODE>
 __global__ __launch_bounds__(512, 1) void gemm_p8w_kernel(GemmParams p) { gemm_p8_body<MODE, 1>(p); }
+
+// (plain kernels: a kernel template with a further non-type parameter got no host stub from hipcc 7.2)
+__global__ __launch_bounds__(512, 1) void gemm_p8w_geglu_kernel(GemmParams p) { gemm_p8_body<0, 1, 1>(p); }
+__global__ __launch_bounds__(512, 1) void gemm_p8w_geglu_bwd_kernel(GemmParams p) { gemm_p8_body<0, 1, 2>(p); }
+
+// The GEGLU fusions on the 256 x 320 configuration: admission (shapes, alignment, 31-bit descriptors) and the cost model of gemm.hip::p8_rule without
+// K splits (the epilogues finish their tile).  SIDLSG_P8_GEGLU=0: the v3 kernels as before (A/B switch).
+static bool p8_geglu_takes(const GemmParams& p) {
+    static const bool on = !(getenv("SIDLSG_P8_GEGLU") && atoi(getenv("SIDLSG_P8_GEGLU")) == 0);
+    const int F = p.geglu ? p.geglu : p.geglu_bwd;
+    if (!on || !F || (p.geglu && p.geglu_bwd) || F % 160 || p.N % 320 || p.K % BK || p.kt_per_split || p.wscale || p.res || p.rowvec || p.flags) return false;
+    if ((p.ldy & 7) || ((uintptr_t)p.Y & 15) || (p.lda & 7) || ((uintptr_t)p.A & 15)) return false;
+    if (p.geglu) {
+        if ((p.C && ((p.ldc & 7) || ((uintptr_t)p.C & 15))) || (p.bias && ((uintptr_t)p.bias & 15)) || (p.Mg && p.bias1 && ((uintptr_t)p.bias1 & 15))) return false;
+        if (((long long)(p.M - 1) * p.ldc + p.N) * 2 >= 0x7FFFFFFFll || ((long long)(p.M - 1) * p.ldy + F) * 2 >= 0x7FFFFFFFll) return false;
+    } else {
+        if (p.bias || !p.Hin || ((uintptr_t)p.Hin & 15) || ((long long)(p.M - 1) * p.ldy + 2 * F) * 2 >= 0x7FFFFFFFll) return false;
+    }
+    const int nk = p.K / BK;
+    const long long t3 = (long long)m_tiles_rt(p, 128) * (p.N / 160), t8 = (long long)m_tiles_rt(p, 256) * (p.N / 320);
+    const double v3_us = (double)((t3 + 511) / 512) * (11.0 + 1.03 * nk), p8_us = (double)((t8 + 255) / 256) * (16.0 + 1.61 * nk);
+    return p8_us < v3_us * 0.97;
+}
+template <int EPI>
+static int launch_gemm_p8_geglu(const GemmParams& p, hipStream_t s) {
+    using G = P8<1>;
+    const int tiles = m_tiles_rt(p, G::BM) * (p.N / G::BN);
+    static bool attr_done = false;
+    auto kern = EPI == 1 ? &gemm_p8w_geglu_kernel : &gemm_p8w_geglu_bwd_kernel;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
+        attr_done = true;
+    }
+    GemmParams q = p;
+    q.group_m = 4;
+    SIDLSG_LAUNCH(kern, dim3(tiles), dim3(G::NTH), (size_t)G::LDS_BYTES, s, q);
+    return sidlsg_last_error();
+}
 
 // admission: what the p8 kernels take at all (the dispatcher adds the tile-count rule)
 template <int MODE>

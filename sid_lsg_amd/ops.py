@@ -1317,8 +1317,71 @@ class _GegluLinear(torch.autograd.Function):
         return dh, None, None, None, None, None, dres
 
 
+_FF_G2 = os.environ.get('SIDLSG_FF_G2', '1') != '0'      # A/B: the grouped pass's FeedForward as one node with the fused GEGLU kernels
+
+
+class _FeedForwardG2(torch.autograd.Function):
+    """The FeedForward block of the GROUPED frozen pass (two networks, stacked batch) as ONE autograd node over the grouped forms of the two
+    GEGLU fusions: forward = sidlsg_gemm_geglu_bf16_g2 (FF-in projection + gating in one kernel; h is written only when a backward will need
+    it) where the fused kernel pays -- K >= 640 with h kept, every admissible shape without -- else grouped GEMM + sidlsg_geglu_fwd, then the
+    grouped FF-out GEMM (+ bias + residual); backward (data gradient only: both networks are frozen) = sidlsg_gemm_geglu_bwd_bf16_g2 (FF-out
+    data gradient with the GEGLU derivative in its epilogue: dy [M, F] is neither written nor re-read) and the grouped FF-in data gradient.
+    Until round 6 this pass -- 64 of an iteration's 144 sample-passes -- ran the unfused chain (grouped GEMMs + stand-alone GEGLU kernels),
+    because the fusions only existed for single weight sets."""
+
+    @staticmethod
+    def forward(ctx, x, b1, w1_16, w1_16t, b2, w2_16, w2_16t, res, keep_h):
+        _chk(x, BF16)
+        M, K = x.shape
+        N2 = w1_16[0].shape[0]
+        F = N2 // 2
+        ensure_workspace(x.device)
+        y = torch.empty((M, F), device=x.device, dtype=BF16)
+        h = None
+        if x.is_contiguous() and lib.sidlsg_gemm_geglu_ok.raw(M, N2, K) and (not keep_h or K >= _GEGLU_FUSE_MIN_K):
+            h = torch.empty((M, N2), device=x.device, dtype=BF16) if keep_h else None
+            lib.sidlsg_gemm_geglu_bf16_g2(_p(x), x.stride(0), _p(w1_16[0]), _p(w1_16[1]), _p(h), N2, _p(y), F, _p(b1[0]), _p(b1[1]), M, N2, K, _s())
+        else:
+            h = gemm(x, w1_16, bias=b1)
+            lib.sidlsg_geglu_fwd(_p(h), _p(y), M, F, _s())
+            if not keep_h:
+                h = None
+        out = gemm(y, w2_16, bias=b2, res=res)
+        ctx.save_for_backward(h)
+        ctx.ops = (w1_16t, w2_16t)
+        ctx.has_res = res is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (h,) = ctx.saved_tensors
+        w1_16t, w2_16t = ctx.ops
+        dout = dout.contiguous()
+        if dout.dtype != BF16:
+            dout = dout.to(BF16)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            M, F2 = h.shape
+            Kd = dout.shape[1]
+            dh = torch.empty_like(h)
+            if lib.sidlsg_gemm_geglu_bwd_ok.raw(M, F2 // 2, Kd):
+                lib.sidlsg_gemm_geglu_bwd_bf16_g2(_p(dout), dout.stride(0), _p(w2_16t[0]), _p(w2_16t[1]), _p(h), _p(dh), F2, M, F2 // 2, Kd, _s())
+            else:
+                dy = gemm(dout, w2_16t)
+                lib.sidlsg_geglu_bwd(_p(h), _p(dy), _p(dh), M, F2 // 2, _s())
+            dx = gemm(dh, w1_16t)
+        dres = dout if (ctx.has_res and ctx.needs_input_grad[7]) else None
+        return dx, None, None, None, None, None, None, dres, None
+
+
 def feed_forward(x, w1, b1, w1_16, w1_16t, w2, b2, w2_16, w2_16t, res=None):
     """diffusers FeedForward (GEGLU projection -> Linear) + the block's residual: out = GEGLU(x W1^T + b1) W2^T + b2 + res."""
+    if (_dual is not None and _FF_G2 and x.dtype == BF16 and isinstance(w1_16, torch.Tensor) and w1_16.dtype == BF16
+            and isinstance(w2_16, torch.Tensor) and w2_16.dtype == BF16 and b1 is not None and b2 is not None and w1_16.shape[0] % 2 == 0
+            and x.shape[0] % 2 == 0):
+        _frozen(_pair(w1), _pair(b1), _pair(w2), _pair(b2))
+        keep_h = torch.is_grad_enabled() and x.requires_grad      # (grad mode is off inside Function.forward: decided here)
+        return _FeedForwardG2.apply(x, _pair(b1), _pair(w1_16), _pair(w1_16t), _pair(b2), _pair(w2_16), _pair(w2_16t), res, keep_h)
     fused_bwd = (_dual is None and x.dtype == BF16 and torch.is_grad_enabled() and isinstance(w2_16, torch.Tensor) and w2_16.dtype == BF16
                  and isinstance(w1_16, torch.Tensor)
                  and lib.sidlsg_gemm_geglu_bwd_ok.raw(x.shape[0], w2_16.shape[1], w2_16.shape[0]))

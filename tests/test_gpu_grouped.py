@@ -8,6 +8,7 @@ block.  What is pinned:
     and within one bf16 rounding where the larger grid changes the split-K decision;
   * network: HipUNet2DCondition.forward_pair == two forward_nhwc calls, forward and input gradients;
   * step: SiDStep with the grouped pass == SiDStep with the two-stream path (losses and updated weights)."""
+import contextlib
 import copy
 import os
 
@@ -132,6 +133,50 @@ def test_grouped_layernorm_equals_two_launches(dev, rows_h, C):
         ys.append(yh.detach())
         dxs.append(xh.grad)
     assert torch.equal(y.detach(), torch.cat(ys)) and torch.equal(xg.grad, torch.cat(dxs)), 'row-wise op: must be bit-equal'
+
+
+# (rows per half, model width C): FeedForward = GEGLU(x W1^T + b1) W2^T + b2 + res with W1 [8 C, C], W2 [C, 4 C].  16384 x 640 / 4096 x 1280: both fused
+# kernels admitted (32x32 / 16x16 stages at batch 16); 32768 x 320: forward fusion only without h, fused backward; 300 x 320: neither (few tiles)
+@pytest.mark.parametrize('Mh,C', [(16384, 640), (4096, 1280), (32768, 320), (300, 320)])
+@pytest.mark.parametrize('grad', [True, False])
+def test_grouped_feed_forward_equals_two_single_passes(dev, Mh, C, grad):
+    """ops.feed_forward inside dual_networks (one node over sidlsg_gemm_geglu_bf16_g2 / sidlsg_gemm_geglu_bwd_bf16_g2, ops._FeedForwardG2) against
+    the two frozen single-set passes on the halves of the stacked batch: output and input gradient; also against the unfused grouped chain
+    (SIDLSG_FF_G2=0 path: grouped GEMMs + stand-alone GEGLU kernels), which it replaced."""
+    from sid_lsg_amd import ops
+    P = lambda t: torch.nn.Parameter(t, requires_grad=False)      # noqa: E731
+    sets = []
+    for s0 in (10, 20):
+        w1, w2 = rnd(8 * C, C, seed=s0, scale=C ** -0.5, dev=dev), rnd(C, 4 * C, seed=s0 + 1, scale=(4 * C) ** -0.5, dev=dev)
+        b1, b2 = rnd(8 * C, seed=s0 + 2, dev=dev).float(), rnd(C, seed=s0 + 3, dev=dev).float()
+        sets.append(dict(w1=P(w1.float()), b1=P(b1), w1_16=w1, w1_16t=w1.t().contiguous(), w2=P(w2.float()), b2=P(b2), w2_16=w2, w2_16t=w2.t().contiguous()))
+    a, b = sets
+    pmap = {id(a[k]): b[k] for k in a}
+    x, res, dout = rnd(2 * Mh, C, seed=1, dev=dev), rnd(2 * Mh, C, seed=2, dev=dev), rnd(2 * Mh, C, seed=3, dev=dev)
+
+    def run(xin, rin, st, dual, dslice):
+        xg, rg = xin.clone().requires_grad_(grad), rin.clone().requires_grad_(grad)
+        ctxm = ops.dual_networks(pmap) if dual else contextlib.nullcontext()
+        with torch.set_grad_enabled(grad), ctxm:
+            out = ops.feed_forward(xg, st['w1'], st['b1'], st['w1_16'], st['w1_16t'], st['w2'], st['b2'], st['w2_16'], st['w2_16t'], rg)
+        if grad:
+            (out.float() * dout[dslice].float()).sum().backward()
+        return out.detach(), (xg.grad, rg.grad) if grad else (None, None)
+    full = slice(0, 2 * Mh)
+    got, (gx, gr) = run(x, res, a, True, full)
+    parts = [run(x[sl], res[sl], st, False, sl) for sl, st in ((slice(0, Mh), a), (slice(Mh, 2 * Mh), b))]
+    ref = torch.cat([p[0] for p in parts])
+    msg = [f'out {same_or_close(got, ref, "feed-forward output")}']
+    if grad:
+        msg.append(f'dx {same_or_close(gx, torch.cat([p[1][0] for p in parts]), "feed-forward dx")}')
+        assert torch.equal(gr, dout), 'the residual gradient is the output gradient'
+    saved, ops._FF_G2 = ops._FF_G2, False
+    try:
+        old, (ox, _) = run(x, res, a, True, full)
+    finally:
+        ops._FF_G2 = saved
+    msg.append(f'vs unfused grouped chain: out {same_or_close(got, old, "fused vs unfused")}' + (f', dx {same_or_close(gx, ox, "fused vs unfused dx")}' if grad else ''))
+    print(f'feed-forward 2 x {Mh} x {C} grad={grad}: ' + '; '.join(msg))
 
 
 @pytest.mark.parametrize('cfg_name,lat,B', [('tiny', 8, 2), ('tiny40', 16, 4), ('tiny21', 16, 2)])
