@@ -209,10 +209,14 @@ DEVFN void p8_epilogue(const GemmParams& p, f32x4 (&acc)[5][4 * (CFG ? 2 : 1)], 
 // p8_epilogue_t (accumulators -> fp32 LDS image, 64 rows per pass, row-major finish, every access branch-free through buffer descriptors); same arithmetic and
 // rounding points as the v3 epilogues (gemm.hip): h = bf16(acc * alpha + bias), y = bf16(a * gelu(g)) from the ROUNDED a, g; dy = bf16(acc * alpha).
 // Forward: the tile's 320 columns are 160 "a" features [160 nt, +160) and the SAME 160 features of the gate half (W rows F + ...: see the loader), so a row of the
-// image holds both operands of its 160 outputs.  Chunks of the a half store y and h[:, f]; chunks of the gate half store h[:, F + f] (a descriptor of zero records
-// when the caller keeps no h: those stores are dropped).
+// image holds both operands of its 160 outputs: a thread owns 8 features of a row with BOTH operands (the first version walked all 40 chunks of a row and
+// evaluated the GELU in the gate-half lanes as well: +17-20 % on the K = 320 forward) and stores y, h[:, f] and h[:, F + f] (a descriptor of zero records when the
+// caller keeps no h: those stores are dropped).
 DEVFN void p8_epilogue_geglu(const GemmParams& p, f32x4 (&acc)[5][8], float* img, int m0, int nt, int wr, int wn0, int li, int lg, int tid) {
-    constexpr int BN = 320, HB = 160, LDI = BN + 4, ROWS = 64, CPR = BN / 8, NCH = ROWS * CPR / 512, NPASS = 4;
+    constexpr int BN = 320, HB = 160, LDI = BN + 4, ROWS = 64, NPASS = 4;
+    constexpr int PPR = HB / 8;                          // (a, gate) chunk PAIRS per image row: a thread owns 8 features of a row, both operands
+    constexpr int NPAIR = ROWS * PPR;                    // 1280 per pass = 2.5 per thread: three branch-free rounds, the last one half masked
+    constexpr int NIT = (NPAIR + 511) / 512;
     float* sbias = img + ROWS * LDI;
     const int F = p.geglu;
     const float* __restrict__ bias = p.bias;
@@ -225,12 +229,15 @@ DEVFN void p8_epilogue_geglu(const GemmParams& p, f32x4 (&acc)[5][8], float* img
         const f32x4 z = {0.f, 0.f, 0.f, 0.f};
         *reinterpret_cast<f32x4*>(sbias + col) = bias ? *reinterpret_cast<const f32x4*>(bias + gcol) : z;
     }
-    int ccol[NCH], clr[NCH];
+    int plr[NIT], pca[NIT];
+    bool pok[NIT];
 #pragma unroll
-    for (int i = 0; i < NCH; i++) {
+    for (int i = 0; i < NIT; i++) {
         const int c = tid + i * 512;
-        clr[i] = c / CPR;
-        ccol[i] = (c - clr[i] * CPR) * 8;
+        pok[i] = c < NPAIR;
+        const int cc = pok[i] ? c : NPAIR - 1;           // (masked lanes recompute the last pair; their stores are dropped)
+        plr[i] = cc / PPR;
+        pca[i] = (cc - plr[i] * PPR) * 8;
     }
 #pragma unroll
     for (int pass = 0; pass < NPASS; pass++) {
@@ -245,26 +252,28 @@ DEVFN void p8_epilogue_geglu(const GemmParams& p, f32x4 (&acc)[5][8], float* img
         }
         __syncthreads();
 #pragma unroll
-        for (int i = 0; i < NCH; i++) {
-            const int lr = clr[i], col = ccol[i];
+        for (int i = 0; i < NIT; i++) {
+            const int lr = plr[i], ca = pca[i];
             const int m = m0 + (pass >> 1) * 128 + (lr >> 5) * 64 + (pass & 1) * 32 + (lr & 31);
-            const bool ok = m < p.M, gate = col >= HB;
-            const int ca = gate ? col - HB : col;
+            const bool ok = pok[i] && m < p.M;
             const float* ip = img + lr * LDI + ca;
+            const f32x4 a0 = *reinterpret_cast<const f32x4*>(ip), a1 = *reinterpret_cast<const f32x4*>(ip + 4);
+            const f32x4 g0 = *reinterpret_cast<const f32x4*>(ip + HB), g1 = *reinterpret_cast<const f32x4*>(ip + HB + 4);
+            const f32x4 ba0 = *reinterpret_cast<const f32x4*>(sbias + ca), ba1 = *reinterpret_cast<const f32x4*>(sbias + ca + 4);
+            const f32x4 bg0 = *reinterpret_cast<const f32x4*>(sbias + HB + ca), bg1 = *reinterpret_cast<const f32x4*>(sbias + HB + ca + 4);
             bf16x8 av, gv, yv;
 #pragma unroll
             for (int e = 0; e < 8; e++) {
-                av[e] = f2bf(ip[e] * p.alpha + sbias[ca + e]);
-                gv[e] = f2bf(ip[HB + e] * p.alpha + sbias[HB + ca + e]);
+                av[e] = f2bf((e < 4 ? a0[e] : a1[e - 4]) * p.alpha + (e < 4 ? ba0[e] : ba1[e - 4]));
+                gv[e] = f2bf((e < 4 ? g0[e] : g1[e - 4]) * p.alpha + (e < 4 ? bg0[e] : bg1[e - 4]));
                 yv[e] = f2bf(bf2f(av[e]) * gelu_t<bf16>(bf2f(gv[e])));
             }
             const int f = nt * HB + ca;
-            const unsigned oy = (ok && !gate) ? ((unsigned)m * (unsigned)p.ldy + f) * 2u : OOB;
-            const unsigned oa = (ok && !gate) ? ((unsigned)m * (unsigned)p.ldc + f) * 2u : OOB;
-            const unsigned og = (ok && gate) ? ((unsigned)m * (unsigned)p.ldc + F + f) * 2u : OOB;
+            const unsigned oy = ok ? ((unsigned)m * (unsigned)p.ldy + f) * 2u : OOB;
+            const unsigned oh = ok ? ((unsigned)m * (unsigned)p.ldc + f) * 2u : OOB;
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, yv), ry, oy, 0, 0);
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, av), rh, oa, 0, 0);
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, gv), rh, og, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, av), rh, oh, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, gv), rh, oh + (unsigned)F * 2u, 0, 0);      // (out of range stays out of range)
         }
     }
 }

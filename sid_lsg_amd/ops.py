@@ -1198,7 +1198,9 @@ def geglu(h):
     return _GEGLU.apply(h)
 
 
-_GEGLU_FUSE_MIN_K = int(os.environ.get('SIDLSG_GEGLU_FUSE_MIN_K', '640'))     # A/B knob: smallest K at which the fused FF-in + GEGLU kernel is used when h is kept
+# A/B knob: smallest K at which the fused FF-in + GEGLU kernel is used when h is kept.  640 while the fusion lived on gemm_v3_kernel only (K = 320 with h: A-stationary
+# GEMM + stand-alone GEGLU 164 + 87 us against 262 us fused, batch 16); 320 since the fusion runs on the 256 x 320 kernel (225-229 us: tools/geglu_p8_bench.py, round 6)
+_GEGLU_FUSE_MIN_K = int(os.environ.get('SIDLSG_GEGLU_FUSE_MIN_K', '320'))
 
 
 class _LinearGEGLU(torch.autograd.Function):
